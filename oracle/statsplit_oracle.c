@@ -1,0 +1,247 @@
+/*
+ * statsplit_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference change-point segmenter
+ * (PyPore/cparsers.pyx, class FastStatSplit).  It exists so that tests/, the smoke
+ * check and bench.py's cpu_baseline leg have something to compare the HIP path
+ * against on machines where /root/reference is absent (the GPU box).  Nothing under
+ * pypore_amd/ may import, link or call it.
+ *
+ * Parity is PINNED: tests/test_oracle_golden.py checks every function here against
+ * golden vectors recorded from the compiled, unmodified reference
+ * (tests/golden/make_golden.py, oracle/build_reference.sh), G1..G8 of SURVEY.md 8(c).
+ *
+ * Arithmetic follows the C that Cython generates from the reference line by line:
+ * fp64 throughout, sequential prefix sums (numpy add.accumulate), pow(x,2.0) for **2,
+ * libm log, no FMA contraction (build with -ffp-contract=off, no -march).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- cparsers.pyx:55-101  FastStatSplit.__init__ (min_gain only) ------------------
+ * "Not given" follows Python truthiness: None and 0 are both falsy in the reference,
+ * so callers pass 0.0 for an omitted parameter.  Returns 0, or -1/-2/-3 for the three
+ * reference assertions (cparsers.pyx:69-76). */
+int so_min_gain(int min_width, int max_width, int window_width,
+                double min_gain_per_sample, double false_positive_rate,
+                double prior_segments_per_second, double sampling_freq,
+                double cutoff_freq, double *out)
+{
+    double fpr = false_positive_rate, sps = prior_segments_per_second, mg;
+    if (!(fpr != 0.0)) fpr = sampling_freq;               /* :64-65 */
+    if (!(sps != 0.0)) sps = sampling_freq / 2.;          /* :66-67 */
+    if (!(max_width >= min_width)) return -1;             /* :69 */
+    if (!(window_width >= 2 * min_width)) return -2;      /* :71 */
+    if (cutoff_freq != 0.0 && !(cutoff_freq <= 0.5 * sampling_freq)) return -3; /* :74-76 */
+    if (min_gain_per_sample != 0.0) {
+        mg = min_gain_per_sample * window_width;          /* :82-84 */
+    } else {
+        double k = (cutoff_freq != 0.0) ? cutoff_freq / (0.5 * sampling_freq) : 1.0; /* :89 */
+        mg = (-log(sps / (sampling_freq - sps)) - log(fpr / sampling_freq)) / k;      /* :95-97 */
+    }
+    *out = mg * 2;                                        /* :101 */
+    return 0;
+}
+
+/* ---- cparsers.pyx:110-111  c = cumsum(x), c2 = cumsum(x*x)  (sequential fp64) ---- */
+static void prefix_sums(const double *x, long n, double *c, double *c2)
+{
+    double a = 0.0, b = 0.0;
+    for (long i = 0; i < n; ++i) {
+        double v = x[i];
+        double sq = v * v;          /* np.multiply(current, current) */
+        if (i == 0) { a = v; b = sq; } else { a = a + v; b = b + sq; }
+        c[i] = a; c2[i] = b;
+    }
+}
+
+/* ---- cparsers.pyx:31-38  var_c ---------------------------------------------------- */
+static inline double var_c(int start, int end, const double *c, const double *c2)
+{
+    if (start == end) return 0;
+    if (start == 0)
+        return c2[end - 1] / end - pow(c[end - 1] / end, 2.0);
+    return (c2[end - 1] - c2[start - 1]) / (end - start)
+         - pow((c[end - 1] - c[start - 1]) / (end - start), 2.0);
+}
+
+typedef struct {
+    const double *c, *c2;
+    int min_width, max_width, window_width;
+    double min_gain;
+    long long n_evals;      /* candidate evaluations (work-amplification statistic) */
+    long long n_windows;
+} so_ctx;
+
+/* ---- cparsers.pyx:157-178  _best_split_stepwise ----------------------------------- */
+static int best_split_stepwise(so_ctx *k, int start, int end, double *scores)
+{
+    if (end - start <= 2 * k->min_width) return -1;                       /* :164 */
+    double var_summed = (end - start) * log(var_c(start, end, k->c, k->c2)); /* :166 */
+    double min_gain = k->min_gain;
+    int x = -1;
+    k->n_windows++;
+    for (int i = start + k->min_width; i < end + 1 - k->min_width; ++i) {  /* :171 */
+        double low = (i - start) * log(var_c(start, i, k->c, k->c2));
+        double high = (end - i) * log(var_c(i, end, k->c, k->c2));
+        double gain = var_summed - (low + high);
+        if (scores) scores[i] = gain;                                     /* :248 */
+        if (gain > min_gain) { min_gain = gain; x = i; }                  /* :175-177 */
+        k->n_evals++;
+    }
+    return x;
+}
+
+/* Work items for the explicit-stack in-order traversal of _recursive_split. */
+typedef struct { int kind, a, b; } so_item;    /* kind 0: CALL(a,b)  1: EMIT(a) */
+typedef struct { so_item *v; long n, cap; } so_stack;
+static int push(so_stack *s, int kind, int a, int b)
+{
+    if (s->n == s->cap) {
+        long nc = s->cap ? s->cap * 2 : 256;
+        so_item *nv = (so_item *)realloc(s->v, nc * sizeof(so_item));
+        if (!nv) return -1;
+        s->v = nv; s->cap = nc;
+    }
+    s->v[s->n].kind = kind; s->v[s->n].a = a; s->v[s->n].b = b; s->n++;
+    return 0;
+}
+
+/* ---- cparsers.pyx:180-203  _recursive_split, same output order, no C recursion ---- */
+static long recursive_split(so_ctx *k, int start0, int end0, int *out, long cap)
+{
+    so_stack st = {0, 0, 0};
+    long cnt = 0;
+    const int mw = k->min_width, maxw = k->max_width, W = k->window_width;
+    push(&st, 0, start0, end0);
+    while (st.n) {
+        so_item it = st.v[--st.n];
+        if (it.kind == 1) { if (cnt < cap) out[cnt] = it.a; cnt++; continue; }
+        int start = it.a, end = it.b, split_at = -1, forced_early = 0;
+        for (long ps = start; ps < (long)end - 2 * mw; ps += W / 2) {      /* :188 */
+            if (ps > (long)start + maxw) {                                 /* :189-191 */
+                int a = start + maxw, b = end - mw;
+                split_at = a <= b ? a : b;
+                forced_early = 1;
+                break;
+            }
+            long pe = ps + W; if (pe > end) pe = end;                      /* :193 */
+            split_at = best_split_stepwise(k, (int)ps, (int)pe, 0);        /* :194 */
+            if (split_at >= 0) break;                                      /* :195-196 */
+        }
+        if (forced_early) {                   /* [split] + rec(split, end): right side only */
+            push(&st, 0, split_at, end);
+            push(&st, 1, split_at, 0);
+            continue;
+        }
+        if (split_at == -1) {                                              /* :198-201 */
+            if (end - start <= maxw) continue;
+            int a = start + maxw, b = end - mw;
+            split_at = a <= b ? a : b;
+        }
+        push(&st, 0, split_at, end);          /* rec(start,split) + [split] + rec(split,end) */
+        push(&st, 1, split_at, 0);
+        push(&st, 0, start, split_at);
+    }
+    free(st.v);
+    return cnt;
+}
+
+/* ---- cparsers.pyx:103-118  FastStatSplit.parse -> breakpoints -----------------------
+ * Writes the sorted breakpoint list (excluding 0 and n) to out[0..cap); returns its
+ * length (may exceed cap: call again with a larger buffer), or -1 on allocation failure.
+ * stats (nullable): [0] candidate evaluations, [1] window scans. */
+long so_parse(const double *x, int n, int min_width, int max_width, int window_width,
+              double min_gain, int *out, long cap, long long *stats)
+{
+    double *c = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *c2 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (!c || !c2) { free(c); free(c2); return -1; }
+    prefix_sums(x, n, c, c2);
+    so_ctx k = { c, c2, min_width, max_width, window_width, min_gain, 0, 0 };
+    long cnt = recursive_split(&k, 0, n, out, cap);
+    if (stats) { stats[0] = k.n_evals; stats[1] = k.n_windows; }
+    free(c); free(c2);
+    return cnt;
+}
+
+/* ---- cparsers.pyx:120-155  best_single_split ------------------------------------------
+ * start=0, end=len(c)-1 (sic), i in range(2, end-2), threshold 0. */
+int so_best_single_split(const double *x, int n, double *gain_out, int *idx_out)
+{
+    double *c = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *c2 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (!c || !c2) { free(c); free(c2); return -1; }
+    prefix_sums(x, n, c, c2);
+    int end = n - 1, xbest = -1;
+    double min_gain = 0.;
+    double var_summed = end * log(var_c(0, end, c, c2));
+    for (int i = 2; i < end - 2; ++i) {
+        double low = i * log(var_c(0, i, c, c2));
+        double high = (end - i) * log(var_c(i, end, c, c2));
+        double gain = var_summed - (low + high);
+        if (gain > min_gain) { min_gain = gain; xbest = i; }
+    }
+    *gain_out = min_gain; *idx_out = xbest;
+    free(c); free(c2);
+    return 0;
+}
+
+/* ---- cparsers.pyx:205-249  score_samples(current, no_split=True) ----------------------
+ * One scan of the whole array as a single window: scores[i] = gain(i) for candidates,
+ * 0 elsewhere (np.zeros); returns the split index or -1. */
+int so_score_window(const double *x, int n, int min_width, double min_gain, double *scores)
+{
+    double *c = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *c2 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (!c || !c2) { free(c); free(c2); return -2; }
+    prefix_sums(x, n, c, c2);
+    memset(scores, 0, sizeof(double) * (size_t)n);
+    so_ctx k = { c, c2, min_width, 0, 0, min_gain, 0, 0 };
+    int r = best_split_stepwise(&k, 0, n, scores);
+    free(c); free(c2);
+    return r;
+}
+
+/* ---- core.py:209-223  Segment.mean / std(population) / min / max ------------------------
+ * Straight fp64 two-pass statistics; the test tolerance for mean/std is 1e-5 relative
+ * (numpy's pairwise summation differs in the last bits only). */
+void so_segment_stats(const double *x, const int *bounds, long nb, int n, double *stats4)
+{
+    for (long s = 0; s <= nb; ++s) {
+        int a = s == 0 ? 0 : bounds[s - 1], b = s == nb ? n : bounds[s];
+        double sum = 0, mn = INFINITY, mx = -INFINITY;
+        for (int i = a; i < b; ++i) { sum += x[i]; if (x[i] < mn) mn = x[i]; if (x[i] > mx) mx = x[i]; }
+        double mean = b > a ? sum / (b - a) : NAN, ss = 0;
+        for (int i = a; i < b; ++i) ss += (x[i] - mean) * (x[i] - mean);
+        stats4[4 * s + 0] = mean;
+        stats4[4 * s + 1] = b > a ? sqrt(ss / (b - a)) : NAN;
+        stats4[4 * s + 2] = mn; stats4[4 * s + 3] = mx;
+    }
+}
+
+/* ---- parsers.py:142-155 + :133-140  lambda_event_parser.parse with the default rules ----
+ * mask = x < threshold; tics at mask edges; one piece per [tics[i], tics[i+1]); keep a piece
+ * iff duration > min_duration and min > min_current and max < threshold.
+ * Writes (start, length) pairs; returns the number of kept events. */
+long so_lambda_events(const double *x, long n, double threshold, long min_duration,
+                      double min_current, long *starts, long *lengths, long cap)
+{
+    long cnt = 0, a = 0;
+    for (long i = 1; i <= n; ++i) {
+        int edge = (i == n) || ((x[i] < threshold) != (x[i - 1] < threshold));
+        if (!edge) continue;
+        if (n > 0) {
+            double mn = INFINITY, mx = -INFINITY;
+            for (long j = a; j < i; ++j) { if (x[j] < mn) mn = x[j]; if (x[j] > mx) mx = x[j]; }
+            if ((i - a) > min_duration && mn > min_current && mx < threshold) {
+                if (cnt < cap) { starts[cnt] = a; lengths[cnt] = i - a; }
+                cnt++;
+            }
+        }
+        a = i;
+    }
+    return cnt;
+}

@@ -1,0 +1,79 @@
+"""The CPU restatement (oracle/statsplit_oracle.c) against golden vectors recorded from the
+compiled, unmodified reference cparsers.pyx -- this is what PINS the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import case_ids, cases, input_pa, npz
+
+
+@pytest.mark.parametrize("case", cases("parse"), ids=case_ids("parse"))
+def test_parse_boundaries_bit_exact(case):
+    x = input_pa(case)
+    p = dict(case["params"])
+    mg = oracle.min_gain(**p)
+    assert repr(mg) == case["min_gain"]          # cparsers.pyx:55-101
+    b = oracle.parse(x, p["min_width"], p["max_width"], p["window_width"], mg)
+    np.testing.assert_array_equal(b, npz()[case["name"] + "/bounds"])
+    if case["name"] + "/mean" in npz():
+        st = oracle.segment_stats(x, b)
+        # north_star tolerance: per-segment mean/std within 1e-5 relative
+        np.testing.assert_allclose(st[:, 0], npz()[case["name"] + "/mean"], rtol=1e-5, atol=0)
+        np.testing.assert_allclose(st[:, 1], npz()[case["name"] + "/std"], rtol=1e-5, atol=1e-12)
+        np.testing.assert_array_equal(st[:, 2], npz()[case["name"] + "/min"])
+        np.testing.assert_array_equal(st[:, 3], npz()[case["name"] + "/max"])
+
+
+@pytest.mark.parametrize("case", cases("score_window"), ids=case_ids("score_window"))
+def test_window_gains_to_the_ulp(case):
+    x = input_pa(case)
+    mg = oracle.min_gain(**case["params"])
+    _, s = oracle.score_window(x, case["params"]["min_width"], mg)
+    g = npz()[case["name"] + "/scores"]
+    # same libm, same operation order: bit-identical, including the zeros outside the candidate range
+    np.testing.assert_array_equal(s, g)
+
+
+@pytest.mark.parametrize("case", cases("best_single_split"), ids=case_ids("best_single_split"))
+def test_best_single_split(case):
+    g, i = oracle.best_single_split(input_pa(case))
+    assert i == case["index"]
+    assert repr(g) == case["gain"]
+
+
+def test_event_detector_matches_reference_parsers_py():
+    z = npz()
+    x = z["G6_events/input"].astype(np.float64) * 2.0 ** -5
+    st, ln = oracle.lambda_events(x, threshold=90)
+    np.testing.assert_array_equal(st, z["G6_events/starts"])
+    np.testing.assert_array_equal(ln, z["G6_events/lengths"])
+    for k in range(len(st)):
+        ev = x[st[k]:st[k] + ln[k]]
+        b = oracle.parse(ev, prior_segments_per_second=10.)
+        np.testing.assert_array_equal(b, z["G6_events/ev%d_bounds" % k])
+
+
+def test_min_gain_known_values():
+    # prior=10 -> 18.4204807339517; +cutoff 2000 -> 460.5120183487925; defaults -> -0.0
+    assert oracle.min_gain(prior_segments_per_second=10) == 18.4204807339517
+    assert oracle.min_gain(prior_segments_per_second=10, cutoff_freq=2000.) == 460.5120183487925
+    assert oracle.min_gain() == 0.0 and np.signbit(oracle.min_gain())
+    with pytest.raises(AssertionError):
+        oracle.min_gain(min_width=10, max_width=5)
+    with pytest.raises(AssertionError):
+        oracle.min_gain(min_width=100, window_width=199)
+    with pytest.raises(AssertionError):
+        oracle.min_gain(cutoff_freq=60000.)
+
+
+@pytest.mark.slow
+def test_1e8_digest():
+    (case,) = cases("parse_digest")
+    x = input_pa(case)
+    b = oracle.parse(x, **{k: v for k, v in case["params"].items()})
+    assert len(b) == case["n_bounds"]
+    assert hashlib.sha256(b.astype(np.int32).tobytes()).hexdigest() == case["sha256"]
+    np.testing.assert_array_equal(b[:32], npz()["G7_1e8/first32"])
+    np.testing.assert_array_equal(b[-32:], npz()["G7_1e8/last32"])
