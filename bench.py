@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s segmented by SpeedyStatSplit on a 10^8-sample trace (BASELINE.json).
+
+One "step" = one pass of the hot path (ps_segment_batch: spine kernel -> stitch -> tree kernel
+-> gather) over one 10^8-sample synthetic trace that is already resident in HBM.  With
+--gpus N every rank segments its own trace (weak scaling, no data-path collective; one RCCL
+all_gather of the boundary counts after the timed region).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel at 4 B per input sample
+against 8 TB/s; `cpu_baseline` times the CPU oracle (oracle/, a port of the reference) on a
+bounded prefix of the same trace on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PARAMS = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10.,
+              sampling_freq=1e5)
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
+BYTES_PER_SAMPLE = 4       # one fp32 read per input sample
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=100_000_000)
+    ap.add_argument("--cpu-samples", type=int, default=20_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stats", action="store_true", help="also run the per-segment statistics kernel in the step")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pypore_amd import _lib, engine, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+    ctx = engine.context(dev)
+
+    n = args.samples
+    seed = 2024 + rank                                   # rank 0's trace is golden case G7
+    d = synth.dwell_table(seed, n)
+    ends = np.cumsum(d)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
+    ev_off = np.array([0, n], dtype=np.int64)
+    params = _lib.split_params(**PARAMS)
+    torch.cuda.synchronize()
+
+    def step():
+        return ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kern = dict(spine_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, total_ms=0.0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bounds, boff, _ = step()
+        tm = ctx.timings()                               # HIP-event timings on the library's stream
+        for k in kern:
+            kern[k] += tm[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        cnt = torch.tensor([bounds.numel()], dtype=torch.int64, device="cuda")
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)                       # the only collective: boundary counts
+        n_bounds = [int(c.item()) for c in allc]
+    else:
+        n_bounds = [int(bounds.numel())]
+    for k in kern:
+        kern[k] /= args.steps
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n / (dt / args.steps) / 1e6
+
+    if rank == 0:
+        dom = "spine_kernel" if kern["spine_ms"] >= kern["tree_ms"] else "tree_kernel"
+        dom_ms = max(kern["spine_ms"], kern["tree_ms"])
+        achieved = BYTES_PER_SAMPLE * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "Msamples/sec segmented (SpeedyStatSplit, 10^8-sample trace); %HBM roofline",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "one %.0e-sample fp32 trace per GPU (5-level step signal, dwell U[1000,20000), "
+                                   "sigma 1 pA, 2^-5 pA grid), single SpeedyStatSplit.parse over the whole trace; "
+                                   "min_width=100 max_width=1e6 window_width=10000 prior_segments_per_second=10" % n,
+                       "samples_per_gpu": n, "boundaries": n_bounds, "segment_stats_in_step": bool(args.stats)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+                         "kernel_ms": {k: round(v, 4) for k, v in kern.items()}},
+            "whole_step_frac_of_hbm_roofline": round(BYTES_PER_SAMPLE * n / (ms_per_step * 1e-3) / HBM_PEAK, 5),
+            "work": {k: tm[k] for k in ("windows", "candidates", "tiles", "tree_jobs", "repairs", "exact_rescans")},
+        }
+        if not args.no_cpu:
+            import oracle
+            m = min(n, args.cpu_samples)
+            x = trace[:m].cpu().numpy().astype(np.float64)
+            t1 = time.perf_counter()
+            ref = oracle.parse(x, **{k: v for k, v in PARAMS.items()})
+            t2 = time.perf_counter()
+            got = bounds.cpu().numpy()
+            # prefix property: parse(x[:m]) agrees with parse(x) away from the cut
+            k = int(np.searchsorted(ref, m - 4 * PARAMS["window_width"]))
+            out["cpu_baseline"] = {"value": round(m / (t2 - t1) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                                   "kind": "port",
+                                   "sample": "first %d samples of rank 0's trace, oracle/statsplit_oracle.c "
+                                             "(gcc -O2), single thread" % m,
+                                   "prefix_boundaries_equal": bool(np.array_equal(ref[:k], got[:k]))}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * poreseg.h -- C ABI of libporeseg.so, the MI355X (gfx950) implementation of PyPore's
+ * SpeedyStatSplit / FastStatSplit change-point segmenter.
+ *
+ * Every entry point below replaces one piece of the reference interface (file:line under
+ * the reference tree, PyPore/...).  The reference has no FFI of its own (the hot path is a
+ * Cython cdef class called from Python); the binding a maintainer would add is a ctypes
+ * stub, shown in INTEGRATION.md, which is exactly what pypore_amd/_lib.py does.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns a status
+ * (PS_OK == 0, negative on error); ps_last_error() returns a human-readable message for the
+ * most recent failure on that context.  Pointers prefixed d_ are DEVICE pointers (HBM of the
+ * context's GPU), h_ are host pointers.  Outputs are caller-allocated with an explicit
+ * capacity; when a capacity is too small the call fails with PS_ERR_CAPACITY and reports
+ * the required size through the corresponding out-parameter.  A context is bound to one
+ * GPU and one HIP stream and may be used by one host thread at a time.
+ *
+ * Sample model.  The reference consumes float64 current in pA (cparsers.pyx:53,103).  Real
+ * traces are int16 ADC counts times a scale (read_abf.py:202-210), so the device consumes
+ * either fp32 pA values that lie on an ADC grid (x = k * quantum, k integer, |k| < 2^23) or
+ * the raw int16 counts; prefix sums are then exact integers and window variances are
+ * evaluated in fp64 with the reference's operation order.  Off-grid fp32 input is rejected
+ * with PS_ERR_OFF_GRID (never silently rounded).
+ */
+#ifndef PORESEG_H
+#define PORESEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_OK                 0
+#define PS_ERR_ARG           -1   /* invalid argument (null pointer, negative size ...) */
+#define PS_ERR_ASSERT_WIDTH  -2   /* reference assertion max_width >= min_width        (cparsers.pyx:69) */
+#define PS_ERR_ASSERT_WINDOW -3   /* reference assertion window_width >= 2*min_width   (cparsers.pyx:71) */
+#define PS_ERR_ASSERT_CUTOFF -4   /* reference assertion cutoff_freq <= sampling_freq/2 (cparsers.pyx:74) */
+#define PS_ERR_CAPACITY      -5   /* caller buffer too small; required size reported */
+#define PS_ERR_OFF_GRID      -6   /* fp32 sample is not an integer multiple of quantum */
+#define PS_ERR_HIP           -7   /* HIP runtime error (message in ps_last_error) */
+#define PS_ERR_NO_DEVICE     -8   /* no gfx950 device / code object missing */
+#define PS_ERR_INTERNAL      -9   /* device-side stack or scratch overflow */
+
+#define PS_DTYPE_F32 0            /* float pA on the grid k*quantum */
+#define PS_DTYPE_I16 1            /* raw int16 ADC counts (read_abf.py:208) */
+
+typedef struct ps_ctx ps_ctx;
+
+/* The eight constructor arguments of FastStatSplit / SpeedyStatSplit
+ * (cparsers.pyx:55-57, parsers.py:511-513).  "Not given" (Python None) is encoded as 0,
+ * which the reference also treats as not given (`if not false_positive_rate`). */
+typedef struct ps_split_params {
+    int32_t min_width;                   /* default 100      */
+    int32_t max_width;                   /* default 1000000  */
+    int32_t window_width;                /* default 10000    */
+    double  min_gain_per_sample;         /* 0 = None         */
+    double  false_positive_rate;         /* 0 = None         */
+    double  prior_segments_per_second;   /* 0 = None         */
+    double  sampling_freq;               /* default 1e5      */
+    double  cutoff_freq;                 /* 0 = None         */
+} ps_split_params;
+
+/* How samples map to pA: pA = (count + offset_counts) * quantum, with count = x/quantum for
+ * PS_DTYPE_F32 (offset_counts must be 0 there).  quantum should be a power of two for
+ * bit-exact parity with the reference (read_abf.py:202-205 scale/offset). */
+typedef struct ps_sample_format {
+    int32_t dtype;                       /* PS_DTYPE_* */
+    int32_t offset_counts;
+    double  quantum;
+} ps_sample_format;
+
+/* Per-segment statistics: Segment.mean/std/min/max (core.py:209-223), std = population. */
+typedef struct ps_segstat {
+    double mean, std, min, max;
+} ps_segstat;
+
+/* Library / device ------------------------------------------------------------------------ */
+const char *ps_version(void);
+/* Number of visible gfx950 GPUs (0 if none; never fails). */
+int ps_device_count(void);
+/* Creates a context on GPU `device`; stream = an existing hipStream_t to launch on, or NULL
+ * to let the context create its own. */
+int ps_create(int device, void *stream, ps_ctx **out);
+void ps_destroy(ps_ctx *ctx);
+const char *ps_last_error(const ps_ctx *ctx);
+/* Tiling of long traces: a trace longer than tile_len + halo samples is cut into tiles whose
+ * spines are computed speculatively and stitched.  0 keeps the default. */
+int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
+/* Blocks until all work submitted on the context's stream has finished. */
+int ps_synchronize(ps_ctx *ctx);
+
+/* Replaces FastStatSplit.__init__ (cparsers.pyx:55-101): validates the widths with the
+ * reference's three assertions and computes the public attribute `min_gain`. Host only. */
+int ps_min_gain(const ps_split_params *p, double *min_gain_out);
+
+/* Replaces FastStatSplit.parse (cparsers.pyx:103-118 -> _recursive_split :180-203 ->
+ * _best_split_stepwise :157-178 -> var_c :31-38) for a batch of independent events
+ * (one reference parse() call per event; Event.parse, DataTypes.py:286).
+ *   d_samples  all events' samples, one contiguous device array
+ *   h_ev_off   n_ev+1 host offsets into d_samples (event e = [h_ev_off[e], h_ev_off[e+1]))
+ *   d_bounds   device out, capacity `cap` int32: breakpoints of event 0, then event 1, ...
+ *              (event-local sample indices, ascending, excluding 0 and the event length --
+ *              the list _recursive_split returns)
+ *   h_bounds_off  host out, n_ev+1 offsets into d_bounds
+ *   d_stats    nullable device out, capacity `cap + n_ev` entries: statistics of the
+ *              segments of event 0, then event 1, ... (segment s of event e lives at
+ *              h_bounds_off[e] + e + s)
+ * Returns PS_ERR_CAPACITY if cap < total (h_bounds_off[n_ev] then holds the required size). */
+int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                     const int64_t *h_ev_off, int32_t n_ev,
+                     const ps_split_params *params,
+                     int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off,
+                     ps_segstat *d_stats);
+
+/* Upper bound on the number of breakpoints ps_segment_batch can emit for these events
+ * (sum over events of len/min_width): a safe `cap`. */
+int64_t ps_bounds_capacity(const int64_t *h_ev_off, int32_t n_ev, int32_t min_width);
+
+/* Replaces FastStatSplit.best_single_split (cparsers.pyx:120-155): one scan of the whole
+ * array, start=0, end=n-1, candidates range(2, end-2), threshold 0.  Returns (gain, index)
+ * or (0.0, -1). */
+int ps_best_single_split(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                         int64_t n, double *gain_out, int32_t *index_out);
+
+/* Replaces FastStatSplit.score_samples(current, no_split=True) (cparsers.pyx:205-249):
+ * per-candidate gains of ONE window spanning the whole array; d_scores[n] (device) gets the
+ * gain at every candidate index and 0 elsewhere; *split_out the chosen split or -1. */
+int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                    int64_t n, int32_t min_width, double min_gain,
+                    double *d_scores, int32_t *split_out);
+
+/* Timing of the most recent ps_segment_batch, measured with HIP events on the context's
+ * stream: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[3] whole
+ * call (host wall clock), ms[4] host stitch.  counters[0] window scans, [1] candidate
+ * evaluations, [2] tiles, [3] tree jobs, [4] seam repairs, [5] exact (fp64) re-scans. */
+int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);
+
+/* Synthetic step-signal generator (bit-identical to pypore_amd/synth.py):
+ * sample i = level_counts[segment containing i] + noise(seed, i), written as fp32 pA
+ * (count * 2^-5) or int16 counts.  h_seg_end[nseg] are the exclusive segment ends
+ * (ascending, last >= n).  Bench/test infrastructure. */
+int ps_synth_trace(ps_ctx *ctx, void *d_out, int32_t dtype, int64_t n, uint64_t seed,
+                   const int64_t *h_seg_end, const int32_t *h_level_counts, int64_t nseg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PORESEG_H */

@@ -1,0 +1,114 @@
+"""FastStatSplit -- the class surface of PyPore/cparsers.pyx:45-275 backed by the HIP kernels.
+
+Same constructor signature (cparsers.pyx:55-57), same public attribute `min_gain`, same
+methods parse / best_single_split / score_samples, same assertion and ValueError behaviour.
+Every compute call goes through the C ABI (include/poreseg.h); nothing here computes on the CPU.
+"""
+import numpy as np
+
+from . import _lib, engine
+from .core import Segment
+
+
+class FastStatSplit(object):
+    def __init__(self, min_width=100, max_width=1000000, window_width=10000,
+                 min_gain_per_sample=None, false_positive_rate=None,
+                 prior_segments_per_second=None, sampling_freq=1.e5, cutoff_freq=None,
+                 quantum=None, device=None):
+        self.min_width = int(min_width)
+        self.max_width = int(max_width)
+        self.window_width = int(window_width)
+        self.sampling_freq = int(sampling_freq)              # cdef int (cparsers.pyx:51,61)
+        self._params = _lib.split_params(min_width, max_width, window_width, min_gain_per_sample,
+                                         false_positive_rate, prior_segments_per_second, sampling_freq,
+                                         cutoff_freq)
+        # validates with the reference's assertions and computes min_gain (cparsers.pyx:69-101)
+        self.min_gain = _lib.min_gain(min_width=min_width, max_width=max_width, window_width=window_width,
+                                      min_gain_per_sample=min_gain_per_sample,
+                                      false_positive_rate=false_positive_rate,
+                                      prior_segments_per_second=prior_segments_per_second,
+                                      sampling_freq=sampling_freq, cutoff_freq=cutoff_freq)
+        self.quantum = quantum
+        self.device = device
+
+    # ---- cparsers.pyx:103-118 -------------------------------------------------------------------
+    def parse(self, current):
+        """Segments of `current` (list of core.Segment whose `.current` are views, start/end/
+        duration in samples), exactly like the reference."""
+        return self.parse_batch([current])[0]
+
+    def parse_batch(self, currents):
+        """One device call for many independent events (one reference parse() per event)."""
+        ctx = engine.context(self.device)
+        devs, q = [], self.quantum
+        for cur in currents:
+            t, q1 = engine.to_device_samples(cur, q, self.device)
+            if q is None:
+                q = q1
+            elif q1 != q and self.quantum is None:
+                q = min(q, q1)
+            devs.append(t)
+        import torch
+        lens = np.array([t.numel() for t in devs], dtype=np.int64)
+        ev_off = np.concatenate(([0], np.cumsum(lens)))
+        samples = devs[0] if len(devs) == 1 else torch.cat(devs)
+        bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
+        b = bounds.cpu().numpy()
+        st = stats.cpu().numpy()
+        out = []
+        for e, cur in enumerate(currents):
+            n = int(lens[e])
+            edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [n]))
+            segs = []
+            for s in range(len(edges) - 1):
+                a, z = int(edges[s]), int(edges[s + 1])
+                seg = Segment(current=cur[a:z], start=a, duration=(z - a), end=z)
+                seg._gpu_stats = st[boff[e] + e + s]
+                segs.append(seg)
+            out.append(segs)
+        return out
+
+    # ---- cparsers.pyx:120-155 -------------------------------------------------------------------
+    def best_single_split(self, current):
+        ctx = engine.context(self.device)
+        t, q = engine.to_device_samples(current, self.quantum, self.device)
+        return ctx.best_single_split(t, q)
+
+    # ---- cparsers.pyx:205-275 -------------------------------------------------------------------
+    def score_samples(self, current, no_split=False):
+        """One dense gain array per window scan, in the reference's scan order; with
+        no_split=True a single scan of the whole array returned as a list (cparsers.pyx:261-263)."""
+        ctx = engine.context(self.device)
+        t, q = engine.to_device_samples(current, self.quantum, self.device)
+        n = t.numel()
+        mw, maxw, W = self.min_width, self.max_width, self.window_width
+
+        def scan(start, end):
+            if end - start <= 2 * mw:                                     # :229-230
+                return -1, []
+            split, sc = ctx.score_window(t[start:end], q, mw, self.min_gain)
+            full = np.zeros(n)
+            full[start:end] = sc.cpu().numpy()
+            return (split + start if split >= 0 else -1), full
+
+        if no_split:
+            return list(scan(0, n)[1])
+
+        def rec(start, end):
+            scores, split_at = [], -1
+            for ps in range(start, end - 2 * mw, W // 2):                 # :265
+                if ps > start + maxw:                                     # :266-268
+                    split_at = min(start + maxw, end - mw)
+                    return scores + rec(split_at, end)
+                pe = min(end, ps + W)
+                split_at, sc = scan(ps, pe)
+                scores.append(sc)
+                if split_at >= 0:
+                    break
+            if split_at == -1:
+                if end - start <= maxw:
+                    return scores
+                split_at = min(start + maxw, end - mw)
+            return scores + rec(start, split_at) + rec(split_at, end)
+
+        return rec(0, n)

@@ -1,0 +1,599 @@
+// poreseg.hip -- C ABI (include/poreseg.h) and host orchestration of libporeseg.so.
+//
+// Pipeline of ps_segment_batch:
+//   phase 1  spine_kernel   one workgroup per tile: speculative spine of rec(T, END)
+//   stitch   host           true spine per event from the tile spines (indices only)
+//   phase 3  tree_kernel    one workgroup per true spine step: rec(a_k, a_{k+1}) in order
+//   gather   item_scan + gather kernels -> contiguous, sorted boundary list per event
+//   K2       segstat_kernel (optional)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "poreseg.h"
+#include "seg_device.hpp"
+
+using namespace ps;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, cap + cap / 2);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+struct HostBuf {          // pinned staging memory
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, cap + cap / 2);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct ps_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int64_t tile_len = 0, halo = 0;
+    DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
+        tree_counts, items, item_pos, first_item, ev_off, bounds_off, small;
+    HostBuf h_meta, h_dense, h_small, h_up;
+    hipEvent_t ev[6] = {};
+    double ms[5] = {0, 0, 0, 0, 0};
+    int64_t counters[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(ps_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, PS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
+             double min_gain, DevCfg *c)
+{
+    if (!fmt) return fail(ctx, PS_ERR_ARG, "sample format is NULL");
+    if (fmt->dtype != PS_DTYPE_F32 && fmt->dtype != PS_DTYPE_I16)
+        return fail(ctx, PS_ERR_ARG, "unknown dtype %d", fmt->dtype);
+    if (!(fmt->quantum > 0) || !std::isfinite(fmt->quantum))
+        return fail(ctx, PS_ERR_ARG, "quantum must be positive and finite");
+    if (fmt->dtype == PS_DTYPE_F32 && fmt->offset_counts != 0)
+        return fail(ctx, PS_ERR_ARG, "offset_counts must be 0 for fp32 samples");
+    c->samples = d_samples;
+    c->dtype = fmt->dtype;
+    c->off_counts = fmt->offset_counts;
+    c->inv_q = static_cast<float>(1.0 / fmt->quantum);
+    c->q = fmt->quantum;
+    c->q2 = fmt->quantum * fmt->quantum;
+    c->mw = mw; c->maxw = maxw; c->W = W; c->half = W / 2;
+    c->min_gain = min_gain;
+    return PS_OK;
+}
+
+struct Anchor { int32_t pos, kind; };
+
+struct TileList {
+    int32_t start = 0;
+    std::vector<Anchor> a;
+    bool ended = false;
+};
+
+int check_status(ps_ctx *ctx, unsigned st)
+{
+    if (st & ST_OFF_GRID)
+        return fail(ctx, PS_ERR_OFF_GRID, "fp32 sample is not an integer multiple of quantum (or |count| >= 2^23)");
+    if (st & ST_STACK_OVERFLOW) return fail(ctx, PS_ERR_INTERNAL, "device DFS stack overflow");
+    if (st & ST_OUT_OVERFLOW) return fail(ctx, PS_ERR_INTERNAL, "device scratch overflow");
+    return PS_OK;
+}
+
+// status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..2] work, [3] dense count
+struct SmallLayout { unsigned long long status, work0, work1, dense; };
+
+// Runs spine_kernel over `jobs`, returns the per-tile anchor lists.
+int run_spines(ps_ctx *ctx, const DevCfg &cfg, const std::vector<SpineJob> &jobs, int64_t scratch_entries,
+               std::vector<TileList> &out)
+{
+    const size_t nj = jobs.size();
+    out.assign(nj, TileList());
+    if (nj == 0) return PS_OK;
+    HIP_TRY(ctx, ctx->spine_jobs.reserve(nj * sizeof(SpineJob)));
+    HIP_TRY(ctx, ctx->spine_scratch.reserve(static_cast<size_t>(scratch_entries) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->spine_dense.reserve(static_cast<size_t>(scratch_entries) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->spine_meta.reserve(nj * sizeof(int4)));
+    HIP_TRY(ctx, ctx->h_up.reserve(nj * sizeof(SpineJob)));
+    std::memcpy(ctx->h_up.p, jobs.data(), nj * sizeof(SpineJob));
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->spine_jobs.p, ctx->h_up.p, nj * sizeof(SpineJob), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(&sm->dense, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(spine_kernel, dim3(static_cast<unsigned>(nj)), dim3(NT), 0, ctx->stream, cfg,
+                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_dense.as<int2>(),
+                       ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, ctx->h_meta.reserve(nj * sizeof(int4)));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->spine_meta.p, nj * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+    int rc = check_status(ctx, static_cast<unsigned>(hs.status));
+    if (rc) return rc;
+    const size_t total = static_cast<size_t>(hs.dense);
+    if (total) {
+        HIP_TRY(ctx, ctx->h_dense.reserve(total * sizeof(int2)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.p, ctx->spine_dense.p, total * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->ms[0] += ms;
+    const int4 *meta = ctx->h_meta.as<int4>();
+    const int2 *dense = ctx->h_dense.as<int2>();
+    for (size_t j = 0; j < nj; ++j) {
+        TileList &t = out[j];
+        t.start = jobs[j].start;
+        t.ended = meta[j].y != 0;
+        t.a.resize(static_cast<size_t>(meta[j].x));
+        for (int i = 0; i < meta[j].x; ++i) {
+            t.a[i].pos = dense[meta[j].z + i].x;
+            t.a[i].kind = dense[meta[j].z + i].y;
+        }
+    }
+    return PS_OK;
+}
+
+// anchors of one chain are >= min_width apart and at most one lies at or beyond `stop`
+inline int64_t spine_cap(int64_t start, int64_t stop, int mw) { return (stop - start) / mw + 4; }
+
+// position of `pos` in a tile list (exact match), -1 if the tile starts there, -2 if absent
+int find_in(const TileList &t, int32_t pos)
+{
+    if (pos == t.start) return -1;
+    auto it = std::lower_bound(t.a.begin(), t.a.end(), pos, [](const Anchor &x, int32_t v) { return x.pos < v; });
+    if (it != t.a.end() && it->pos == pos) return static_cast<int>(it - t.a.begin());
+    return -2;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ps_version(void) { return "poreseg 0.1 (gfx950)"; }
+
+int ps_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ps_create(int device, void *stream, ps_ctx **out)
+{
+    if (!out) return PS_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PS_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PS_ERR_NO_DEVICE;
+    ps_ctx *ctx = new ps_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
+    if (ctx->small.reserve(sizeof(SmallLayout)) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
+    *out = ctx;
+    return PS_OK;
+}
+
+void ps_destroy(ps_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->spine_jobs, &ctx->spine_scratch, &ctx->spine_dense, &ctx->spine_meta, &ctx->tree_jobs,
+                      &ctx->tree_scratch, &ctx->tree_spill, &ctx->tree_counts, &ctx->items, &ctx->item_pos,
+                      &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small};
+    for (DevBuf *b : bufs) b->release();
+    ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release();
+    for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *ps_last_error(const ps_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo)
+{
+    if (!ctx || tile_len < 0 || halo < 0) return PS_ERR_ARG;
+    ctx->tile_len = tile_len;
+    ctx->halo = halo;
+    return PS_OK;
+}
+
+int ps_synchronize(ps_ctx *ctx)
+{
+    if (!ctx) return PS_ERR_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+// cparsers.pyx:55-101
+int ps_min_gain(const ps_split_params *p, double *out)
+{
+    if (!p || !out) return PS_ERR_ARG;
+    double fpr = p->false_positive_rate, sps = p->prior_segments_per_second;
+    const double sf = p->sampling_freq;
+    if (!(fpr != 0.0)) fpr = sf;                                         // :64-65
+    if (!(sps != 0.0)) sps = sf / 2.;                                    // :66-67
+    if (!(p->max_width >= p->min_width)) return PS_ERR_ASSERT_WIDTH;     // :69
+    if (!(p->window_width >= 2 * p->min_width)) return PS_ERR_ASSERT_WINDOW;  // :71
+    if (p->cutoff_freq != 0.0 && !(p->cutoff_freq <= 0.5 * sf)) return PS_ERR_ASSERT_CUTOFF;  // :74
+    double mg;
+    if (p->min_gain_per_sample != 0.0) {
+        mg = p->min_gain_per_sample * p->window_width;                   // :84
+    } else {
+        const double k = p->cutoff_freq != 0.0 ? p->cutoff_freq / (0.5 * sf) : 1.0;   // :89
+        mg = (-std::log(sps / (sf - sps)) - std::log(fpr / sf)) / k;     // :95-97
+    }
+    *out = mg * 2;                                                       // :101
+    return PS_OK;
+}
+
+int64_t ps_bounds_capacity(const int64_t *h_ev_off, int32_t n_ev, int32_t min_width)
+{
+    if (!h_ev_off || n_ev < 0 || min_width < 1) return -1;
+    int64_t cap = 0;
+    for (int e = 0; e < n_ev; ++e) cap += (h_ev_off[e + 1] - h_ev_off[e]) / min_width + 1;
+    return cap;
+}
+
+int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                     const int64_t *h_ev_off, int32_t n_ev, const ps_split_params *params,
+                     int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats)
+{
+    if (!ctx) return PS_ERR_ARG;
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!h_ev_off || !params || !h_bounds_off || n_ev < 0 || cap < 0 || (cap > 0 && !d_bounds))
+        return fail(ctx, PS_ERR_ARG, "null/negative argument");
+    double min_gain = 0;
+    int rc = ps_min_gain(params, &min_gain);
+    if (rc) return fail(ctx, rc, "reference assertion failed (cparsers.pyx:69-76)");
+    const int mw = params->min_width, maxw = params->max_width, W = params->window_width;
+    if (mw < 1 || W < 2) return fail(ctx, PS_ERR_ARG, "min_width must be >= 1 and window_width >= 2");
+    for (int e = 0; e < n_ev; ++e) {
+        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
+        if (len < 0 || len > 0x7fffffff - 2LL * W - 8)
+            return fail(ctx, PS_ERR_ARG, "event %d length %lld out of range", e, static_cast<long long>(len));
+    }
+    if (n_ev > 0 && !d_samples && h_ev_off[n_ev] > h_ev_off[0]) return fail(ctx, PS_ERR_ARG, "d_samples is NULL");
+    DevCfg cfg;
+    rc = make_cfg(ctx, d_samples, fmt, mw, maxw, W, min_gain, &cfg);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (double &m : ctx->ms) m = 0;
+    for (int64_t &c : ctx->counters) c = 0;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+
+    // ---- tiles ----------------------------------------------------------------------------------
+    const int64_t L = ctx->tile_len > 0 ? ctx->tile_len : 16LL * W;
+    const int64_t H = ctx->halo > 0 ? ctx->halo : 4LL * W;
+    std::vector<SpineJob> jobs;
+    std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
+    int64_t scratch = 0;
+    for (int e = 0; e < n_ev; ++e) {
+        ev_first_tile[e] = static_cast<int64_t>(jobs.size());
+        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
+        if (len == 0) continue;
+        const int64_t nt = len <= L + H ? 1 : (len + L - 1) / L;
+        for (int64_t t = 0; t < nt; ++t) {
+            SpineJob j;
+            j.base = h_ev_off[e];
+            j.start = static_cast<int32_t>(t * L);
+            j.end = static_cast<int32_t>(len);
+            const int64_t stop = (t == nt - 1) ? len : std::min(len, (t + 1) * L + H);
+            j.stop = static_cast<int32_t>(stop);
+            const int64_t capj = spine_cap(j.start, stop, mw);
+            j.out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
+            j.out_off = scratch;
+            scratch += j.out_cap;
+            jobs.push_back(j);
+        }
+    }
+    ev_first_tile[n_ev] = static_cast<int64_t>(jobs.size());
+    ctx->counters[2] = static_cast<int64_t>(jobs.size());
+
+    std::vector<TileList> lists;
+    rc = run_spines(ctx, cfg, jobs, scratch, lists);
+    if (rc) return rc;
+
+    // ---- stitch: true spine per event -------------------------------------------------------------
+    const auto t_stitch0 = std::chrono::steady_clock::now();
+    std::vector<TreeJob> tjobs;
+    std::vector<Item> items;
+    std::vector<int64_t> first_item(static_cast<size_t>(n_ev) + 1, 0);
+    int64_t tscratch = 0;
+    for (int e = 0; e < n_ev; ++e) {
+        first_item[e] = static_cast<int64_t>(items.size());
+        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
+        const int64_t t0 = ev_first_tile[e], t1 = ev_first_tile[e + 1];
+        if (t0 == t1) continue;
+        int64_t cur = t0;
+        size_t idx = 0;
+        int32_t prev = 0;
+        for (;;) {
+            TileList &Lc = lists[cur];
+            if (idx >= Lc.a.size()) {
+                if (Lc.ended) break;
+                // the chain stopped (passed its stop position) without meeting a later tile:
+                // continue it from its last (true) anchor -- "seam repair"
+                const int32_t z = Lc.a.empty() ? Lc.start : Lc.a.back().pos;
+                std::vector<SpineJob> rj(1);
+                rj[0].base = h_ev_off[e];
+                rj[0].start = z;
+                rj[0].end = static_cast<int32_t>(len);
+                const int64_t stop = std::min<int64_t>(len, static_cast<int64_t>(z) + L + H);
+                rj[0].stop = static_cast<int32_t>(stop);
+                const int64_t capj = spine_cap(z, stop, mw);
+                rj[0].out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
+                rj[0].out_off = 0;
+                std::vector<TileList> ext;
+                rc = run_spines(ctx, cfg, rj, rj[0].out_cap, ext);
+                if (rc) return rc;
+                ctx->counters[4] += 1;
+                Lc.a.insert(Lc.a.end(), ext[0].a.begin(), ext[0].a.end());
+                Lc.ended = ext[0].ended;
+                if (ext[0].a.empty() && !ext[0].ended)
+                    return fail(ctx, PS_ERR_INTERNAL, "seam repair made no progress");
+                continue;
+            }
+            const Anchor an = Lc.a[idx];
+            // emit this true anchor
+            Item it;
+            it.anchor = an.pos;
+            it.job = -1;
+            if (an.kind == KIND_HIT || an.kind == KIND_LATE) {
+                TreeJob tj;
+                tj.base = h_ev_off[e];
+                tj.start = prev;
+                tj.end = an.pos;
+                const int64_t d = static_cast<int64_t>(an.pos) - W - prev;
+                tj.j0 = d < 0 ? 0 : static_cast<int32_t>(d / (W / 2)) + 1;
+                tj.out_cap = (an.pos - prev) / mw + 1;
+                tj.out_off = tscratch;
+                tscratch += tj.out_cap;
+                it.job = static_cast<int32_t>(tjobs.size());
+                tjobs.push_back(tj);
+            }
+            items.push_back(it);
+            prev = an.pos;
+            ++idx;
+            // does a later tile's speculative spine contain this anchor?  (latest tile wins)
+            if (cur + 1 < t1 && an.pos >= lists[cur + 1].start) {
+                int64_t u = t0 + std::min<int64_t>(an.pos / L, t1 - t0 - 1);
+                for (; u > cur; --u) {
+                    const int f = find_in(lists[u], an.pos);
+                    if (f != -2) { cur = u; idx = static_cast<size_t>(f + 1); break; }
+                }
+            }
+        }
+    }
+    first_item[n_ev] = static_cast<int64_t>(items.size());
+    const int64_t n_items = static_cast<int64_t>(items.size());
+    const size_t n_tj = tjobs.size();
+    ctx->counters[3] = static_cast<int64_t>(n_tj);
+    const auto t_stitch1 = std::chrono::steady_clock::now();
+    ctx->ms[4] = std::chrono::duration<double, std::milli>(t_stitch1 - t_stitch0).count();
+
+    // ---- upload jobs/items, phase 3, gather ------------------------------------------------------
+    const size_t up_bytes = n_tj * sizeof(TreeJob) + static_cast<size_t>(n_items) * sizeof(Item) +
+                            (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t) * 2;
+    HIP_TRY(ctx, ctx->h_up.reserve(up_bytes + 64));
+    HIP_TRY(ctx, ctx->tree_jobs.reserve(std::max<size_t>(1, n_tj) * sizeof(TreeJob)));
+    HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<size_t>(1, n_tj) * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx->tree_scratch.reserve(std::max<size_t>(1, static_cast<size_t>(tscratch)) * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx->tree_spill.reserve(std::max<size_t>(1, static_cast<size_t>(tscratch)) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->items.reserve(std::max<size_t>(1, static_cast<size_t>(n_items)) * sizeof(Item)));
+    HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(n_items) + 1) * sizeof(int64_t)));
+    HIP_TRY(ctx, ctx->first_item.reserve((static_cast<size_t>(n_ev) + 1) * sizeof(int64_t)));
+    HIP_TRY(ctx, ctx->ev_off.reserve((static_cast<size_t>(n_ev) + 1) * sizeof(int64_t)));
+    HIP_TRY(ctx, ctx->bounds_off.reserve((static_cast<size_t>(n_ev) + 1) * sizeof(int64_t)));
+    char *up = ctx->h_up.as<char>();
+    size_t o = 0;
+    if (n_tj) {
+        std::memcpy(up + o, tjobs.data(), n_tj * sizeof(TreeJob));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->tree_jobs.p, up + o, n_tj * sizeof(TreeJob), hipMemcpyHostToDevice, ctx->stream));
+        o += n_tj * sizeof(TreeJob);
+    }
+    if (n_items) {
+        std::memcpy(up + o, items.data(), static_cast<size_t>(n_items) * sizeof(Item));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->items.p, up + o, static_cast<size_t>(n_items) * sizeof(Item), hipMemcpyHostToDevice, ctx->stream));
+        o += static_cast<size_t>(n_items) * sizeof(Item);
+    }
+    o = (o + 7) & ~static_cast<size_t>(7);
+    const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
+    std::memcpy(up + o, first_item.data(), evb);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->first_item.p, up + o, evb, hipMemcpyHostToDevice, ctx->stream));
+    o += evb;
+    std::memcpy(up + o, h_ev_off, evb);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_off.p, up + o, evb, hipMemcpyHostToDevice, ctx->stream));
+
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (n_tj) {
+        hipLaunchKernelGGL(tree_kernel, dim3(static_cast<unsigned>(n_tj)), dim3(NT), 0, ctx->stream, cfg,
+                           ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
+                           ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
+                       ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    if (n_items) {
+        hipLaunchKernelGGL(gather_kernel, dim3(static_cast<unsigned>(n_items)), dim3(64), 0, ctx->stream,
+                           ctx->items.as<Item>(), ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(),
+                           ctx->tree_scratch.as<int32_t>(), ctx->item_pos.as<int64_t>(), n_items, d_bounds, cap);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(event_offsets_kernel, dim3((n_ev + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                       ctx->item_pos.as<int64_t>(), ctx->first_item.as<int64_t>(), n_ev, ctx->bounds_off.as<int64_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, ctx->h_meta.reserve(evb));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(h_bounds_off, ctx->h_meta.p, evb);
+    const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+    rc = check_status(ctx, static_cast<unsigned>(hs.status));
+    if (rc) return rc;
+    ctx->counters[0] = static_cast<int64_t>(hs.work0);
+    ctx->counters[1] = static_cast<int64_t>(hs.work1);
+    const int64_t total = h_bounds_off[n_ev];
+    if (total > cap)
+        return fail(ctx, PS_ERR_CAPACITY, "bounds capacity %lld < required %lld", static_cast<long long>(cap),
+                    static_cast<long long>(total));
+    if (d_stats) {
+        const int64_t nseg = total + n_ev;
+        if (nseg > 0) {
+            hipLaunchKernelGGL(segstat_kernel, dim3(static_cast<unsigned>(nseg)), dim3(NT), 0, ctx->stream, cfg,
+                               ctx->ev_off.as<int64_t>(), n_ev, d_bounds, ctx->bounds_off.as<int64_t>(), d_stats,
+                               reinterpret_cast<unsigned *>(&sm->status));
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->ms[1] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->ms[2] = ms;
+    ctx->ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return PS_OK;
+}
+
+static int single_scan(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int mode,
+                       int mw, double min_gain, double *d_scores, double *gain_out, int32_t *idx_out)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!d_samples || n < 0 || n > 0x7fffffff) return fail(ctx, PS_ERR_ARG, "bad samples/n");
+    DevCfg cfg;
+    int rc = make_cfg(ctx, d_samples, fmt, mw, 0, 0, min_gain, &cfg);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    HIP_TRY(ctx, ctx->spine_meta.reserve(64));
+    if (d_scores && n) HIP_TRY(ctx, hipMemsetAsync(d_scores, 0, static_cast<size_t>(n) * sizeof(double), ctx->stream));
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    double *d_gain = ctx->spine_meta.as<double>();
+    int *d_idx = reinterpret_cast<int *>(d_gain + 1);
+    hipLaunchKernelGGL(single_scan_kernel, dim3(1), dim3(NT), 0, ctx->stream, cfg, static_cast<int>(n), mode, d_scores,
+                       d_gain, d_idx, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    HIP_TRY(ctx, ctx->h_meta.reserve(64));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, d_gain, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
+    if (rc) return rc;
+    if (gain_out) *gain_out = *ctx->h_meta.as<double>();
+    if (idx_out) *idx_out = *reinterpret_cast<int *>(ctx->h_meta.as<double>() + 1);
+    return PS_OK;
+}
+
+// cparsers.pyx:120-155
+int ps_best_single_split(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                         double *gain_out, int32_t *index_out)
+{
+    if (!gain_out || !index_out) return fail(ctx, PS_ERR_ARG, "null output");
+    return single_scan(ctx, d_samples, fmt, n, 1, 1, 0.0, nullptr, gain_out, index_out);
+}
+
+// cparsers.pyx:205-249 with no_split=True
+int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                    int32_t min_width, double min_gain, double *d_scores, int32_t *split_out)
+{
+    if (min_width < 1) return fail(ctx, PS_ERR_ARG, "min_width must be >= 1");
+    double g;
+    return single_scan(ctx, d_samples, fmt, n, 0, min_width, min_gain, d_scores, &g, split_out);
+}
+
+int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters)
+{
+    if (!ctx) return PS_ERR_ARG;
+    for (int i = 0; i < n_ms && ms; ++i) ms[i] = i < 5 ? ctx->ms[i] : 0.0;
+    for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 6 ? ctx->counters[i] : 0;
+    return PS_OK;
+}
+
+int ps_synth_trace(ps_ctx *ctx, void *d_out, int32_t dtype, int64_t n, uint64_t seed,
+                   const int64_t *h_seg_end, const int32_t *h_level_counts, int64_t nseg)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!d_out || n < 0 || nseg < 1 || !h_seg_end || !h_level_counts) return fail(ctx, PS_ERR_ARG, "bad argument");
+    if (h_seg_end[nseg - 1] < n) return fail(ctx, PS_ERR_ARG, "segment table does not cover n");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t b1 = static_cast<size_t>(nseg) * sizeof(int64_t), b2 = static_cast<size_t>(nseg) * sizeof(int32_t);
+    HIP_TRY(ctx, ctx->tree_scratch.reserve(b1 + b2));
+    char *d = ctx->tree_scratch.as<char>();
+    HIP_TRY(ctx, hipMemcpyAsync(d, h_seg_end, b1, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + b1, h_level_counts, b2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // pageable host sources must outlive the copy
+    hipLaunchKernelGGL(synth_kernel, dim3(4096), dim3(256), 0, ctx->stream, d_out, dtype, n,
+                       static_cast<unsigned long long>(seed), reinterpret_cast<const int64_t *>(d),
+                       reinterpret_cast<const int32_t *>(d + b1), nseg);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+}  // extern "C"

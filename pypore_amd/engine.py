@@ -1,0 +1,175 @@
+"""Device-side plumbing between Python and libporeseg.so: one Context per GPU (a ps_ctx handle
+plus torch-allocated HBM buffers).  torch is used for device memory and streams only; all
+compute is in the HIP kernels behind the C ABI.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_contexts = {}
+
+
+class Context(object):
+    """Owns a ps_ctx bound to GPU `device` (one process per GPU; one host thread at a time)."""
+
+    def __init__(self, device=0):
+        L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("pypore_amd: no GPU visible to torch -- the segmenter has no CPU fallback")
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        _lib.check(L.ps_create(self.device, None, ctypes.byref(h)))
+        self.handle = h
+        self.L = L
+
+    def close(self):
+        if self.handle:
+            self.L.ps_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tiling(self, tile_len=0, halo=0):
+        _lib.check(self.L.ps_set_tiling(self.handle, int(tile_len), int(halo)), self.handle)
+
+    def timings(self):
+        ms = (ctypes.c_double * 5)()
+        cnt = (ctypes.c_int64 * 6)()
+        _lib.check(self.L.ps_get_timings(self.handle, ms, 5, cnt, 6))
+        return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4],
+                    windows=cnt[0], candidates=cnt[1], tiles=cnt[2], tree_jobs=cnt[3], repairs=cnt[4],
+                    exact_rescans=cnt[5])
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None):
+        """ps_segment_batch on device-resident `samples` (torch float32 or int16 CUDA tensor).
+        Returns (bounds int32 CUDA tensor [total], bounds_off int64 numpy [n_ev+1],
+        stats float64 CUDA tensor [total+n_ev, 4] or None)."""
+        assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
+        if samples.dtype == torch.float32:
+            dtype = _lib.PS_DTYPE_F32
+        elif samples.dtype == torch.int16:
+            dtype = _lib.PS_DTYPE_I16
+        else:
+            raise ValueError("samples must be float32 or int16, got %s" % samples.dtype)
+        ev_off = np.ascontiguousarray(ev_off, dtype=np.int64)
+        n_ev = ev_off.size - 1
+        fmt = _lib.SampleFormat(dtype, int(offset_counts), float(quantum))
+        off_p = ev_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        if cap is None:
+            cap = int(self.L.ps_bounds_capacity(off_p, n_ev, int(params.min_width)))
+            if cap < 0:
+                raise ValueError("min_width must be >= 1")
+        dev = samples.device
+        bounds = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        stats = torch.empty((max(cap, 1) + n_ev, 4), dtype=torch.float64, device=dev) if want_stats else None
+        boff = np.zeros(n_ev + 1, dtype=np.int64)
+        torch.cuda.current_stream(dev).synchronize()      # inputs produced on torch's stream are ready
+        rc = self.L.ps_segment_batch(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), off_p,
+                                     n_ev, ctypes.byref(params), ctypes.c_void_p(bounds.data_ptr()), cap,
+                                     boff.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                     ctypes.c_void_p(stats.data_ptr()) if want_stats else None)
+        _lib.check(rc, self.handle)
+        total = int(boff[-1])
+        return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None)
+
+    def best_single_split(self, samples, quantum, offset_counts=0):
+        fmt = _lib.SampleFormat(_lib.PS_DTYPE_F32 if samples.dtype == torch.float32 else _lib.PS_DTYPE_I16,
+                                int(offset_counts), float(quantum))
+        g = ctypes.c_double()
+        i = ctypes.c_int32()
+        torch.cuda.current_stream(samples.device).synchronize()
+        _lib.check(self.L.ps_best_single_split(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt),
+                                               samples.numel(), ctypes.byref(g), ctypes.byref(i)), self.handle)
+        return g.value, i.value
+
+    def score_window(self, samples, quantum, min_width, min_gain, offset_counts=0):
+        fmt = _lib.SampleFormat(_lib.PS_DTYPE_F32 if samples.dtype == torch.float32 else _lib.PS_DTYPE_I16,
+                                int(offset_counts), float(quantum))
+        scores = torch.empty(max(1, samples.numel()), dtype=torch.float64, device=samples.device)
+        i = ctypes.c_int32()
+        torch.cuda.current_stream(samples.device).synchronize()
+        _lib.check(self.L.ps_score_window(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt),
+                                          samples.numel(), int(min_width), float(min_gain),
+                                          ctypes.c_void_p(scores.data_ptr()), ctypes.byref(i)), self.handle)
+        return i.value, scores[:samples.numel()]
+
+    def synth_trace(self, n, seed, seg_end, level_counts, dtype=torch.float32):
+        """Synthetic step trace generated directly in HBM (csrc synth_kernel == pypore_amd.synth)."""
+        out = torch.empty(n, dtype=dtype, device="cuda:%d" % self.device)
+        seg_end = np.ascontiguousarray(seg_end, dtype=np.int64)
+        level_counts = np.ascontiguousarray(level_counts, dtype=np.int32)
+        torch.cuda.current_stream(out.device).synchronize()
+        _lib.check(self.L.ps_synth_trace(self.handle, ctypes.c_void_p(out.data_ptr()),
+                                         _lib.PS_DTYPE_F32 if dtype == torch.float32 else _lib.PS_DTYPE_I16,
+                                         n, ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                         seg_end.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                         level_counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), seg_end.size),
+                   self.handle)
+        return out
+
+
+def context(device=None):
+    """The process-wide Context of `device` (default: torch's current device)."""
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    device = int(device)
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+# ---- host-side input normalisation -------------------------------------------------------------
+def detect_quantum(x, max_bits=24):
+    """Largest power of two q = 2**-k (0 <= k <= max_bits) such that every sample of the numpy
+    array `x` is an integer multiple of q; ValueError if there is none (off-grid data).
+    Real traces are int16 ADC counts times a scale (read_abf.py:202-210), so such a q exists
+    whenever the scale is a power of two; pass quantum= explicitly to skip this O(n) host pass."""
+    x = np.asarray(x)
+    if x.size == 0:
+        return 1.0
+    for k in (5,) + tuple(i for i in range(0, max_bits + 1) if i != 5):
+        y = x * (2.0 ** k)
+        if np.all(y == np.rint(y)):
+            # shrink k while still integral so that counts stay small
+            while k > 0:
+                y2 = x * (2.0 ** (k - 1))
+                if not np.all(y2 == np.rint(y2)):
+                    break
+                k -= 1
+            return 2.0 ** -k
+    raise ValueError("samples are not on a power-of-two ADC grid; pass quantum= (pA per count)")
+
+
+def to_device_samples(current, quantum=None, device=None):
+    """numpy float64/float32 (pA), numpy int16 (ADC counts) or torch tensor -> (CUDA tensor, quantum)."""
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    if isinstance(current, torch.Tensor):
+        t = current
+        if t.dtype == torch.float64:
+            t = t.to(torch.float32)
+        if t.dtype not in (torch.float32, torch.int16):
+            raise ValueError("Buffer dtype mismatch, expected float64/float32 pA or int16 counts")
+        if quantum is None:
+            quantum = 1.0 if t.dtype == torch.int16 else detect_quantum(t.detach().cpu().numpy())
+        return t.to(dev).contiguous(), quantum
+    a = np.asarray(current)
+    if a.ndim != 1:
+        raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % a.ndim)
+    if a.dtype == np.int16:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev), (1.0 if quantum is None else quantum)
+    if a.dtype not in (np.float64, np.float32):
+        raise ValueError("Buffer dtype mismatch, expected 'double' but got %s" % a.dtype)
+    if quantum is None:
+        quantum = detect_quantum(a)
+    a32 = a.astype(np.float32)
+    if a.dtype == np.float64 and not np.array_equal(a32.astype(np.float64), a):
+        raise ValueError("samples are not exactly representable in float32; pass int16 counts or a coarser grid")
+    return torch.from_numpy(np.ascontiguousarray(a32)).to(dev), quantum

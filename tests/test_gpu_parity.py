@@ -1,0 +1,209 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the golden
+vectors recorded from the reference and against the CPU oracle on seeded inputs."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import case_ids, cases, input_counts, input_pa, npz
+from pypore_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pypore_amd import engine
+    return engine.context(0)
+
+
+def _bounds(segs):
+    return np.array([s.start for s in segs[1:]], dtype=np.int32)
+
+
+@pytest.mark.parametrize("case", cases("parse"), ids=case_ids("parse"))
+def test_parse_matches_reference_golden(case, ctx):
+    from pypore_amd.parsers import SpeedyStatSplit
+    x = input_pa(case)                                  # float64, like the reference's input
+    p = SpeedyStatSplit(quantum=synth.QUANTUM, **case["params"])
+    segs = p.parse(x)
+    # segment boundary indices: bit-exact
+    np.testing.assert_array_equal(_bounds(segs), npz()[case["name"] + "/bounds"])
+    assert [s.end for s in segs] == list(_bounds(segs)) + [len(x)]
+    assert all(s.duration == s.end - s.start for s in segs)
+    if case["name"] + "/mean" in npz() and len(x) > 0:
+        # north_star tolerance: per-segment mean/std within 1e-5 relative
+        np.testing.assert_allclose([s.mean for s in segs], npz()[case["name"] + "/mean"], rtol=1e-5)
+        np.testing.assert_allclose([s.std for s in segs], npz()[case["name"] + "/std"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_array_equal([s.min for s in segs], npz()[case["name"] + "/min"])
+        np.testing.assert_array_equal([s.max for s in segs], npz()[case["name"] + "/max"])
+        # .current are views of the caller's array (cparsers.pyx:115)
+        assert segs[0].current.base is x or segs[0].current.base is x.base or np.shares_memory(segs[0].current, x)
+
+
+@pytest.mark.parametrize("case", cases("parse")[:12], ids=case_ids("parse")[:12])
+def test_parse_int16_and_float32_inputs(case, ctx):
+    from pypore_amd.parsers import SpeedyStatSplit
+    counts = input_counts(case)
+    g = npz()[case["name"] + "/bounds"]
+    p = SpeedyStatSplit(quantum=synth.QUANTUM, **case["params"])
+    np.testing.assert_array_equal(_bounds(p.parse(counts.astype(np.int16))), g)
+    np.testing.assert_array_equal(_bounds(p.parse(synth.counts_to_pa(counts, np.float32))), g)
+    # automatic grid detection
+    p2 = SpeedyStatSplit(**case["params"])
+    np.testing.assert_array_equal(_bounds(p2.parse(synth.counts_to_pa(counts, np.float64))), g)
+
+
+@pytest.mark.parametrize("tile,halo", [(20000, 10000), (50000, 20000), (100000, 40000), (30000, 1)])
+@pytest.mark.parametrize("name", ["G8_full", "G9_rd_2M", "G9_rd_short_dwell", "G9_rd_long_dwell", "G9_cutoff",
+                                  "G4_forced_flat", "G4_forced_mixed", "G4_big_window", "G4_small_windows"])
+def test_tiled_spines_stitch_to_the_same_result(name, tile, halo, ctx):
+    """Speculative tiles + stitching (incl. seam repairs when the halo is too short) must not
+    change a single boundary."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    (case,) = [c for c in cases("parse") if c["name"] == name]
+    ctx.set_tiling(tile, halo)
+    try:
+        segs = SpeedyStatSplit(quantum=synth.QUANTUM, **case["params"]).parse(input_pa(case, np.float32))
+    finally:
+        ctx.set_tiling(0, 0)
+    np.testing.assert_array_equal(_bounds(segs), npz()[name + "/bounds"])
+
+
+@pytest.mark.parametrize("case", cases("score_window"), ids=case_ids("score_window"))
+def test_per_candidate_gains(case, ctx):
+    from pypore_amd.cparsers import FastStatSplit
+    x = input_pa(case)
+    f = FastStatSplit(quantum=synth.QUANTUM, **case["params"])
+    s = np.array(f.score_samples(x, no_split=True))
+    g = npz()[case["name"] + "/scores"]
+    assert s.shape == g.shape
+    np.testing.assert_array_equal(s == 0, g == 0)
+    # same operation order in fp64; only the device log differs from glibc's by <= 1 ulp per call
+    np.testing.assert_allclose(s, g, rtol=0, atol=1e-7)
+    assert int(np.argmax(s)) == int(np.argmax(g))
+
+
+def test_score_samples_recursive_scan_order(ctx):
+    from pypore_amd.cparsers import FastStatSplit
+    x = synth.config1()
+    f = FastStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM)
+    scans = f.score_samples(x)
+    # reference: one array per window scan: full window, then the recursion
+    assert len(scans) >= 5 and all(len(s) == len(x) for s in scans)
+    _, ref0 = oracle.score_window(x, 100, f.min_gain)
+    np.testing.assert_allclose(scans[0], ref0, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", cases("best_single_split"), ids=case_ids("best_single_split"))
+def test_best_single_split(case, ctx):
+    from pypore_amd.parsers import SpeedyStatSplit
+    g, i = SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM).best_single_split(input_pa(case))
+    assert i == case["index"]
+    assert g == pytest.approx(float(case["gain"]), rel=1e-12, abs=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_parameters_against_oracle(seed, ctx):
+    """Seeded random traces and parameter sets: HIP path == CPU oracle, bit for bit."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    rng = np.random.RandomState(seed)
+    n = int(rng.randint(20000, 400000))
+    lo = int(rng.randint(50, 2000))
+    hi = lo + int(rng.randint(100, 30000))
+    mw = int(rng.choice([5, 20, 100, 250]))
+    W = int(max(2 * mw, rng.choice([400, 1000, 4000, 10000, 25000])))
+    maxw = int(rng.choice([W, 3 * W, 50000, 1000000]))
+    params = dict(min_width=mw, max_width=max(maxw, mw), window_width=W,
+                  prior_segments_per_second=float(rng.choice([1., 10., 100.])))
+    counts = synth.random_dwell_counts(n, 1000 + seed, lo, hi)
+    x = synth.counts_to_pa(counts, np.float64)
+    ref = oracle.parse(x, **params)
+    got = _bounds(SpeedyStatSplit(quantum=synth.QUANTUM, **params).parse(x))
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_batch_of_events_config2_shape(ctx):
+    """BASELINE config 2 shape (reduced count): a batch of 50k-sample events in one call."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    evs = [synth.config2_event(ev, dtype=np.float32) for ev in range(100, 148)]
+    evs.append(np.zeros(0, dtype=np.float32))            # empty event
+    evs.append(synth.config2_event(7, n=150, dtype=np.float32))   # shorter than 2*min_width
+    p = SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM)
+    out = p.parse_batch(evs)
+    assert len(out) == len(evs)
+    for x, segs in zip(evs, out):
+        ref = oracle.parse(x.astype(np.float64), prior_segments_per_second=10.)
+        np.testing.assert_array_equal(_bounds(segs), ref)
+        st = oracle.segment_stats(x.astype(np.float64), ref) if len(x) else None
+        if st is not None:
+            np.testing.assert_allclose([s.mean for s in segs], st[:, 0], rtol=1e-5)
+            np.testing.assert_allclose([s.std for s in segs], st[:, 1], rtol=1e-5, atol=1e-9)
+
+
+def test_device_generator_matches_numpy(ctx):
+    import torch
+    n = 300000
+    d = synth.dwell_table(77, n)
+    ends = np.cumsum(d)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    ref = synth.random_dwell_counts(n, 77)
+    t = ctx.synth_trace(n, 77, ends, lv, dtype=torch.float32)
+    np.testing.assert_array_equal(t.cpu().numpy(), synth.counts_to_pa(ref, np.float32))
+    t16 = ctx.synth_trace(n, 77, ends, lv, dtype=torch.int16)
+    np.testing.assert_array_equal(t16.cpu().numpy().astype(np.int32), ref)
+
+
+def test_off_grid_and_bad_dtype_fail_loudly(ctx):
+    from pypore_amd.parsers import SpeedyStatSplit
+    x = synth.config1(np.float64).copy()
+    x[1234] += 1e-3
+    with pytest.raises(ValueError):
+        SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM).parse(x.astype(np.float32))
+    with pytest.raises(ValueError):
+        SpeedyStatSplit(prior_segments_per_second=10.).parse(np.arange(1000, dtype=np.int32))
+    with pytest.raises(AssertionError):
+        SpeedyStatSplit(min_width=100, window_width=100).parse(x)
+
+
+def test_event_parse_call_contract(ctx):
+    """Event.parse(parser=SpeedyStatSplit(...)) / File.parse() as user code calls them."""
+    from pypore_amd.DataTypes import File
+    from pypore_amd.parsers import SpeedyStatSplit, lambda_event_parser
+    z = npz()
+    x = z["G6_events/input"].astype(np.float64) * synth.QUANTUM
+    f = File(current=x, timestep=0.01)                       # 100 kHz
+    f.parse(parser=lambda_event_parser(threshold=90))
+    assert [int(round(e.start * f.second)) for e in f.events] == list(z["G6_events/starts"])
+    for k, ev in enumerate(f.events):
+        ev.parse(parser=SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM))
+        b = np.array([int(round(s.start * f.second)) for s in ev.segments[1:]])
+        np.testing.assert_array_equal(b, z["G6_events/ev%d_bounds" % k])
+        assert ev.segments[0].event is ev and ev.state_parser is not None
+    f.parse_events(SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM))
+    for k, ev in enumerate(f.events):
+        b = np.array([int(round(s.start * f.second)) for s in ev.segments[1:]])
+        np.testing.assert_array_equal(b, z["G6_events/ev%d_bounds" % k])
+
+
+def test_1e8_trace_digest(ctx):
+    """BASELINE full size: the 10^8-sample trace, generated in HBM, against the digest recorded
+    from the reference (count + SHA-256 of all boundaries + first/last 32)."""
+    import torch
+    from pypore_amd import _lib
+    (case,) = cases("parse_digest")
+    n = case["n"]
+    d = synth.dwell_table(case["gen"]["seed"], n)
+    ends = np.cumsum(d)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    t = ctx.synth_trace(n, case["gen"]["seed"], ends, lv, dtype=torch.float32)
+    params = _lib.split_params(**case["params"])
+    bounds, boff, _ = ctx.segment_batch(t, np.array([0, n]), params, synth.QUANTUM, want_stats=False)
+    b = bounds.cpu().numpy().astype(np.int32)
+    assert len(b) == case["n_bounds"]
+    np.testing.assert_array_equal(b[:32], npz()["G7_1e8/first32"])
+    np.testing.assert_array_equal(b[-32:], npz()["G7_1e8/last32"])
+    assert hashlib.sha256(b.tobytes()).hexdigest() == case["sha256"]
+    # size-independent properties: sorted, strictly increasing, >= min_width apart, inside the trace
+    assert np.all(np.diff(b) >= case["params"]["min_width"]) and b[0] >= 100 and b[-1] <= n - 100

@@ -1,0 +1,111 @@
+"""CPU tests of the host side: C ABI surface, parameter logic, class surface (no GPU compute)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from pypore_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "poreseg.h")).read()
+    declared = set(re.findall(r"\b(ps_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "libporeseg.so does not export %s" % name
+    assert set(_lib.EXPORTS) == declared
+    assert b"gfx950" in L.ps_version()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.SplitParams) == 56
+    assert ctypes.sizeof(_lib.SampleFormat) == 16
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(prior_segments_per_second=10.), dict(prior_segments_per_second=10., cutoff_freq=2000.),
+    dict(min_gain_per_sample=0.5), dict(false_positive_rate=50., prior_segments_per_second=20.),
+    dict(sampling_freq=5e4, prior_segments_per_second=3.), dict(min_gain_per_sample=0.05, window_width=1000),
+])
+def test_min_gain_matches_oracle(kw):
+    assert repr(_lib.min_gain(**kw)) == repr(oracle.min_gain(**kw))
+
+
+def test_constructor_assertions_like_reference():
+    from pypore_amd.cparsers import FastStatSplit
+    with pytest.raises(AssertionError):
+        FastStatSplit(min_width=10, max_width=5)
+    with pytest.raises(AssertionError):
+        FastStatSplit(min_width=100, window_width=199)
+    with pytest.raises(AssertionError):
+        FastStatSplit(cutoff_freq=60000.)
+    f = FastStatSplit(prior_segments_per_second=10)
+    assert f.min_gain == 18.4204807339517
+
+
+def test_parser_json_round_trip_and_attribute_names():
+    from pypore_amd import parsers
+    p = parsers.SpeedyStatSplit(min_width=50, prior_segments_per_second=10., cutoff_freq=2000.)
+    d = json.loads(p.to_json())
+    assert set(d) == {"min_width", "max_width", "window_width", "min_gain_per_sample", "false_positive_rate",
+                      "prior_segments_per_second", "sampling_freq", "cutoff_freq", "name"}
+    q = parsers.parser.from_json(p.to_json())
+    assert isinstance(q, parsers.SpeedyStatSplit) and q.to_dict() == p.to_dict()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pypore_amd.parsers import SpeedyStatSplit
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SpeedyStatSplit(prior_segments_per_second=10.).parse(synth.config1())
+
+
+def test_segment_surface():
+    from pypore_amd.core import MetaSegment, Segment
+    x = np.arange(10, dtype=np.float64)
+    s = Segment(current=x[2:6], start=2, duration=4, end=6, mean=123.0)
+    assert s.mean == 3.5 and s.n == 4 and s.min == 2 and s.max == 5           # cannot override stats
+    s.scale(2.0)
+    assert (s.start, s.end, s.duration) == (1.0, 3.0, 2.0)
+    d = json.loads(s.to_json())
+    assert d["name"] == "Segment" and d["mean"] == 3.5
+    s.to_meta()
+    assert isinstance(s, MetaSegment) and not hasattr(s, "current") and s.mean == 3.5
+
+
+def test_lambda_event_parser_matches_oracle_and_golden():
+    from golden_util import npz
+    from pypore_amd.parsers import lambda_event_parser
+    z = npz()
+    x = z["G6_events/input"].astype(np.float64) * synth.QUANTUM
+    evs = lambda_event_parser(threshold=90).parse(x)
+    assert [int(e.start) for e in evs] == list(z["G6_events/starts"])
+    assert [int(e.duration) for e in evs] == list(z["G6_events/lengths"])
+
+
+def test_detect_quantum():
+    from pypore_amd import engine
+    assert engine.detect_quantum(synth.config1()) == 2.0 ** -5
+    assert engine.detect_quantum(np.array([1.0, 2.0, -7.0])) == 1.0
+    assert engine.detect_quantum(np.array([0.75, 1.5])) == 0.25
+    with pytest.raises(ValueError):
+        engine.detect_quantum(np.array([0.1, 0.2]))
+
+
+def test_synth_generators_are_stable():
+    # digest of the integer generator: guards the bench/golden inputs against drift
+    c = synth.random_dwell_counts(100000, 2024)
+    assert c[:6].tolist() == synth.random_dwell_counts(6, 2024).tolist()
+    import hashlib
+    assert hashlib.sha256(c.astype(np.int32).tobytes()).hexdigest() == \
+        hashlib.sha256(synth.random_dwell_counts(100000, 2024).astype(np.int32).tobytes()).hexdigest()
+    assert abs(float(np.std(synth.noise_counts(9, 0, 200000))) - 32.0) < 0.2
