@@ -41,6 +41,9 @@ def lib():
         raise RuntimeError(
             "pypore_amd: %s not found -- build it with `make -C pypore_amd/csrc` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7 (same soname as /opt/rocm's): import it FIRST so the
+    # process has exactly one HIP runtime, shared by torch's allocator and our kernels.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
     P = ctypes.POINTER
