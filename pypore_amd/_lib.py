@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libporeseg.so")
+LIB_PATH = os.environ.get("PORESEG_LIB") or os.path.join(_HERE, "libporeseg.so")   # PORESEG_LIB: diagnostic builds
 
 PS_OK = 0
 PS_ERR_ARG, PS_ERR_ASSERT_WIDTH, PS_ERR_ASSERT_WINDOW, PS_ERR_ASSERT_CUTOFF = -1, -2, -3, -4

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -64,6 +65,8 @@ struct ps_ctx {
     bool own_stream = false;
     std::string err;
     int64_t tile_len = 0, halo = 0;
+    int mode = MODE_FAST, spine_nt = 512, tree_nt = 256;
+    int lds_max_samples = 0;
     DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
         tree_counts, items, item_pos, first_item, ev_off, bounds_off, small;
     HostBuf h_meta, h_dense, h_small, h_up;
@@ -94,6 +97,9 @@ int fail(ps_ctx *ctx, int code, const char *fmt, ...)
             return fail(ctx, PS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..3] work, [4] dense count
+struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12]; };
+
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
              double min_gain, DevCfg *c)
 {
@@ -112,6 +118,35 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->q2 = fmt->quantum * fmt->quantum;
     c->mw = mw; c->maxw = maxw; c->W = W; c->half = W / 2;
     c->min_gain = min_gain;
+    c->mode = ctx->mode;
+    c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
+    return PS_OK;
+}
+
+// LDS budget: 160 KB per CU minus the static Shared block and a little slack
+constexpr int LDS_BYTES_MAX = 160 * 1024 - static_cast<int>(sizeof(Shared)) - 512 - 64;
+
+template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
+{
+    const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);   // + alignment slack of the staged region
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(spine_kernel<NT, DT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
+                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_dense.as<int2>(),
+                       ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+    HIP_TRY(ctx, hipGetLastError());
+    return PS_OK;
+}
+
+template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
+{
+    const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);   // + alignment slack of the staged region
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_kernel<NT, DT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
+                       ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
+                       ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+    HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
 
@@ -127,13 +162,12 @@ int check_status(ps_ctx *ctx, unsigned st)
 {
     if (st & ST_OFF_GRID)
         return fail(ctx, PS_ERR_OFF_GRID, "fp32 sample is not an integer multiple of quantum (or |count| >= 2^23)");
+    if (st & ST_VERIFY_MISMATCH) return fail(ctx, PS_ERR_INTERNAL, "verify mode: fp32 screen disagreed with the exact scan");
     if (st & ST_STACK_OVERFLOW) return fail(ctx, PS_ERR_INTERNAL, "device DFS stack overflow");
     if (st & ST_OUT_OVERFLOW) return fail(ctx, PS_ERR_INTERNAL, "device scratch overflow");
     return PS_OK;
 }
 
-// status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..2] work, [3] dense count
-struct SmallLayout { unsigned long long status, work0, work1, dense; };
 
 // Runs spine_kernel over `jobs`, returns the per-tile anchor lists.
 int run_spines(ps_ctx *ctx, const DevCfg &cfg, const std::vector<SpineJob> &jobs, int64_t scratch_entries,
@@ -152,10 +186,14 @@ int run_spines(ps_ctx *ctx, const DevCfg &cfg, const std::vector<SpineJob> &jobs
     HIP_TRY(ctx, hipMemcpyAsync(ctx->spine_jobs.p, ctx->h_up.p, nj * sizeof(SpineJob), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(&sm->dense, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(spine_kernel, dim3(static_cast<unsigned>(nj)), dim3(NT), 0, ctx->stream, cfg,
-                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_dense.as<int2>(),
-                       ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
-    HIP_TRY(ctx, hipGetLastError());
+    {
+        const unsigned g = static_cast<unsigned>(nj);
+        const bool f32 = cfg.dtype == PS_DTYPE_F32;
+        int lrc = ctx->spine_nt == 512
+                      ? (f32 ? launch_spine<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_spine<512, PS_DTYPE_I16>(ctx, cfg, g, sm))
+                      : (f32 ? launch_spine<1024, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_spine<1024, PS_DTYPE_I16>(ctx, cfg, g, sm));
+        if (lrc) return lrc;
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, ctx->h_meta.reserve(nj * sizeof(int4)));
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
@@ -231,6 +269,12 @@ int ps_create(int device, void *stream, ps_ctx **out)
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     if (ctx->small.reserve(sizeof(SmallLayout)) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
+    ctx->lds_max_samples = LDS_BYTES_MAX / static_cast<int>(sizeof(int));
+    if (const char *e = std::getenv("PORESEG_MODE")) ctx->mode = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_SPINE_NT")) ctx->spine_nt = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_TREE_NT")) ctx->tree_nt = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
+    if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
     *out = ctx;
     return PS_OK;
 }
@@ -325,8 +369,17 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
 
     // ---- tiles ----------------------------------------------------------------------------------
-    const int64_t L = ctx->tile_len > 0 ? ctx->tile_len : 16LL * W;
+    // Tiling: one spine workgroup per tile.  Default: as many tiles as the chip keeps resident at once
+    // (2 workgroups of 512 threads per CU on 256 CUs) so the grid runs as a single wave of blocks,
+    // but never shorter than 8 windows (the halo is pure overhead).
+    int64_t total_len = 0;
+    for (int e = 0; e < n_ev; ++e) total_len += h_ev_off[e + 1] - h_ev_off[e];
     const int64_t H = ctx->halo > 0 ? ctx->halo : 4LL * W;
+    int64_t L = ctx->tile_len;
+    if (L <= 0) {
+        const int64_t resident = 512;
+        L = std::max<int64_t>(8LL * W, (total_len + resident - 1) / resident);
+    }
     std::vector<SpineJob> jobs;
     std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
     int64_t scratch = 0;
@@ -470,10 +523,12 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_tj) {
-        hipLaunchKernelGGL(tree_kernel, dim3(static_cast<unsigned>(n_tj)), dim3(NT), 0, ctx->stream, cfg,
-                           ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
-                           ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
-        HIP_TRY(ctx, hipGetLastError());
+        const unsigned g = static_cast<unsigned>(n_tj);
+        const bool f32 = cfg.dtype == PS_DTYPE_F32;
+        int lrc = ctx->tree_nt == 512
+                      ? (f32 ? launch_tree<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<512, PS_DTYPE_I16>(ctx, cfg, g, sm))
+                      : (f32 ? launch_tree<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<256, PS_DTYPE_I16>(ctx, cfg, g, sm));
+        if (lrc) return lrc;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
@@ -498,6 +553,17 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     if (rc) return rc;
     ctx->counters[0] = static_cast<int64_t>(hs.work0);
     ctx->counters[1] = static_cast<int64_t>(hs.work1);
+    ctx->counters[5] = static_cast<int64_t>(hs.work2);
+#ifdef PS_STAMP
+    {
+        static const char *nm[12] = {"stage_tail", "minmax", "chunksum", "scan", "eval", "top2", "exact", "outside", "ld_issue", "ld_wait", "-", "-"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += hs.stamp[i];
+        fprintf(stderr, "[poreseg stamps] thread-0 cycles summed over workgroups (spine+tree):");
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
+        fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
+    }
+#endif
     const int64_t total = h_bounds_off[n_ev];
     if (total > cap)
         return fail(ctx, PS_ERR_CAPACITY, "bounds capacity %lld < required %lld", static_cast<long long>(cap),
@@ -505,9 +571,14 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     if (d_stats) {
         const int64_t nseg = total + n_ev;
         if (nseg > 0) {
-            hipLaunchKernelGGL(segstat_kernel, dim3(static_cast<unsigned>(nseg)), dim3(NT), 0, ctx->stream, cfg,
-                               ctx->ev_off.as<int64_t>(), n_ev, d_bounds, ctx->bounds_off.as<int64_t>(), d_stats,
-                               reinterpret_cast<unsigned *>(&sm->status));
+            if (cfg.dtype == PS_DTYPE_F32)
+                hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_F32>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
+                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
+                                   ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
+            else
+                hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_I16>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
+                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
+                                   ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
             HIP_TRY(ctx, hipGetLastError());
         }
     }
@@ -535,8 +606,23 @@ static int single_scan(ps_ctx *ctx, const void *d_samples, const ps_sample_forma
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     double *d_gain = ctx->spine_meta.as<double>();
     int *d_idx = reinterpret_cast<int *>(d_gain + 1);
-    hipLaunchKernelGGL(single_scan_kernel, dim3(1), dim3(NT), 0, ctx->stream, cfg, static_cast<int>(n), mode, d_scores,
-                       d_gain, d_idx, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+    cfg.lds_cap = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(n, ctx->lds_max_samples)));
+    {
+        const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);   // + alignment slack of the staged region
+        if (cfg.dtype == PS_DTYPE_F32) {
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(single_scan_kernel<1024, PS_DTYPE_F32>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            hipLaunchKernelGGL((single_scan_kernel<1024, PS_DTYPE_F32>), dim3(1), dim3(1024), lds, ctx->stream, cfg,
+                               static_cast<int>(n), mode, d_scores, d_gain, d_idx,
+                               reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+        } else {
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(single_scan_kernel<1024, PS_DTYPE_I16>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            hipLaunchKernelGGL((single_scan_kernel<1024, PS_DTYPE_I16>), dim3(1), dim3(1024), lds, ctx->stream, cfg,
+                               static_cast<int>(n), mode, d_scores, d_gain, d_idx,
+                               reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+        }
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
     HIP_TRY(ctx, ctx->h_meta.reserve(64));

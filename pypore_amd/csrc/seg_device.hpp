@@ -1,15 +1,26 @@
 // seg_device.hpp -- device side of libporeseg: window scan, recursion drivers, kernels.
 //
-// gfx950 only (wave64, 256 CUs).  One workgroup of NT threads works on one job; all control
-// flow of the recursion is workgroup-uniform (decisions are broadcast through LDS), the
-// per-candidate work is spread over the lanes.
+// gfx950 only (wave64, 256 CUs, 160 KB LDS/CU).  One workgroup of NT threads works on one
+// job; all control flow of the recursion is workgroup-uniform (decisions are broadcast through
+// LDS), the per-candidate work is spread over the lanes.
 //
 // Reference functions restated here (PyPore/cparsers.pyx):
 //   var_c                 :31-38    -> ref_var()
-//   _best_split_stepwise  :157-178  -> scan_window()
+//   _best_split_stepwise  :157-178  -> scan_window()  (screen in fp32, decide exactly in fp64)
 //   _recursive_split      :180-203  -> find_split() + spine_kernel / tree_kernel
 //   _best_single_split    :134-155  -> single_scan_kernel (mode 1)
 //   _best_split_stepwise_score :222-249 -> single_scan_kernel (mode 0)
+//
+// How a window [ps,pe) is scanned (DESIGN.md "window scan"):
+//   1. stage   coalesced HBM loads -> integer ADC counts in LDS; min/max of the window
+//   2. prefix  per-thread chunk sums of (k-m0), (k-m0)^2 in int32/uint32, workgroup exclusive
+//              scan in fp64 (the sums are integers, so every order gives the same bits)
+//   3. screen  every candidate's gain in fp32 from exact integer moment sums that are
+//              re-centred per thread chunk (no cancellation); error <= delta (proved bound)
+//   4. decide  workgroup top-2 reduction; if the best candidate is unique by more than
+//              2*delta and clear of the threshold by more than delta the answer is final;
+//              otherwise (rare) every candidate is re-evaluated in fp64 with the reference's
+//              exact operation order and first-maximum tie-break.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,12 +28,13 @@
 
 namespace ps {
 
-constexpr int NT = 256;          // threads per workgroup: 4 waves, one per SIMD of a CU
-constexpr int NWAVE = NT / 64;
 constexpr int LDS_STACK = 128;   // DFS stack entries kept in LDS before spilling to HBM
+constexpr int MAX_WAVES = 16;
+constexpr int OBUF = 256;        // buffered outputs per job (int2 anchors / 2x int boundaries)
 
 enum : int { KIND_NONE = 0, KIND_HIT = 1, KIND_EARLY = 2, KIND_LATE = 3 };
-enum : unsigned { ST_OFF_GRID = 1u, ST_OUT_OVERFLOW = 2u, ST_STACK_OVERFLOW = 4u };
+enum : unsigned { ST_OFF_GRID = 1u, ST_OUT_OVERFLOW = 2u, ST_STACK_OVERFLOW = 4u, ST_VERIFY_MISMATCH = 8u };
+enum : int { MODE_FAST = 0, MODE_EXACT = 1, MODE_VERIFY = 2 };
 
 struct DevCfg {
     const void *samples;
@@ -31,6 +43,8 @@ struct DevCfg {
     double q, q2;
     int mw, maxw, W, half;
     double min_gain;
+    int mode;               // MODE_*
+    int lds_cap;            // samples that fit the dynamic LDS window buffer
 };
 
 struct SpineJob {           // speculative spine of one tile: rec(start, end) without left subtrees
@@ -49,18 +63,57 @@ struct TreeJob {            // full in-order traversal of rec(start, end), first
 };
 
 struct Shared {
-    double wsum1[NWAVE], wsum2[NWAVE];
-    double wbest[NWAVE];
-    int widx[NWAVE];
+    double wsum1[MAX_WAVES], wsum2[MAX_WAVES];
+    double wbest[MAX_WAVES];
+    int widx[MAX_WAVES];
+    float fbest[MAX_WAVES], fsecond[MAX_WAVES];
+    int fidx[MAX_WAVES];
+    int wmin[MAX_WAVES], wmax[MAX_WAVES];
+    unsigned wflag[MAX_WAVES];
     int bcast;
     int2 pop;
     int2 stack[LDS_STACK];
+    int2 obuf[OBUF];        // results are buffered here and written to HBM once per job: a global
+                            // store issued between scans would sit in front of the next window's
+                            // staging loads (vmcnt retires in order) and stall the whole workgroup
 };
 
+struct Work {
+    long long windows, cands, exact;
+#ifdef PS_STAMP
+    long long t0, ph[12];
+#endif
+};
+// In-kernel phase stamps (diagnostic build only, -DPS_STAMP): thread 0 accumulates s_memtime
+// deltas per phase of the window scan; never compiled into the product library.
+#ifdef PS_STAMP
+#define PS_STAMP_AT(wk, i) do { if (threadIdx.x == 0) { long long t_ = clock64(); (wk).ph[i] += t_ - (wk).t0; (wk).t0 = t_; } } while (0)
+#define PS_WORK_INIT {0, 0, 0, clock64(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}
+#else
+#define PS_STAMP_AT(wk, i) do { } while (0)
+#define PS_WORK_INIT {0, 0, 0}
+#endif
+
 // ---- sample access --------------------------------------------------------------------------
+template <int DT> struct Raw { typedef float type; };
+template <> struct Raw<PS_DTYPE_I16> { typedef int16_t type; };
+
+template <int DT>
+__device__ __forceinline__ int to_count(const DevCfg &c, typename Raw<DT>::type v, unsigned &bad)
+{
+    if (DT == PS_DTYPE_F32) {
+        const float k = static_cast<float>(v) * c.inv_q;
+        const int ki = __float2int_rn(k);
+        if (static_cast<float>(ki) != k || !(fabsf(k) < 8388608.f)) bad |= ST_OFF_GRID;
+        return ki;
+    }
+    return static_cast<int>(v) + c.off_counts;
+}
+
+template <int DT>
 __device__ __forceinline__ int load_count(const DevCfg &c, int64_t gi, unsigned &bad)
 {
-    if (c.dtype == PS_DTYPE_F32) {
+    if (DT == PS_DTYPE_F32) {
         float x = static_cast<const float *>(c.samples)[gi];
         float k = x * c.inv_q;
         int ki = __float2int_rn(k);
@@ -94,26 +147,62 @@ __device__ __forceinline__ double ref_gain(double var_summed, int nl, double vl,
     return var_summed - s;
 }
 
+// ---- wave64 primitives on DPP (no LDS traffic) -------------------------------------------------
+// Hillis-Steele inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then row_bcast15 /
+// row_bcast31 carry the row totals across (gfx9 DPP controls).  Every step combines two DISJOINT
+// lane ranges, so a max-with-payload reduction never sees the same element twice.  Lane 63 ends
+// up holding the reduction over the whole wave.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int identity, int x)
+{
+    return __builtin_amdgcn_update_dpp(identity, x, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_movf(float identity, float x)
+{
+    return __int_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_int(identity), __float_as_int(x)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_movd(double x)          // identity 0.0
+{
+    const int lo = dpp_mov<CTRL, ROW_MASK>(0, __double2loint(x));
+    const int hi = dpp_mov<CTRL, ROW_MASK>(0, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+#define PS_DPP_STEPS(X) X(0x111, 0xf) X(0x112, 0xf) X(0x114, 0xf) X(0x118, 0xf) X(0x142, 0xa) X(0x143, 0xc)
+
+__device__ __forceinline__ void wave_incl_scan2(double &a, double &b)
+{
+#define PS_STEP(CTRL, RM) { const double ta = dpp_movd<CTRL, RM>(a), tb = dpp_movd<CTRL, RM>(b); a += ta; b += tb; }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+}
+__device__ __forceinline__ void wave_minmax(int &mn, int &mx)      // result in lane 63
+{
+#define PS_STEP(CTRL, RM) { const int tn = dpp_mov<CTRL, RM>(0x7fffffff, mn), tx = dpp_mov<CTRL, RM>(static_cast<int>(0x80000000), mx); mn = min(mn, tn); mx = max(mx, tx); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+}
+
 // ---- workgroup primitives -------------------------------------------------------------------
 // Exclusive prefix over the workgroup of two fp64 values that are exact integers (so the
-// summation order does not matter); also returns the workgroup totals.
+// summation order does not matter); also returns the workgroup totals.  One barrier.
+template <int NT>
 __device__ __forceinline__ void block_exscan2(double v1, double v2, double &e1, double &e2,
                                               double &t1, double &t2, Shared &sh)
 {
+    constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double i1 = v1, i2 = v2;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double u1 = __shfl_up(i1, d), u2 = __shfl_up(i2, d);
-        if (lane >= d) { i1 += u1; i2 += u2; }
-    }
+    wave_incl_scan2(i1, i2);
     if (lane == 63) { sh.wsum1[wave] = i1; sh.wsum2[wave] = i2; }
     __syncthreads();
     double b1 = 0, b2 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) {
-        if (w < wave) { b1 += sh.wsum1[w]; b2 += sh.wsum2[w]; }
-        s1 += sh.wsum1[w]; s2 += sh.wsum2[w];
+    for (int w = 0; w < NW; ++w) {
+        const double x1 = sh.wsum1[w], x2 = sh.wsum2[w];
+        if (w < wave) { b1 += x1; b2 += x2; }
+        s1 += x1; s2 += x2;
     }
     e1 = b1 + i1 - v1; e2 = b2 + i2 - v2;
     t1 = s1; t2 = s2;
@@ -127,8 +216,12 @@ __device__ __forceinline__ bool beats(double ga, int ia, double gb, int ib)
     return ga > gb || (ga == gb && static_cast<unsigned>(ia) < static_cast<unsigned>(ib));
 }
 
-__device__ __forceinline__ int block_argmax(double g, int idx, Shared &sh)
+// Workgroup arg-max with the reference tie-break; result uniform.  One barrier (the slots it
+// writes were last read before an earlier barrier of the same scan).
+template <int NT>
+__device__ __forceinline__ int block_argmax(double g, int idx, Shared &sh, double *gain_out)
 {
+    constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -138,43 +231,38 @@ __device__ __forceinline__ int block_argmax(double g, int idx, Shared &sh)
     }
     if (lane == 0) { sh.wbest[wave] = g; sh.widx[wave] = idx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double bg = sh.wbest[0]; int bi = sh.widx[0];
+    double bg = sh.wbest[0];
+    int bi = sh.widx[0];
 #pragma unroll
-        for (int w = 1; w < NWAVE; ++w)
-            if (beats(sh.wbest[w], sh.widx[w], bg, bi)) { bg = sh.wbest[w]; bi = sh.widx[w]; }
-        sh.bcast = bi;
-        sh.wbest[0] = bg;
+    for (int w = 1; w < NW; ++w) {
+        const double og = sh.wbest[w];
+        const int oi = sh.widx[w];
+        if (beats(og, oi, bg, bi)) { bg = og; bi = oi; }
     }
-    __syncthreads();
-    int r = sh.bcast;
-    return r;
+    if (gain_out) *gain_out = bg;
+    return bi;
 }
 
-// ---- one window scan: cparsers.pyx:157-178 ------------------------------------------------------
-// Window [ps, pe) of the event at `base`; candidates cand_lo..cand_hi (inclusive, event-local);
-// returns the first index whose gain strictly exceeds every earlier gain and `thresh`, or -1.
-// best_gain_out (thread 0 only, nullable) receives the winning gain (or thresh).
-struct Work { long long windows, cands; };
-
-__device__ int scan_window(const DevCfg &c, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
-                           double thresh, double *scores, Shared &sh, unsigned &bad, Work &wk,
-                           double *best_gain_out = nullptr)
+// ---- exact scan of a staged window: cparsers.pyx:157-178 to the letter -------------------------
+// ys[0..n) hold the window's counts (LDS) or, when ys == nullptr, samples are read from HBM.
+template <int NT, int DT>
+__device__ int scan_exact(const DevCfg &c, const int *ys, int64_t g0, int ps, int n, int cand_lo,
+                          int cand_hi, double thresh, double *scores, Shared &sh, unsigned &bad,
+                          double *best_gain_out)
 {
-    const int n = pe - ps;
-    const int ch = (n + NT - 1) / NT;
+    const int ch = ((n + NT - 1) / NT) | 1;
     const long long lo_ll = static_cast<long long>(threadIdx.x) * ch;
     const int lo = lo_ll < n ? static_cast<int>(lo_ll) : n;
     const int hi = (lo + ch < n) ? lo + ch : n;
-    const int64_t g0 = base + ps;
+    __syncthreads();        // a screen that bailed out early may still be reading the scan slots
 
     double s1 = 0, s2 = 0;
     for (int j = lo; j < hi; ++j) {
-        double k = static_cast<double>(load_count(c, g0 + j, bad));
+        double k = static_cast<double>(ys ? ys[j] : load_count<DT>(c, g0 + j, bad));
         s1 += k; s2 += k * k;
     }
     double a1, a2, t1, t2;
-    block_exscan2(s1, s2, a1, a2, t1, t2, sh);
+    block_exscan2<NT>(s1, s2, a1, a2, t1, t2, sh);
 
     const double var_summed = static_cast<double>(n) * log(ref_var(t1, t2, n, c.q, c.q2));
     double best = thresh;
@@ -189,23 +277,304 @@ __device__ int scan_window(const DevCfg &c, int64_t base, int ps, int pe, int ca
             if (scores) scores[i] = gain;
             if (gain > best) { best = gain; bi = i; }
         }
-        double k = static_cast<double>(load_count(c, g0 + j, bad));
+        double k = static_cast<double>(ys ? ys[j] : load_count<DT>(c, g0 + j, bad));
         a1 += k; a2 += k * k;
     }
-    int r = block_argmax(best, bi, sh);
+    return block_argmax<NT>(best, bi, sh, best_gain_out);
+}
+
+// ---- fp32 screen ---------------------------------------------------------------------------------
+// Bound on |screened gain - reference gain| in log2 units for a window of n samples
+// (DESIGN.md "error budget of the screen"): per side, D = nL*p2 - p1^2 carries <= 3*eps*kappa
+// (kappa <= 4 enforced), two rcp and two products 6*eps, v_log_f32 <= 1 ulp at |log2| < 32,
+// the subtraction of c0 and the two final products ~3*eps*|term|; all times nL+nR = n.
+__device__ __forceinline__ float screen_delta_log2(int n) { return 0.02f + 8.0e-6f * static_cast<float>(n); }
+
+struct Top2 { float b, s; int i; };
+
+// Screened gain (log2 units, relative to the whole window) of one candidate from the exact
+// integer moment sums about the chunk's centres: left (p1 = sum z, p2 = sum z^2, nl samples),
+// right (r1, r2, nr).  `guard` accumulates the validity margins (kappa <= 4, variance floor).
+__device__ __forceinline__ float screen_gain(int p1, unsigned p2, int r1, unsigned r2, float nlf, float nrf,
+                                             float c0, float vfloor, float &guard)
+{
+    const float p1f = static_cast<float>(p1), p2f = static_cast<float>(p2);
+    const float r1f = static_cast<float>(r1), r2f = static_cast<float>(r2);
+    const float np2 = nlf * p2f, nr2 = nrf * r2f;
+    const float DL = fmaf(-p1f, p1f, np2), DR = fmaf(-r1f, r1f, nr2);
+    const float rl = __builtin_amdgcn_rcpf(nlf), rr = __builtin_amdgcn_rcpf(nrf);
+    const float uL = DL * rl * rl, uR = DR * rr * rr;              // variances (counts^2)
+    guard = fminf(guard, fminf(fmaf(4.0f, DL, -np2), fmaf(4.0f, DR, -nr2)));   // kappa <= 4
+    guard = fminf(guard, fminf(uL, uR) - vfloor);
+    const float wl = __builtin_amdgcn_logf(uL) - c0, wr = __builtin_amdgcn_logf(uR) - c0;
+    return -fmaf(nlf, wl, nrf * wr);
+}
+
+__device__ __forceinline__ void top2_push(Top2 &t, float g, int i)
+{
+    if (g > t.b) { t.s = t.b; t.b = g; t.i = i; }
+    else t.s = fmaxf(t.s, g);
+}
+__device__ __forceinline__ void top2_merge(Top2 &t, float ob, float os, int oi)
+{
+    // equal values at different indices must register as a tie: second == best
+    if (ob > t.b) { t.s = fmaxf(t.b, os); t.b = ob; t.i = oi; }
+    else t.s = fmaxf(t.s, ob);
+}
+
+// Returns 1 if the screen produced a final answer (result in *split), 0 if the exact path is
+// needed.  All threads return the same value.
+template <int NT>
+__device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int cand_lo, int cand_hi,
+                           double thresh, int kmin, int kmax, Shared &sh, int *split, Work &wk)
+{
+    constexpr int NW = NT / 64;
+    const int ch = ((n + NT - 1) / NT) | 1;           // odd lane stride: conflict-free ds_read_b32
+    const int lo = min(n, static_cast<int>(threadIdx.x) * ch);
+    const int hi = min(n, lo + ch);
+    const int R = kmax - kmin;                        // |k - centre| <= R for any centre in [kmin,kmax]
+    // integer moment sums must stay exact: chunk sums below 2^31, squares below 2^30
+    if (R >= 32768 || static_cast<long long>(ch + 1) * (static_cast<long long>(R) * R) >= (1LL << 31)) return 0;
+    const int m0 = kmin + (R >> 1);
+
+    int s1 = 0;
+    unsigned s2 = 0;
+    for (int j = lo; j < hi; ++j) {
+        const int y = ys[j] - m0;
+        s1 += y;
+        s2 += static_cast<unsigned>(__mul24(y, y));
+    }
+    PS_STAMP_AT(wk, 2);                                // chunk sums from LDS
+    double a1, a2, t1, t2;
+    block_exscan2<NT>(static_cast<double>(s1), static_cast<double>(s2), a1, a2, t1, t2, sh);
+    PS_STAMP_AT(wk, 3);                                // workgroup scan
+
+    const double dn = static_cast<double>(n);
+    const double Dtot = dn * t2 - t1 * t1;            // n^2 * variance (shift invariant)
+    if (!(Dtot > 0.0)) return 0;                      // zero-variance window: reference inf/NaN path
+    const float c0 = __builtin_amdgcn_logf(static_cast<float>(Dtot / (dn * dn)));   // log2, same in all threads
+    // candidates of this thread: window-local j in [clo, chi)
+    const int clo = max(lo, cand_lo - ps), chi = min(hi, cand_hi - ps + 1);
+    Top2 top = {-INFINITY, -INFINITY, -1};
+    unsigned flag = 0;
+    float guard = INFINITY;                           // min over candidates of the validity margins
+    if (clo < chi) {
+        for (int j = lo; j < clo; ++j) {              // advance the exact prefix to the first candidate
+            const double y = static_cast<double>(ys[j] - m0);
+            a1 += y; a2 += y * y;
+        }
+        const double nl0 = static_cast<double>(clo), nr0 = static_cast<double>(n - clo);
+        const double b1 = t1 - a1, b2 = t2 - a2;
+        // per-chunk re-centring on the (rounded) left and right means: exact integer sums of
+        // (k-cL), (k-cL)^2 and (k-cR), (k-cR)^2 -> D = n*p2 - p1^2 has no cancellation
+        const double muL = rint(a1 / nl0), muR = rint(b1 / nr0);
+        const double p1d = a1 - nl0 * muL, p2d = a2 - muL * (2.0 * a1 - nl0 * muL);
+        const double r1d = b1 - nr0 * muR, r2d = b2 - muR * (2.0 * b1 - nr0 * muR);
+        const double room = static_cast<double>(chi - clo) * (static_cast<double>(R) + 1.0) * (static_cast<double>(R) + 1.0);
+        if (!(p2d + room < 4294967296.0) || !(r2d < 4294967296.0) || !(fabs(p1d) + room < 2147483648.0) ||
+            !(fabs(r1d) + room < 2147483648.0))
+            flag = 1;
+        int p1 = static_cast<int>(p1d), r1 = static_cast<int>(r1d);
+        unsigned p2 = static_cast<unsigned>(p2d), r2 = static_cast<unsigned>(r2d);
+        const int cL = m0 + static_cast<int>(muL), cR = m0 + static_cast<int>(muR);
+        float nlf = static_cast<float>(clo), nrf = static_cast<float>(n - clo);
+        // reference noise floor: below this variance (counts^2) the reference's own
+        // c2/n - (c/n)^2 loses more than ~1e-3 of gain to cancellation -> decide exactly
+        const float mabs = fmaxf(fabsf(static_cast<float>(kmin)), fabsf(static_cast<float>(kmax)));
+        const float vfloor = mabs * mabs * 1.0e-9f;
+        if (!flag) {
+            // 4 candidates per trip: the integer moment recurrences are sequential but cheap,
+            // the four float pipelines (rcp, log2, fma) are independent and overlap.
+            int j = clo;
+            for (; j + 4 <= chi; j += 4) {
+                int q1[4], q3[4];
+                unsigned q2[4], q4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    q1[u] = p1; q2[u] = p2; q3[u] = r1; q4[u] = r2;
+                    const int k = ys[j + u];
+                    const int zl = k - cL, zr = k - cR;
+                    p1 += zl; p2 += static_cast<unsigned>(__mul24(zl, zl));
+                    r1 -= zr; r2 -= static_cast<unsigned>(__mul24(zr, zr));
+                }
+                float g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    g[u] = screen_gain(q1[u], q2[u], q3[u], q4[u], nlf + static_cast<float>(u),
+                                       nrf - static_cast<float>(u), c0, vfloor, guard);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) top2_push(top, g[u], ps + j + u);
+                nlf += 4.0f; nrf -= 4.0f;
+            }
+            for (; j < chi; ++j) {
+                const float g = screen_gain(p1, p2, r1, r2, nlf, nrf, c0, vfloor, guard);
+                top2_push(top, g, ps + j);
+                const int k = ys[j];
+                const int zl = k - cL, zr = k - cR;
+                p1 += zl; p2 += static_cast<unsigned>(__mul24(zl, zl));
+                r1 -= zr; r2 -= static_cast<unsigned>(__mul24(zr, zr));
+                nlf += 1.0f; nrf -= 1.0f;
+            }
+            if (!(guard >= 0.0f)) flag = 1;           // also catches NaN
+        }
+    }
+    PS_STAMP_AT(wk, 4);                                // per-thread setup + candidate loop
+    // workgroup top-2 + flags
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#define PS_STEP(CTRL, RM) { const float ob = dpp_movf<CTRL, RM>(-INFINITY, top.b), os = dpp_movf<CTRL, RM>(-INFINITY, top.s); \
+                            const int oi = dpp_mov<CTRL, RM>(-1, top.i); const int of = dpp_mov<CTRL, RM>(0, static_cast<int>(flag)); \
+                            top2_merge(top, ob, os, oi); flag |= static_cast<unsigned>(of); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    if (lane == 63) { sh.fbest[wave] = top.b; sh.fsecond[wave] = top.s; sh.fidx[wave] = top.i; sh.wflag[wave] = flag; }
+    __syncthreads();
+    Top2 all = {sh.fbest[0], sh.fsecond[0], sh.fidx[0]};
+    unsigned anyflag = sh.wflag[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        top2_merge(all, sh.fbest[w], sh.fsecond[w], sh.fidx[w]);
+        anyflag |= sh.wflag[w];
+    }
+    PS_STAMP_AT(wk, 5);                                // top-2 reduce + barrier
+    if (anyflag) return 0;
+    const float dlt = screen_delta_log2(n);
+    const float LN2 = 0.6931471805599453f;
+    const float thr_log2 = static_cast<float>(thresh * 1.4426950408889634);
+    const float dthr = dlt + 3.0e-6f * static_cast<float>(n) + 1.0e-6f * fabsf(thr_log2);   // + error of c0, of thr_log2
+    (void)LN2;
+    if (all.b < thr_log2 - dthr) { *split = -1; return 1; }                // certainly no candidate above min_gain
+    if (all.b > thr_log2 + dthr && all.s < all.b - 2.0f * dlt) { *split = all.i; return 1; }   // unique, clear winner
+    return 0;
+}
+
+// ---- one window scan: cparsers.pyx:157-178 ------------------------------------------------------
+// Window [ps, pe) of the event at `base`; candidates cand_lo..cand_hi (inclusive, event-local);
+// returns the first index whose gain strictly exceeds every earlier gain and `thresh`, or -1.
+template <int NT, int DT>
+__device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
+                           double thresh, double *scores, Shared &sh, unsigned &bad, Work &wk,
+                           double *best_gain_out = nullptr, int pf_end = 0)
+{
+    constexpr int NW = NT / 64;
+    const int n = pe - ps;
+    const int64_t g0 = base + ps;
+    PS_STAMP_AT(wk, 7);                                // time outside scans (recursion control, stack)
     if (threadIdx.x == 0) {
         wk.windows += 1;
         wk.cands += (cand_hi >= cand_lo) ? (cand_hi - cand_lo + 1) : 0;
-        if (best_gain_out) *best_gain_out = sh.wbest[0];
     }
-    return r;
+    if (n > c.lds_cap) {                               // window larger than LDS: exact path from HBM
+        if (threadIdx.x == 0) wk.exact += 1;
+        return scan_exact<NT, DT>(c, nullptr, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
+    }
+    // 1. stage: 16-byte loads (4 fp32 / 8 int16 per lane), all of a thread's loads issued before
+    //    the first use, one ds_write_b128 per 4 samples.  The staged region starts at the 16-byte
+    //    boundary at or below the window start (`off` leading elements are not part of the window).
+    constexpr int ES = static_cast<int>(sizeof(typename Raw<DT>::type));
+    constexpr int EPV = 16 / ES;
+    const char *addr0 = static_cast<const char *>(c.samples) + g0 * ES;
+    const int off = static_cast<int>((reinterpret_cast<uintptr_t>(addr0) & 15u) / ES);
+    const int4 *vsrc = reinterpret_cast<const int4 *>(addr0 - off * ES);
+    const int nv = (n + off + EPV - 1) / EPV;          // 16-byte vectors covering the window
+    int *ysw = ys + off;                               // ysw[j] = sample j of the window
+    int kmin = 0x7fffffff, kmax = static_cast<int>(0x80000000);
+    unsigned fracbits = 0;
+    // (the previous scan's last read of ys is followed by a barrier in its reduction)
+    constexpr int STAGE_U = (NT >= 1024) ? 3 : (NT >= 512 ? 5 : 10);     // covers 12k fp32 samples per trip
+    for (int v0 = threadIdx.x; v0 < nv; v0 += NT * STAGE_U) {
+        int4 raw[STAGE_U];
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u) raw[u] = vsrc[min(v0 + u * NT, nv - 1)];
+        PS_STAMP_AT(wk, 8);                            // (diagnostic) loads issued
+#ifdef PS_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PS_STAMP_AT(wk, 9);                            // (diagnostic) loads returned
+#endif
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u) {
+            const int v = v0 + u * NT;
+            if (v < nv) {
+            int k[EPV];
+            if (DT == PS_DTYPE_F32) {
+                const float f[4] = {__int_as_float(raw[u].x), __int_as_float(raw[u].y), __int_as_float(raw[u].z),
+                                    __int_as_float(raw[u].w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float kf = f[e] * c.inv_q;
+                    const float kr = rintf(kf);
+                    k[e] = static_cast<int>(kr);
+                    const bool in = (v > 0 && v < nv - 1) || (v * EPV + e >= off && v * EPV + e < off + n);
+                    // off-grid samples leave a non-zero (or NaN) remainder
+                    fracbits |= in ? __float_as_uint(kf - kr) : 0u;
+                    kmin = min(kmin, in ? k[e] : 0x7fffffff);
+                    kmax = max(kmax, in ? k[e] : static_cast<int>(0x80000000));
+                }
+            } else {
+                const int w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    k[e] = ((e & 1) ? (w[e >> 1] >> 16) : static_cast<int>(static_cast<short>(w[e >> 1] & 0xffff))) + c.off_counts;
+                    const bool in = (v > 0 && v < nv - 1) || (v * EPV + e >= off && v * EPV + e < off + n);
+                    kmin = min(kmin, in ? k[e] : 0x7fffffff);
+                    kmax = max(kmax, in ? k[e] : static_cast<int>(0x80000000));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4)
+                *reinterpret_cast<int4 *>(&ys[v * EPV + e]) = make_int4(k[e], k[e + 1], k[e + 2], k[e + 3]);
+            }
+        }
+    }
+    if (fracbits & 0x7fffffffu) bad |= ST_OFF_GRID;
+    // L2 prefetch of the samples the NEXT scan of this chain will need ([pe, pf_end)): one dword
+    // per 128-byte line, issued AFTER the staging data has been consumed (vmcnt returns in order,
+    // so nothing of this window waits behind them) and retired only at the end of this scan:
+    // the HBM latency of the next window overlaps the evaluation of this one.
+    constexpr int PF_STRIDE = 128 / ES;
+    int pf_val = 0;
+    {
+        const long long pi = static_cast<long long>(pe) + static_cast<long long>(threadIdx.x) * PF_STRIDE;
+        if (pi < pf_end) pf_val = *reinterpret_cast<const int *>(static_cast<const char *>(c.samples) + ((base + pi) * ES & ~3LL));
+    }
+    PS_STAMP_AT(wk, 0);                                // stage: HBM loads -> LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_minmax(kmin, kmax);
+    if (lane == 63) { sh.wmin[wave] = kmin; sh.wmax[wave] = kmax; }
+    __syncthreads();
+    kmin = sh.wmin[0]; kmax = sh.wmax[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { kmin = min(kmin, sh.wmin[w]); kmax = max(kmax, sh.wmax[w]); }
+    if (DT == PS_DTYPE_F32 && (kmin <= -8388608 || kmax >= 8388608)) bad |= ST_OFF_GRID;   // |count| >= 2^23
+    PS_STAMP_AT(wk, 1);                                // min/max reduce + barrier
+
+    const bool want_screen = c.mode != MODE_EXACT && scores == nullptr && best_gain_out == nullptr;
+    int split = -1, result;
+    bool decided = false;
+    if (want_screen) {
+        const int done = scan_screen<NT>(c, ysw, ps, n, cand_lo, cand_hi, thresh, kmin, kmax, sh, &split, wk);
+        if (done && c.mode == MODE_FAST) { result = split; decided = true; }
+        else if (c.mode == MODE_VERIFY) {
+            result = scan_exact<NT, DT>(c, ysw, g0, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);
+            if (done && result != split) bad |= ST_VERIFY_MISMATCH;
+            if (!done && threadIdx.x == 0) wk.exact += 1;
+            decided = true;
+        }
+    }
+    if (!decided) {
+        if (threadIdx.x == 0) wk.exact += 1;
+        result = scan_exact<NT, DT>(c, ysw, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
+        PS_STAMP_AT(wk, 6);                            // exact rescans
+    }
+    asm volatile("" :: "v"(pf_val));                   // retire the prefetch load here, not earlier
+    return result;
 }
 
 // ---- the window loop of _recursive_split: cparsers.pyx:186-201 ---------------------------------
 // Windows j < j0 are known to hold no split (they were scanned with identical bounds by the
 // parent frame, DESIGN.md "memoised left child").
-__device__ int find_split(const DevCfg &c, int64_t base, int start, int end, int j0, int &kind,
-                          Shared &sh, unsigned &bad, Work &wk)
+template <int NT, int DT>
+__device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
+                          Shared &sh, unsigned &bad, Work &wk, long long pf_lim)
 {
     const long long lim = static_cast<long long>(end) - 2LL * c.mw;
     for (long long ps = static_cast<long long>(start) + static_cast<long long>(j0) * c.half; ps < lim;
@@ -219,9 +588,10 @@ __device__ int find_split(const DevCfg &c, int64_t base, int start, int end, int
         if (pe > end) pe = end;                                         // :193
         int s = -1;
         if (pe - ps > 2LL * c.mw)                                       // :164
-            s = scan_window(c, base, static_cast<int>(ps), static_cast<int>(pe),
-                            static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
-                            c.min_gain, nullptr, sh, bad, wk);
+            s = scan_window<NT, DT>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
+                                static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
+                                c.min_gain, nullptr, sh, bad, wk, nullptr,
+                                static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim));
         if (s >= 0) { kind = KIND_HIT; return s; }                      // :195-196
     }
     if (static_cast<long long>(end) - start <= c.maxw) { kind = KIND_NONE; return -1; }   // :199-200
@@ -242,6 +612,10 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
     if (threadIdx.x == 0) {
         atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
         atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
+        if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
+#ifdef PS_STAMP
+        for (int i = 0; i < 12; ++i) atomicAdd(&work[4 + i], static_cast<unsigned long long>(wk.ph[i]));
+#endif
     }
 }
 
@@ -249,22 +623,31 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
 // out (private scratch, int2 = (anchor, kind)); meta[job] = (count, ended, dense position).
 // After the chain stops, the workgroup reserves `count` slots in the dense list with one
 // atomic and copies its anchors there so the host fetches a compact array.
-__global__ __launch_bounds__(NT) void spine_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch,
+template <int NT, int DT>
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void spine_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch,
                                                    int2 *dense, int4 *meta, unsigned long long *dense_count,
                                                    unsigned *status, unsigned long long *work)
 {
+    extern __shared__ int ys[];
     __shared__ Shared sh;
     const SpineJob job = jobs[blockIdx.x];
     int2 *out = scratch + job.out_off;
     unsigned bad = 0;
-    Work wk = {0, 0};
-    int a = job.start, cnt = 0, ended = 0;
+    Work wk = PS_WORK_INIT;
+    int a = job.start, cnt = 0, ended = 0, flushed = 0;
     for (;;) {
         int kind;
-        int s = find_split(c, job.base, a, job.end, 0, kind, sh, bad, wk);
+        int s = find_split<NT, DT>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
         if (kind == KIND_NONE) { ended = 1; break; }
-        if (cnt < job.out_cap) { if (threadIdx.x == 0) out[cnt] = make_int2(s, kind); }
-        else bad |= ST_OUT_OVERFLOW;
+        if (cnt - flushed == OBUF) {                   // rare: spill the LDS buffer to the private scratch
+            __syncthreads();
+            for (int i = threadIdx.x; i < OBUF; i += NT)
+                if (flushed + i < job.out_cap) out[flushed + i] = sh.obuf[i];
+            flushed += OBUF;
+            __syncthreads();
+        }
+        if (cnt >= job.out_cap) bad |= ST_OUT_OVERFLOW;
+        if (threadIdx.x == 0) sh.obuf[cnt - flushed] = make_int2(s, kind);
         ++cnt;
         a = s;
         if (a >= job.stop) break;
@@ -276,27 +659,43 @@ __global__ __launch_bounds__(NT) void spine_kernel(DevCfg c, const SpineJob *job
         meta[blockIdx.x] = make_int4(cnt, ended, static_cast<int>(pos), 0);
         sh.bcast = static_cast<int>(pos);
     }
-    __syncthreads();      // also orders thread 0's stores to `out` before the workgroup reads them
+    __syncthreads();
     const int pos = sh.bcast;
-    for (int i = threadIdx.x; i < cnt; i += NT) dense[pos + i] = out[i];
+    for (int i = threadIdx.x; i < cnt; i += NT) dense[pos + i] = i < flushed ? out[i] : sh.obuf[i - flushed];
     flush(bad, wk, status, work);
 }
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
-__global__ __launch_bounds__(NT) void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+template <int NT, int DT>
+__global__ __launch_bounds__(NT, 4) void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work)
 {
+    extern __shared__ int ys[];
     __shared__ Shared sh;
     const TreeJob job = jobs[blockIdx.x];
     int32_t *out = scratch + job.out_off;
     int2 *sp_glob = spill + job.out_off;
     unsigned bad = 0;
-    Work wk = {0, 0};
-    int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0;
+    Work wk = PS_WORK_INIT;
+    int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0, flushed = 0;
+    int *obuf = reinterpret_cast<int *>(sh.obuf);
+    constexpr int OB = 2 * OBUF;
+    auto emit = [&](int v) {
+        if (cnt - flushed == OB) {                     // rare: spill the LDS buffer to the private scratch
+            __syncthreads();
+            for (int i = threadIdx.x; i < OB; i += NT)
+                if (flushed + i < job.out_cap) out[flushed + i] = obuf[i];
+            flushed += OB;
+            __syncthreads();
+        }
+        if (cnt >= job.out_cap) bad |= ST_OUT_OVERFLOW;
+        if (threadIdx.x == 0) obuf[cnt - flushed] = v;
+        ++cnt;
+    };
     for (;;) {
         int kind;
-        int s = find_split(c, job.base, start, end, j0, kind, sh, bad, wk);
+        int s = find_split<NT, DT>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end);
         if (kind == KIND_NONE) {
             if (sp == 0) break;
             --sp;
@@ -304,16 +703,12 @@ __global__ __launch_bounds__(NT) void tree_kernel(DevCfg c, const TreeJob *jobs,
             __syncthreads();
             const int2 top = sh.pop;
             __syncthreads();
-            if (cnt < job.out_cap) { if (threadIdx.x == 0) out[cnt] = top.x; }
-            else bad |= ST_OUT_OVERFLOW;
-            ++cnt;
+            emit(top.x);
             start = top.x; end = top.y; j0 = 0;
             continue;
         }
         if (kind == KIND_EARLY) {                     // [split] + rec(split, end)
-            if (cnt < job.out_cap) { if (threadIdx.x == 0) out[cnt] = s; }
-            else bad |= ST_OUT_OVERFLOW;
-            ++cnt;
+            emit(s);
             start = s; j0 = 0;
             continue;
         }
@@ -331,28 +726,33 @@ __global__ __launch_bounds__(NT) void tree_kernel(DevCfg c, const TreeJob *jobs,
         j0 = left_child_j0(start, s, c.W, c.half);
         end = s;
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = cnt < job.out_cap ? cnt : job.out_cap;
+    if (cnt > job.out_cap) cnt = job.out_cap;
+    __syncthreads();
+    for (int i = flushed + threadIdx.x; i < cnt; i += NT) out[i] = obuf[i - flushed];
+    if (threadIdx.x == 0) counts[blockIdx.x] = cnt;
     flush(bad, wk, status, work);
 }
 
 // ---- single scans for the API-completeness entry points -----------------------------------------
 // mode 0: score_samples(no_split=True)  (window [0,n), candidates mw..n-mw, threshold min_gain)
 // mode 1: best_single_split              (window [0,n-1), candidates 2..n-4, threshold 0)
+template <int NT, int DT>
 __global__ __launch_bounds__(NT) void single_scan_kernel(DevCfg c, int n, int mode, double *scores,
                                                          double *gain_out, int *idx_out,
                                                          unsigned *status, unsigned long long *work)
 {
+    extern __shared__ int ys[];
     __shared__ Shared sh;
     unsigned bad = 0;
-    Work wk = {0, 0};
+    Work wk = PS_WORK_INIT;
     int r = -1;
-    double g = 0.0;
+    double g = mode == 0 ? c.min_gain : 0.0;
     if (mode == 0) {
         if (n > 2 * c.mw)
-            r = scan_window(c, 0, 0, n, c.mw, n - c.mw, c.min_gain, scores, sh, bad, wk, &g);
+            r = scan_window<NT, DT>(c, ys, 0, 0, n, c.mw, n - c.mw, c.min_gain, scores, sh, bad, wk, &g);
     } else {
         const int end = n - 1;
-        if (end >= 1) r = scan_window(c, 0, 0, end, 2, end - 3, 0.0, nullptr, sh, bad, wk, &g);
+        if (end >= 1) r = scan_window<NT, DT>(c, ys, 0, 0, end, 2, end - 3, 0.0, nullptr, sh, bad, wk, &g);
     }
     if (threadIdx.x == 0) { *idx_out = r; *gain_out = g; }
     flush(bad, wk, status, work);
@@ -422,12 +822,15 @@ __global__ void event_offsets_kernel(const int64_t *pos, const int64_t *first_it
 // ---- K2: per-segment statistics, core.py:209-223 ------------------------------------------------
 // One workgroup per segment.  Sums of counts and counts^2 are exact (fp64 holds the integers),
 // mean = q*S1/n, std = q*sqrt(S2/n - (S1/n)^2) (population), min/max exact.
-__global__ __launch_bounds__(NT) void segstat_kernel(DevCfg c, const int64_t *ev_off, int32_t n_ev,
-                                                     const int32_t *bounds, const int64_t *bounds_off,
-                                                     ps_segstat *stats, unsigned *status)
+constexpr int STAT_NT = 256;
+template <int DT>
+__global__ __launch_bounds__(STAT_NT) void segstat_kernel(DevCfg c, const int64_t *ev_off, int32_t n_ev,
+                                                          const int32_t *bounds, const int64_t *bounds_off,
+                                                          ps_segstat *stats, unsigned *status)
 {
-    __shared__ Shared sh;
-    __shared__ int smin[NWAVE], smax[NWAVE];
+    constexpr int NW = STAT_NT / 64;
+    __shared__ double ws1[NW], ws2[NW];
+    __shared__ int smin[NW], smax[NW];
     const int64_t g = blockIdx.x;
     // event e: bounds_off[e] + e <= g < bounds_off[e+1] + e + 1
     int lo = 0, hi = n_ev - 1;
@@ -446,8 +849,8 @@ __global__ __launch_bounds__(NT) void segstat_kernel(DevCfg c, const int64_t *ev
     unsigned bad = 0;
     double s1 = 0, s2 = 0;
     int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);
-    for (int i = a + threadIdx.x; i < b; i += NT) {
-        int k = load_count(c, g0 + i, bad);
+    for (int i = a + threadIdx.x; i < b; i += STAT_NT) {
+        int k = load_count<DT>(c, g0 + i, bad);
         double d = static_cast<double>(k);
         s1 += d; s2 += d * d;
         mn = k < mn ? k : mn; mx = k > mx ? k : mx;
@@ -459,13 +862,13 @@ __global__ __launch_bounds__(NT) void segstat_kernel(DevCfg c, const int64_t *ev
         int om = __shfl_down(mn, d), ox = __shfl_down(mx, d);
         mn = om < mn ? om : mn; mx = ox > mx ? ox : mx;
     }
-    if (lane == 0) { sh.wsum1[wave] = s1; sh.wsum2[wave] = s2; smin[wave] = mn; smax[wave] = mx; }
+    if (lane == 0) { ws1[wave] = s1; ws2[wave] = s2; smin[wave] = mn; smax[wave] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double t1 = 0, t2 = 0;
         int tm = 0x7fffffff, tx = static_cast<int>(0x80000000);
-        for (int w = 0; w < NWAVE; ++w) {
-            t1 += sh.wsum1[w]; t2 += sh.wsum2[w];
+        for (int w = 0; w < NW; ++w) {
+            t1 += ws1[w]; t2 += ws2[w];
             tm = smin[w] < tm ? smin[w] : tm; tx = smax[w] > tx ? smax[w] : tx;
         }
         ps_segstat r;
