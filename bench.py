@@ -65,8 +65,13 @@ def main():
     params = _lib.split_params(**PARAMS)
     torch.cuda.synchronize()
 
+    from pypore_amd import dist as pdist
+
     def step():
-        return ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats)
+        b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats)
+        if world > 1:
+            pdist.gather_varlen(b)                       # the final boundary-index gather (RCCL)
+        return b, o, st
 
     def barrier():
         torch.cuda.synchronize()
