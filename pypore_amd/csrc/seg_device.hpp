@@ -292,28 +292,38 @@ __device__ __forceinline__ float screen_delta_log2(int n) { return 0.02f + 8.0e-
 
 struct Top2 { float b, s; int i; };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 // Screened gain (log2 units, relative to the whole window) of one candidate from the exact
 // integer moment sums about the chunk's centres: left (p1 = sum z, p2 = sum z^2, nl samples),
-// right (r1, r2, nr).  `guard` accumulates the validity margins (kappa <= 4, variance floor).
-__device__ __forceinline__ float screen_gain(int p1, unsigned p2, int r1, unsigned r2, float nlf, float nrf,
-                                             float c0, float vfloor, float &guard)
+// right (r1, r2, nr).  The (left, right) pair is carried in 2-wide vectors so the arithmetic
+// maps to v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32.  `guard` accumulates the validity margins
+// (kappa = n*p2/D <= 4 and the variance floor) with v_min3_f32.
+__device__ __forceinline__ float screen_gain(int p1, unsigned p2, int r1, unsigned r2, f2 nv, float c0,
+                                             float vfloor, float &guard)
 {
-    const float p1f = static_cast<float>(p1), p2f = static_cast<float>(p2);
-    const float r1f = static_cast<float>(r1), r2f = static_cast<float>(r2);
-    const float np2 = nlf * p2f, nr2 = nrf * r2f;
-    const float DL = fmaf(-p1f, p1f, np2), DR = fmaf(-r1f, r1f, nr2);
-    const float rl = __builtin_amdgcn_rcpf(nlf), rr = __builtin_amdgcn_rcpf(nrf);
-    const float uL = DL * rl * rl, uR = DR * rr * rr;              // variances (counts^2)
-    guard = fminf(guard, fminf(fmaf(4.0f, DL, -np2), fmaf(4.0f, DR, -nr2)));   // kappa <= 4
-    guard = fminf(guard, fminf(uL, uR) - vfloor);
-    const float wl = __builtin_amdgcn_logf(uL) - c0, wr = __builtin_amdgcn_logf(uR) - c0;
-    return -fmaf(nlf, wl, nrf * wr);
+    const f2 s1 = {static_cast<float>(p1), static_cast<float>(r1)};
+    const f2 s2 = {static_cast<float>(p2), static_cast<float>(r2)};
+    const f2 ns2 = nv * s2;
+    const f2 D = __builtin_elementwise_fma(-s1, s1, ns2);                 // n*p2 - p1^2
+    const f2 four = {4.0f, 4.0f};
+    const f2 g = __builtin_elementwise_fma(four, D, -ns2);                // >= 0  <=>  kappa <= 4
+    const f2 r = {__builtin_amdgcn_rcpf(nv.x), __builtin_amdgcn_rcpf(nv.y)};
+    const f2 u = D * r * r;                                               // variances (counts^2)
+    guard = fminf(guard, fminf(g.x, g.y));
+    guard = fminf(guard, fminf(u.x, u.y) - vfloor);
+    const f2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+    const f2 cc = {c0, c0};
+    const f2 t = nv * (lg - cc);
+    return -(t.x + t.y);
 }
 
 __device__ __forceinline__ void top2_push(Top2 &t, float g, int i)
 {
-    if (g > t.b) { t.s = t.b; t.b = g; t.i = i; }
-    else t.s = fmaxf(t.s, g);
+    // second largest of {b, s, g} with s <= b is their median; an exact tie gives s == b
+    t.s = __builtin_amdgcn_fmed3f(t.b, g, t.s);
+    t.i = g > t.b ? i : t.i;
+    t.b = fmaxf(t.b, g);
 }
 __device__ __forceinline__ void top2_merge(Top2 &t, float ob, float os, int oi)
 {
@@ -377,7 +387,8 @@ __device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int ca
         int p1 = static_cast<int>(p1d), r1 = static_cast<int>(r1d);
         unsigned p2 = static_cast<unsigned>(p2d), r2 = static_cast<unsigned>(r2d);
         const int cL = m0 + static_cast<int>(muL), cR = m0 + static_cast<int>(muR);
-        float nlf = static_cast<float>(clo), nrf = static_cast<float>(n - clo);
+        f2 nv = {static_cast<float>(clo), static_cast<float>(n - clo)};
+        const f2 step1 = {1.0f, -1.0f};
         // reference noise floor: below this variance (counts^2) the reference's own
         // c2/n - (c/n)^2 loses more than ~1e-3 of gain to cancellation -> decide exactly
         const float mabs = fmaxf(fabsf(static_cast<float>(kmin)), fabsf(static_cast<float>(kmax)));
@@ -399,21 +410,21 @@ __device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int ca
                 }
                 float g[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    g[u] = screen_gain(q1[u], q2[u], q3[u], q4[u], nlf + static_cast<float>(u),
-                                       nrf - static_cast<float>(u), c0, vfloor, guard);
+                for (int u = 0; u < 4; ++u) {
+                    g[u] = screen_gain(q1[u], q2[u], q3[u], q4[u], nv, c0, vfloor, guard);
+                    nv += step1;
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) top2_push(top, g[u], ps + j + u);
-                nlf += 4.0f; nrf -= 4.0f;
             }
             for (; j < chi; ++j) {
-                const float g = screen_gain(p1, p2, r1, r2, nlf, nrf, c0, vfloor, guard);
+                const float g = screen_gain(p1, p2, r1, r2, nv, c0, vfloor, guard);
                 top2_push(top, g, ps + j);
                 const int k = ys[j];
                 const int zl = k - cL, zr = k - cR;
                 p1 += zl; p2 += static_cast<unsigned>(__mul24(zl, zl));
                 r1 -= zr; r2 -= static_cast<unsigned>(__mul24(zr, zr));
-                nlf += 1.0f; nrf -= 1.0f;
+                nv += step1;
             }
             if (!(guard >= 0.0f)) flag = 1;           // also catches NaN
         }
