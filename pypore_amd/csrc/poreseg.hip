@@ -67,6 +67,7 @@ struct ps_ctx {
     int64_t tile_len = 0, halo = 0;
     int mode = MODE_FAST, spine_nt = 512, tree_nt = 256;
     int lds_max_samples = 0;
+    int rep_eval = 1, rep_stage = 1, rep_sum = 1;
     DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
         tree_counts, items, item_pos, first_item, ev_off, bounds_off, small;
     HostBuf h_meta, h_dense, h_small, h_up;
@@ -120,6 +121,7 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->min_gain = min_gain;
     c->mode = ctx->mode;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
+    c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
 }
 
@@ -189,7 +191,9 @@ int run_spines(ps_ctx *ctx, const DevCfg &cfg, const std::vector<SpineJob> &jobs
     {
         const unsigned g = static_cast<unsigned>(nj);
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
-        int lrc = ctx->spine_nt == 512
+        int lrc = ctx->spine_nt == 256
+                      ? (f32 ? launch_spine<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_spine<256, PS_DTYPE_I16>(ctx, cfg, g, sm))
+                  : ctx->spine_nt == 512
                       ? (f32 ? launch_spine<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_spine<512, PS_DTYPE_I16>(ctx, cfg, g, sm))
                       : (f32 ? launch_spine<1024, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_spine<1024, PS_DTYPE_I16>(ctx, cfg, g, sm));
         if (lrc) return lrc;
@@ -273,6 +277,9 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_MODE")) ctx->mode = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_SPINE_NT")) ctx->spine_nt = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_TREE_NT")) ctx->tree_nt = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_REP_EVAL")) ctx->rep_eval = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_REP_STAGE")) ctx->rep_stage = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
     *out = ctx;

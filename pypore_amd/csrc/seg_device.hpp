@@ -45,6 +45,7 @@ struct DevCfg {
     double min_gain;
     int mode;               // MODE_*
     int lds_cap;            // samples that fit the dynamic LDS window buffer
+    int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
 
 struct SpineJob {           // speculative spine of one tile: rec(start, end) without left subtrees
@@ -299,8 +300,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // right (r1, r2, nr).  The (left, right) pair is carried in 2-wide vectors so the arithmetic
 // maps to v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32.  `guard` accumulates the validity margins
 // (kappa = n*p2/D <= 4 and the variance floor) with v_min3_f32.
-__device__ __forceinline__ float screen_gain(int p1, unsigned p2, int r1, unsigned r2, f2 nv, float c0,
-                                             float vfloor, float &guard)
+__device__ __forceinline__ float screen_gain(int p1, unsigned p2, int r1, unsigned r2, f2 nv, f2 cc,
+                                             float &kguard, float &umin)
 {
     const f2 s1 = {static_cast<float>(p1), static_cast<float>(r1)};
     const f2 s2 = {static_cast<float>(p2), static_cast<float>(r2)};
@@ -310,10 +311,9 @@ __device__ __forceinline__ float screen_gain(int p1, unsigned p2, int r1, unsign
     const f2 g = __builtin_elementwise_fma(four, D, -ns2);                // >= 0  <=>  kappa <= 4
     const f2 r = {__builtin_amdgcn_rcpf(nv.x), __builtin_amdgcn_rcpf(nv.y)};
     const f2 u = D * r * r;                                               // variances (counts^2)
-    guard = fminf(guard, fminf(g.x, g.y));
-    guard = fminf(guard, fminf(u.x, u.y) - vfloor);
+    kguard = fminf(kguard, fminf(g.x, g.y));
+    umin = fminf(umin, fminf(u.x, u.y));
     const f2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
-    const f2 cc = {c0, c0};
     const f2 t = nv * (lg - cc);
     return -(t.x + t.y);
 }
@@ -349,11 +349,12 @@ __device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int ca
 
     int s1 = 0;
     unsigned s2 = 0;
+    for (int rep = 0; rep < c.rep_sum; ++rep) { s1 = 0; s2 = 0;
     for (int j = lo; j < hi; ++j) {
         const int y = ys[j] - m0;
         s1 += y;
         s2 += static_cast<unsigned>(__mul24(y, y));
-    }
+    } asm volatile("" :: "v"(s1), "v"(s2)); }
     PS_STAMP_AT(wk, 2);                                // chunk sums from LDS
     double a1, a2, t1, t2;
     block_exscan2<NT>(static_cast<double>(s1), static_cast<double>(s2), a1, a2, t1, t2, sh);
@@ -362,38 +363,48 @@ __device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int ca
     const double dn = static_cast<double>(n);
     const double Dtot = dn * t2 - t1 * t1;            // n^2 * variance (shift invariant)
     if (!(Dtot > 0.0)) return 0;                      // zero-variance window: reference inf/NaN path
-    const float c0 = __builtin_amdgcn_logf(static_cast<float>(Dtot / (dn * dn)));   // log2, same in all threads
+    // log2 of the window variance (counts^2), identical in all threads: 4 roundings + 1 ulp of log
+    const float rn = __builtin_amdgcn_rcpf(static_cast<float>(n));
+    const float c0 = __builtin_amdgcn_logf(static_cast<float>(Dtot) * rn * rn);
+    const f2 cc = {c0, c0};
     // candidates of this thread: window-local j in [clo, chi)
     const int clo = max(lo, cand_lo - ps), chi = min(hi, cand_hi - ps + 1);
     Top2 top = {-INFINITY, -INFINITY, -1};
     unsigned flag = 0;
-    float guard = INFINITY;                           // min over candidates of the validity margins
+    float kguard = INFINITY, umin = INFINITY;         // validity margins, minimum over candidates
     if (clo < chi) {
         for (int j = lo; j < clo; ++j) {              // advance the exact prefix to the first candidate
             const double y = static_cast<double>(ys[j] - m0);
             a1 += y; a2 += y * y;
         }
-        const double nl0 = static_cast<double>(clo), nr0 = static_cast<double>(n - clo);
+        // Per-chunk re-centring on (integers near) the left and right means: exact integer sums of
+        // z = k - c and z^2 per side -> D = n*p2 - p1^2 has no cancellation.  The first moments fit
+        // int32 (|a1| <= n*R/2 < 2^31), the second moments are formed in fp64 (exact below 2^53).
+        const int nl0 = clo, nr0 = n - clo;
         const double b1 = t1 - a1, b2 = t2 - a2;
-        // per-chunk re-centring on the (rounded) left and right means: exact integer sums of
-        // (k-cL), (k-cL)^2 and (k-cR), (k-cR)^2 -> D = n*p2 - p1^2 has no cancellation
-        const double muL = rint(a1 / nl0), muR = rint(b1 / nr0);
-        const double p1d = a1 - nl0 * muL, p2d = a2 - muL * (2.0 * a1 - nl0 * muL);
-        const double r1d = b1 - nr0 * muR, r2d = b2 - muR * (2.0 * b1 - nr0 * muR);
-        const double room = static_cast<double>(chi - clo) * (static_cast<double>(R) + 1.0) * (static_cast<double>(R) + 1.0);
-        if (!(p2d + room < 4294967296.0) || !(r2d < 4294967296.0) || !(fabs(p1d) + room < 2147483648.0) ||
-            !(fabs(r1d) + room < 2147483648.0))
+        const int a1i = static_cast<int>(a1), b1i = static_cast<int>(b1);
+        const int muL = __float2int_rn(static_cast<float>(a1i) * __builtin_amdgcn_rcpf(static_cast<float>(nl0)));
+        const int muR = __float2int_rn(static_cast<float>(b1i) * __builtin_amdgcn_rcpf(static_cast<float>(nr0)));
+        int p1 = a1i - __mul24(nl0, muL), r1 = b1i - __mul24(nr0, muR);
+        const double muLd = static_cast<double>(muL), muRd = static_cast<double>(muR);
+        const double p2d = a2 - muLd * (a1 + static_cast<double>(p1));     // a2 - mu*(2*a1 - nl0*mu)
+        const double r2d = b2 - muRd * (b1 + static_cast<double>(r1));
+        const float roomf = static_cast<float>(chi - clo) * (static_cast<float>(R) + 1.0f) * (static_cast<float>(R) + 1.0f);
+        if (!(static_cast<float>(p2d) + roomf < 4.2e9f) || !(static_cast<float>(r2d) < 4.2e9f) ||
+            !(fabsf(static_cast<float>(p1)) + roomf < 2.1e9f) || !(fabsf(static_cast<float>(r1)) + roomf < 2.1e9f))
             flag = 1;
-        int p1 = static_cast<int>(p1d), r1 = static_cast<int>(r1d);
         unsigned p2 = static_cast<unsigned>(p2d), r2 = static_cast<unsigned>(r2d);
-        const int cL = m0 + static_cast<int>(muL), cR = m0 + static_cast<int>(muR);
+        const int cL = m0 + muL, cR = m0 + muR;
         f2 nv = {static_cast<float>(clo), static_cast<float>(n - clo)};
         const f2 step1 = {1.0f, -1.0f};
         // reference noise floor: below this variance (counts^2) the reference's own
         // c2/n - (c/n)^2 loses more than ~1e-3 of gain to cancellation -> decide exactly
         const float mabs = fmaxf(fabsf(static_cast<float>(kmin)), fabsf(static_cast<float>(kmax)));
         const float vfloor = mabs * mabs * 1.0e-9f;
-        if (!flag) {
+        const int p1_0 = p1, r1_0 = r1; const unsigned p2_0 = p2, r2_0 = r2; const f2 nv_0 = nv;
+        if (!flag) for (int rep = 0; rep < c.rep_eval; ++rep) {
+            p1 = p1_0; r1 = r1_0; p2 = p2_0; r2 = r2_0; nv = nv_0; top.b = -INFINITY; top.s = -INFINITY; top.i = -1;
+            asm volatile("" : "+v"(p1), "+v"(r1));
             // 4 candidates per trip: the integer moment recurrences are sequential but cheap,
             // the four float pipelines (rcp, log2, fma) are independent and overlap.
             int j = clo;
@@ -411,22 +422,22 @@ __device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int ca
                 float g[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    g[u] = screen_gain(q1[u], q2[u], q3[u], q4[u], nv, c0, vfloor, guard);
+                    g[u] = screen_gain(q1[u], q2[u], q3[u], q4[u], nv, cc, kguard, umin);
                     nv += step1;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) top2_push(top, g[u], ps + j + u);
+                for (int u = 0; u < 4; ++u) top2_push(top, g[u], j + u);
             }
             for (; j < chi; ++j) {
-                const float g = screen_gain(p1, p2, r1, r2, nv, c0, vfloor, guard);
-                top2_push(top, g, ps + j);
+                const float g = screen_gain(p1, p2, r1, r2, nv, cc, kguard, umin);
+                top2_push(top, g, j);
                 const int k = ys[j];
                 const int zl = k - cL, zr = k - cR;
                 p1 += zl; p2 += static_cast<unsigned>(__mul24(zl, zl));
                 r1 -= zr; r2 -= static_cast<unsigned>(__mul24(zr, zr));
                 nv += step1;
             }
-            if (!(guard >= 0.0f)) flag = 1;           // also catches NaN
+            if (!(kguard >= 0.0f) || !(umin >= vfloor)) flag = 1;   // also catches NaN
         }
     }
     PS_STAMP_AT(wk, 4);                                // per-thread setup + candidate loop
@@ -454,14 +465,14 @@ __device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int ca
     const float dthr = dlt + 3.0e-6f * static_cast<float>(n) + 1.0e-6f * fabsf(thr_log2);   // + error of c0, of thr_log2
     (void)LN2;
     if (all.b < thr_log2 - dthr) { *split = -1; return 1; }                // certainly no candidate above min_gain
-    if (all.b > thr_log2 + dthr && all.s < all.b - 2.0f * dlt) { *split = all.i; return 1; }   // unique, clear winner
+    if (all.b > thr_log2 + dthr && all.s < all.b - 2.0f * dlt) { *split = ps + all.i; return 1; }   // unique, clear winner
     return 0;
 }
 
 // ---- one window scan: cparsers.pyx:157-178 ------------------------------------------------------
 // Window [ps, pe) of the event at `base`; candidates cand_lo..cand_hi (inclusive, event-local);
 // returns the first index whose gain strictly exceeds every earlier gain and `thresh`, or -1.
-template <int NT, int DT>
+template <int NT, int DT, bool VALIDATE>
 __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                            double thresh, double *scores, Shared &sh, unsigned &bad, Work &wk,
                            double *best_gain_out = nullptr, int pf_end = 0)
@@ -492,8 +503,10 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     unsigned fracbits = 0;
     // (the previous scan's last read of ys is followed by a barrier in its reduction)
     constexpr int STAGE_U = (NT >= 1024) ? 3 : (NT >= 512 ? 5 : 10);     // covers 12k fp32 samples per trip
+    for (int rep = 0; rep < c.rep_stage; ++rep)
     for (int v0 = threadIdx.x; v0 < nv; v0 += NT * STAGE_U) {
         int4 raw[STAGE_U];
+        unsigned k_frac[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int u = 0; u < STAGE_U; ++u) raw[u] = vsrc[min(v0 + u * NT, nv - 1)];
         PS_STAMP_AT(wk, 8);                            // (diagnostic) loads issued
@@ -505,34 +518,42 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
         for (int u = 0; u < STAGE_U; ++u) {
             const int v = v0 + u * NT;
             if (v < nv) {
-            int k[EPV];
-            if (DT == PS_DTYPE_F32) {
-                const float f[4] = {__int_as_float(raw[u].x), __int_as_float(raw[u].y), __int_as_float(raw[u].z),
-                                    __int_as_float(raw[u].w)};
+                int k[EPV];
+                if (DT == PS_DTYPE_F32) {
+                    const float f[4] = {__int_as_float(raw[u].x), __int_as_float(raw[u].y), __int_as_float(raw[u].z),
+                                        __int_as_float(raw[u].w)};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float kf = f[e] * c.inv_q;
-                    const float kr = rintf(kf);
-                    k[e] = static_cast<int>(kr);
-                    const bool in = (v > 0 && v < nv - 1) || (v * EPV + e >= off && v * EPV + e < off + n);
-                    // off-grid samples leave a non-zero (or NaN) remainder
-                    fracbits |= in ? __float_as_uint(kf - kr) : 0u;
-                    kmin = min(kmin, in ? k[e] : 0x7fffffff);
-                    kmax = max(kmax, in ? k[e] : static_cast<int>(0x80000000));
+                    for (int e = 0; e < 4; ++e) {
+                        const float kf = f[e] * c.inv_q;
+                        k[e] = static_cast<int>(kf);          // on-grid values are integers: truncation is exact
+                        // off-grid samples leave a non-zero (or NaN) remainder
+                        if (VALIDATE) k_frac[e] = __float_as_uint(kf - static_cast<float>(k[e]));
+                    }
+                } else {
+                    const int w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        k[e] = ((e & 1) ? (w[e >> 1] >> 16) : static_cast<int>(static_cast<short>(w[e >> 1] & 0xffff))) + c.off_counts;
                 }
-            } else {
-                const int w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                if (v > 0 && v < nv - 1) {                    // interior vector: every element is in the window
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    k[e] = ((e & 1) ? (w[e >> 1] >> 16) : static_cast<int>(static_cast<short>(w[e >> 1] & 0xffff))) + c.off_counts;
-                    const bool in = (v > 0 && v < nv - 1) || (v * EPV + e >= off && v * EPV + e < off + n);
-                    kmin = min(kmin, in ? k[e] : 0x7fffffff);
-                    kmax = max(kmax, in ? k[e] : static_cast<int>(0x80000000));
+                    for (int e = 0; e < EPV; e += 2) {
+                        kmin = min(kmin, min(k[e], k[e + 1]));     // v_min3 / v_max3
+                        kmax = max(kmax, max(k[e], k[e + 1]));
+                    }
+                    if (VALIDATE && DT == PS_DTYPE_F32) fracbits |= (k_frac[0] | k_frac[1]) | (k_frac[2] | k_frac[3]);
+                } else {                                      // first / last vector: mask the elements outside
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const bool in = v * EPV + e >= off && v * EPV + e < off + n;
+                        kmin = min(kmin, in ? k[e] : 0x7fffffff);
+                        kmax = max(kmax, in ? k[e] : static_cast<int>(0x80000000));
+                        if (VALIDATE && DT == PS_DTYPE_F32) fracbits |= in ? k_frac[e & 3] : 0u;
+                    }
                 }
-            }
 #pragma unroll
-            for (int e = 0; e < EPV; e += 4)
-                *reinterpret_cast<int4 *>(&ys[v * EPV + e]) = make_int4(k[e], k[e + 1], k[e + 2], k[e + 3]);
+                for (int e = 0; e < EPV; e += 4)
+                    *reinterpret_cast<int4 *>(&ys[v * EPV + e]) = make_int4(k[e], k[e + 1], k[e + 2], k[e + 3]);
             }
         }
     }
@@ -583,7 +604,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 // ---- the window loop of _recursive_split: cparsers.pyx:186-201 ---------------------------------
 // Windows j < j0 are known to hold no split (they were scanned with identical bounds by the
 // parent frame, DESIGN.md "memoised left child").
-template <int NT, int DT>
+template <int NT, int DT, bool VALIDATE>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
                           Shared &sh, unsigned &bad, Work &wk, long long pf_lim)
 {
@@ -599,7 +620,7 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
         if (pe > end) pe = end;                                         // :193
         int s = -1;
         if (pe - ps > 2LL * c.mw)                                       // :164
-            s = scan_window<NT, DT>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
+            s = scan_window<NT, DT, VALIDATE>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
                                 static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
                                 c.min_gain, nullptr, sh, bad, wk, nullptr,
                                 static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim));
@@ -648,7 +669,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void spine_kernel(DevCfg 
     int a = job.start, cnt = 0, ended = 0, flushed = 0;
     for (;;) {
         int kind;
-        int s = find_split<NT, DT>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
+        int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
         if (kind == KIND_NONE) { ended = 1; break; }
         if (cnt - flushed == OBUF) {                   // rare: spill the LDS buffer to the private scratch
             __syncthreads();
@@ -706,7 +727,7 @@ __global__ __launch_bounds__(NT, 4) void tree_kernel(DevCfg c, const TreeJob *jo
     };
     for (;;) {
         int kind;
-        int s = find_split<NT, DT>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end);
+        int s = find_split<NT, DT, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end);
         if (kind == KIND_NONE) {
             if (sp == 0) break;
             --sp;
@@ -760,10 +781,10 @@ __global__ __launch_bounds__(NT) void single_scan_kernel(DevCfg c, int n, int mo
     double g = mode == 0 ? c.min_gain : 0.0;
     if (mode == 0) {
         if (n > 2 * c.mw)
-            r = scan_window<NT, DT>(c, ys, 0, 0, n, c.mw, n - c.mw, c.min_gain, scores, sh, bad, wk, &g);
+            r = scan_window<NT, DT, true>(c, ys, 0, 0, n, c.mw, n - c.mw, c.min_gain, scores, sh, bad, wk, &g);
     } else {
         const int end = n - 1;
-        if (end >= 1) r = scan_window<NT, DT>(c, ys, 0, 0, end, 2, end - 3, 0.0, nullptr, sh, bad, wk, &g);
+        if (end >= 1) r = scan_window<NT, DT, true>(c, ys, 0, 0, end, 2, end - 3, 0.0, nullptr, sh, bad, wk, &g);
     }
     if (threadIdx.x == 0) { *idx_out = r; *gain_out = g; }
     flush(bad, wk, status, work);
