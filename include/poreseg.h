@@ -87,6 +87,11 @@ const char *ps_last_error(const ps_ctx *ctx);
 /* Tiling of long traces: a trace longer than tile_len + halo samples is cut into tiles whose
  * spines are computed speculatively and stitched.  0 keeps the default. */
 int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
+/* Diagnostic / tuning options (none changes a result): "mode" 0 screen+exact (default), 1 exact fp64
+ * scans only, 2 verify (screen and exact must agree); "stitch_host" 1 forces the host-stitch
+ * pipeline (halo tiles + seam repairs, otherwise only the fallback); "spine_nt" 256/512/1024,
+ * "tree_nt" 256/512 workgroup sizes.  Unknown names return PS_ERR_ARG. */
+int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);
 /* Blocks until all work submitted on the context's stream has finished. */
 int ps_synchronize(ps_ctx *ctx);
 

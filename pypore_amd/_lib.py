@@ -13,7 +13,7 @@ PS_ERR_ARG, PS_ERR_ASSERT_WIDTH, PS_ERR_ASSERT_WINDOW, PS_ERR_ASSERT_CUTOFF = -1
 PS_ERR_CAPACITY, PS_ERR_OFF_GRID, PS_ERR_HIP, PS_ERR_NO_DEVICE, PS_ERR_INTERNAL = -5, -6, -7, -8, -9
 PS_DTYPE_F32, PS_DTYPE_I16 = 0, 1
 
-EXPORTS = ["ps_version", "ps_device_count", "ps_create", "ps_destroy", "ps_last_error", "ps_set_tiling",
+EXPORTS = ["ps_version", "ps_device_count", "ps_create", "ps_destroy", "ps_last_error", "ps_set_tiling", "ps_set_option",
            "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_bounds_capacity",
            "ps_best_single_split", "ps_score_window", "ps_get_timings", "ps_synth_trace"]
 
@@ -55,6 +55,7 @@ def lib():
     L.ps_last_error.argtypes = [vp]
     L.ps_last_error.restype = ctypes.c_char_p
     L.ps_set_tiling.argtypes = [vp, i64, i64]
+    L.ps_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     L.ps_synchronize.argtypes = [vp]
     L.ps_min_gain.argtypes = [P(SplitParams), P(dbl)]
     L.ps_segment_batch.argtypes = [vp, vp, P(SampleFormat), P(i64), i32, P(SplitParams), vp, i64, P(i64), vp]

@@ -68,6 +68,9 @@ struct ps_ctx {
     int mode = MODE_FAST, spine_nt = 512, tree_nt = 256;
     int lds_max_samples = 0;
     int rep_eval = 1, rep_stage = 1, rep_sum = 1;
+    int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
+    DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
+    HostBuf h_hdr;
     DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
         tree_counts, items, item_pos, first_item, ev_off, bounds_off, small;
     HostBuf h_meta, h_dense, h_small, h_up;
@@ -128,14 +131,14 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
 // LDS budget: 160 KB per CU minus the static Shared block and a little slack
 constexpr int LDS_BYTES_MAX = 160 * 1024 - static_cast<int>(sizeof(Shared)) - 512 - 64;
 
-template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
+template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, bool list_mode = false)
 {
     const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);   // + alignment slack of the staged region
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(spine_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
-                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_dense.as<int2>(),
-                       ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(),
+                       list_mode ? nullptr : ctx->spine_dense.as<int2>(), ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -244,6 +247,236 @@ int find_in(const TileList &t, int32_t pos)
 
 }  // namespace
 
+namespace {
+// Phase 3 onwards.  Expects tree_jobs / items / first_item / ev_off populated on the device.
+int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, int32_t n_ev,
+                        int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
+                        std::chrono::steady_clock::time_point t_begin)
+{
+    int rc;
+    const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (n_tj) {
+        const unsigned g = static_cast<unsigned>(n_tj);
+        const bool f32 = cfg.dtype == PS_DTYPE_F32;
+        int lrc = ctx->tree_nt == 512
+                      ? (f32 ? launch_tree<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<512, PS_DTYPE_I16>(ctx, cfg, g, sm))
+                      : (f32 ? launch_tree<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<256, PS_DTYPE_I16>(ctx, cfg, g, sm));
+        if (lrc) return lrc;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
+                       ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    if (n_items) {
+        hipLaunchKernelGGL(gather_kernel, dim3(static_cast<unsigned>(n_items)), dim3(64), 0, ctx->stream,
+                           ctx->items.as<Item>(), ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(),
+                           ctx->tree_scratch.as<int32_t>(), ctx->item_pos.as<int64_t>(), n_items, d_bounds, cap);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(event_offsets_kernel, dim3((n_ev + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                       ctx->item_pos.as<int64_t>(), ctx->first_item.as<int64_t>(), n_ev, ctx->bounds_off.as<int64_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, ctx->h_meta.reserve(evb));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(h_bounds_off, ctx->h_meta.p, evb);
+    const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+    rc = check_status(ctx, static_cast<unsigned>(hs.status));
+    if (rc) return rc;
+    ctx->counters[0] = static_cast<int64_t>(hs.work0);
+    ctx->counters[1] = static_cast<int64_t>(hs.work1);
+    ctx->counters[5] = static_cast<int64_t>(hs.work2);
+#ifdef PS_STAMP
+    {
+        static const char *nm[12] = {"stage_tail", "minmax", "chunksum", "scan", "eval", "top2", "exact", "outside", "ld_issue", "ld_wait", "-", "-"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += hs.stamp[i];
+        fprintf(stderr, "[poreseg stamps] thread-0 cycles summed over workgroups (spine+tree):");
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
+        fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
+    }
+#endif
+    const int64_t total = h_bounds_off[n_ev];
+    if (total > cap)
+        return fail(ctx, PS_ERR_CAPACITY, "bounds capacity %lld < required %lld", static_cast<long long>(cap),
+                    static_cast<long long>(total));
+    if (d_stats) {
+        const int64_t nseg = total + n_ev;
+        if (nseg > 0) {
+            if (cfg.dtype == PS_DTYPE_F32)
+                hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_F32>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
+                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
+                                   ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
+            else
+                hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_I16>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
+                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
+                                   ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->ms[1] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->ms[2] = ms;
+    ctx->ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return PS_OK;
+}
+
+
+constexpr int RC_FALLBACK = 1;
+
+template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
+{
+    const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bridge_kernel<NT, DT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
+                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
+                       ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
+                       &sm->work0);
+    HIP_TRY(ctx, hipGetLastError());
+    return PS_OK;
+}
+
+// Device-stitch pipeline: tile spines without halo, seam bridges, assemble kernel (true spine,
+// tree jobs, items) -- the host only reads a 32-byte header between phase 1 and phase 3.
+// Returns RC_FALLBACK when a seam could not be bridged on the device (rare); the caller then runs
+// the host-stitch pipeline, which repairs seams one by one.
+int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *h_ev_off, int32_t n_ev, int mw, int W,
+                        int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
+                        std::chrono::steady_clock::time_point t_begin)
+{
+    int64_t total_len = 0;
+    for (int e = 0; e < n_ev; ++e) total_len += h_ev_off[e + 1] - h_ev_off[e];
+    int64_t L = ctx->tile_len;
+    if (L <= 0) L = std::max<int64_t>(8LL * W, (total_len + 1023) / 1024);
+    L = std::min<int64_t>(L, 0x7fffffff);
+    std::vector<SpineJob> jobs;
+    std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
+    int64_t list_entries = 0;
+    for (int e = 0; e < n_ev; ++e) {
+        ev_first_tile[e] = static_cast<int64_t>(jobs.size());
+        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
+        if (len == 0) continue;
+        const int64_t nt = (len + L - 1) / L;
+        if (static_cast<int64_t>(jobs.size()) + nt > 0x7ffffff0) return RC_FALLBACK;
+        for (int64_t t = 0; t < nt; ++t) {
+            SpineJob j;
+            j.base = h_ev_off[e];
+            j.start = static_cast<int32_t>(t * L);
+            j.end = static_cast<int32_t>(len);
+            j.stop = static_cast<int32_t>(t == nt - 1 ? len : (t + 1) * L);
+            j.out_cap = static_cast<int32_t>(std::min<int64_t>((j.stop - j.start) / mw + 4, 0x7fffffff));
+            j.out_off = list_entries;
+            j.first_tile = static_cast<int32_t>(ev_first_tile[e]);
+            j.ntiles = static_cast<int32_t>(nt);
+            j.tile_len = static_cast<int32_t>(L);
+            j.pad_ = 0;
+            list_entries += j.out_cap;
+            jobs.push_back(j);
+        }
+    }
+    ev_first_tile[n_ev] = static_cast<int64_t>(jobs.size());
+    const size_t nj = jobs.size();
+    ctx->counters[2] = static_cast<int64_t>(nj);
+    const int64_t max_items = list_entries + static_cast<int64_t>(nj) * BR_MAX;
+    const int64_t tscratch_bound = (n_ev ? h_ev_off[n_ev] : 0) / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
+    const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
+
+    HIP_TRY(ctx, ctx->spine_jobs.reserve(std::max<size_t>(1, nj) * sizeof(SpineJob)));
+    HIP_TRY(ctx, ctx->spine_scratch.reserve(std::max<int64_t>(1, list_entries) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->spine_meta.reserve(std::max<size_t>(4, nj) * sizeof(int4)));
+    HIP_TRY(ctx, ctx->bridges.reserve(std::max<size_t>(1, nj) * BR_MAX * sizeof(int2)));
+    HIP_TRY(ctx, ctx->bmeta.reserve(std::max<size_t>(1, nj) * sizeof(int4)));
+    HIP_TRY(ctx, ctx->tile_i32.reserve(std::max<size_t>(1, nj) * 4 * sizeof(int)));
+    HIP_TRY(ctx, ctx->sp_off.reserve((nj + 1) * sizeof(long long)));
+    HIP_TRY(ctx, ctx->spine_items.reserve(std::max<int64_t>(1, max_items) * sizeof(int4)));
+    HIP_TRY(ctx, ctx->tree_jobs.reserve(std::max<int64_t>(1, max_items) * sizeof(TreeJob)));
+    HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<int64_t>(1, max_items) * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx->items.reserve(std::max<int64_t>(1, max_items) * sizeof(Item)));
+    HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(max_items) + 1) * sizeof(int64_t)));
+    HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->first_item.reserve(evb));
+    HIP_TRY(ctx, ctx->ev_first_tile.reserve(evb));
+    HIP_TRY(ctx, ctx->ev_off.reserve(evb));
+    HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
+    HIP_TRY(ctx, ctx->asm_hdr.reserve(sizeof(AsmHeader)));
+    HIP_TRY(ctx, ctx->h_hdr.reserve(sizeof(AsmHeader)));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+
+    // one upload blob: [jobs | ev_first_tile | ev_off]
+    const size_t jb = nj * sizeof(SpineJob);
+    HIP_TRY(ctx, ctx->h_up.reserve(jb + 2 * evb + 64));
+    char *up = ctx->h_up.as<char>();
+    if (nj) std::memcpy(up, jobs.data(), jb);
+    std::memcpy(up + jb, ev_first_tile.data(), evb);
+    std::memcpy(up + jb + evb, h_ev_off, evb);
+    if (nj) HIP_TRY(ctx, hipMemcpyAsync(ctx->spine_jobs.p, up, jb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_first_tile.p, up + jb, evb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_off.p, up + jb + evb, evb, hipMemcpyHostToDevice, ctx->stream));
+
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    const bool f32 = cfg.dtype == PS_DTYPE_F32;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (nj) {
+        const unsigned g = static_cast<unsigned>(nj);
+        int lrc = ctx->spine_nt == 256
+                      ? (f32 ? launch_spine<256, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<256, PS_DTYPE_I16>(ctx, cfg, g, sm, true))
+                  : ctx->spine_nt == 512
+                      ? (f32 ? launch_spine<512, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<512, PS_DTYPE_I16>(ctx, cfg, g, sm, true))
+                      : (f32 ? launch_spine<1024, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<1024, PS_DTYPE_I16>(ctx, cfg, g, sm, true));
+        if (lrc) return lrc;
+        lrc = ctx->spine_nt == 256
+                  ? (f32 ? launch_bridge<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<256, PS_DTYPE_I16>(ctx, cfg, g, sm))
+                  : (f32 ? launch_bridge<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<512, PS_DTYPE_I16>(ctx, cfg, g, sm));
+        if (lrc) return lrc;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    int *ti = ctx->tile_i32.as<int>();
+    const size_t njp = std::max<size_t>(1, nj);
+    // per-tile arrays of the stitch live in LDS when they fit: (nj+1) int64 + 4*nj int32
+    const size_t tile_lds = (nj + 1) * sizeof(long long) + 4 * nj * sizeof(int);
+    const int use_lds = tile_lds <= 150 * 1024;
+    if (use_lds)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(assemble_tiles_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds)));
+    hipLaunchKernelGGL(assemble_tiles_kernel, dim3(1), dim3(1024), use_lds ? tile_lds : 0, ctx->stream,
+                       static_cast<int>(nj), ctx->spine_meta.as<int4>(), ctx->bmeta.as<int4>(),
+                       ctx->ev_first_tile.as<int64_t>(), n_ev, ti, ti + njp, ti + 2 * njp, ti + 3 * njp,
+                       ctx->sp_off.as<long long>(), ctx->first_item.as<int64_t>(), ctx->asm_hdr.as<AsmHeader>(),
+                       static_cast<long long>(max_items), use_lds);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr.p, ctx->asm_hdr.p, sizeof(AsmHeader), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+    int rc = check_status(ctx, static_cast<unsigned>(hs.status));
+    if (rc) return rc;
+    const AsmHeader hd = *ctx->h_hdr.as<AsmHeader>();
+    if (hd.fail) return RC_FALLBACK;
+    if (hd.n_items) {
+        hipLaunchKernelGGL(assemble_items_kernel, dim3(static_cast<unsigned>((hd.n_items + 255) / 256)), dim3(256), 0,
+                           ctx->stream, ctx->spine_jobs.as<SpineJob>(), static_cast<int>(nj), ctx->spine_meta.as<int4>(),
+                           ctx->spine_scratch.as<int2>(), ctx->bridges.as<int2>(), ti + 3 * njp,
+                           ctx->sp_off.as<long long>(), hd.n_items, mw, W, ctx->tree_jobs.as<TreeJob>(),
+                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>());
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->counters[3] = hd.n_items;
+    rc = finish_batch(ctx, cfg, static_cast<size_t>(hd.n_items), hd.n_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->ms[0] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]) == hipSuccess) ctx->ms[4] = ms;     // device stitch incl. header sync
+    return rc;
+}
+}  // namespace
+
 extern "C" {
 
 const char *ps_version(void) { return "poreseg 0.1 (gfx950)"; }
@@ -280,6 +513,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_EVAL")) ctx->rep_eval = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_REP_STAGE")) ctx->rep_stage = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
     *out = ctx;
@@ -293,9 +527,10 @@ void ps_destroy(ps_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->spine_jobs, &ctx->spine_scratch, &ctx->spine_dense, &ctx->spine_meta, &ctx->tree_jobs,
                       &ctx->tree_scratch, &ctx->tree_spill, &ctx->tree_counts, &ctx->items, &ctx->item_pos,
-                      &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small};
+                      &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
+                      &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile};
     for (DevBuf *b : bufs) b->release();
-    ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release();
+    ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -308,6 +543,18 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo)
     if (!ctx || tile_len < 0 || halo < 0) return PS_ERR_ARG;
     ctx->tile_len = tile_len;
     ctx->halo = halo;
+    return PS_OK;
+}
+
+int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return PS_ERR_ARG;
+    const std::string n(name);
+    if (n == "mode" && value >= 0 && value <= 2) ctx->mode = static_cast<int>(value);
+    else if (n == "stitch_host") ctx->stitch_host = value != 0;
+    else if (n == "spine_nt" && (value == 256 || value == 512 || value == 1024)) ctx->spine_nt = static_cast<int>(value);
+    else if (n == "tree_nt" && (value == 256 || value == 512)) ctx->tree_nt = static_cast<int>(value);
+    else return fail(ctx, PS_ERR_ARG, "unknown option or value: %s", name);
     return PS_OK;
 }
 
@@ -375,6 +622,16 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     for (int64_t &c : ctx->counters) c = 0;
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
 
+    if (!ctx->stitch_host) {
+        rc = device_stitch_batch(ctx, cfg, h_ev_off, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+        if (rc != RC_FALLBACK) return rc;
+        // a seam could not be bridged on the device: redo with the host stitch (halo tiles + repairs)
+        for (double &m : ctx->ms) m = 0;
+        for (int64_t &c : ctx->counters) c = 0;
+        ctx->counters[4] = 1000000;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    }
+
     // ---- tiles ----------------------------------------------------------------------------------
     // Tiling: one spine workgroup per tile.  Default: as many tiles as the chip keeps resident at once
     // (2 workgroups of 512 threads per CU on 256 CUs) so the grid runs as a single wave of blocks,
@@ -405,6 +662,7 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
             const int64_t capj = spine_cap(j.start, stop, mw);
             j.out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
             j.out_off = scratch;
+            j.first_tile = 0; j.ntiles = 1; j.tile_len = 0x7fffffff; j.pad_ = 0;
             scratch += j.out_cap;
             jobs.push_back(j);
         }
@@ -446,6 +704,7 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
                 const int64_t capj = spine_cap(z, stop, mw);
                 rj[0].out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
                 rj[0].out_off = 0;
+                rj[0].first_tile = 0; rj[0].ntiles = 1; rj[0].tile_len = 0x7fffffff; rj[0].pad_ = 0;
                 std::vector<TileList> ext;
                 rc = run_spines(ctx, cfg, rj, rj[0].out_cap, ext);
                 if (rc) return rc;
@@ -527,75 +786,7 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     std::memcpy(up + o, h_ev_off, evb);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_off.p, up + o, evb, hipMemcpyHostToDevice, ctx->stream));
 
-    SmallLayout *sm = ctx->small.as<SmallLayout>();
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    if (n_tj) {
-        const unsigned g = static_cast<unsigned>(n_tj);
-        const bool f32 = cfg.dtype == PS_DTYPE_F32;
-        int lrc = ctx->tree_nt == 512
-                      ? (f32 ? launch_tree<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<512, PS_DTYPE_I16>(ctx, cfg, g, sm))
-                      : (f32 ? launch_tree<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<256, PS_DTYPE_I16>(ctx, cfg, g, sm));
-        if (lrc) return lrc;
-    }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
-                       ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>());
-    HIP_TRY(ctx, hipGetLastError());
-    if (n_items) {
-        hipLaunchKernelGGL(gather_kernel, dim3(static_cast<unsigned>(n_items)), dim3(64), 0, ctx->stream,
-                           ctx->items.as<Item>(), ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(),
-                           ctx->tree_scratch.as<int32_t>(), ctx->item_pos.as<int64_t>(), n_items, d_bounds, cap);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    hipLaunchKernelGGL(event_offsets_kernel, dim3((n_ev + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                       ctx->item_pos.as<int64_t>(), ctx->first_item.as<int64_t>(), n_ev, ctx->bounds_off.as<int64_t>());
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, ctx->h_meta.reserve(evb));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(h_bounds_off, ctx->h_meta.p, evb);
-    const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
-    rc = check_status(ctx, static_cast<unsigned>(hs.status));
-    if (rc) return rc;
-    ctx->counters[0] = static_cast<int64_t>(hs.work0);
-    ctx->counters[1] = static_cast<int64_t>(hs.work1);
-    ctx->counters[5] = static_cast<int64_t>(hs.work2);
-#ifdef PS_STAMP
-    {
-        static const char *nm[12] = {"stage_tail", "minmax", "chunksum", "scan", "eval", "top2", "exact", "outside", "ld_issue", "ld_wait", "-", "-"};
-        unsigned long long tot = 0;
-        for (int i = 0; i < 12; ++i) tot += hs.stamp[i];
-        fprintf(stderr, "[poreseg stamps] thread-0 cycles summed over workgroups (spine+tree):");
-        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
-        fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
-    }
-#endif
-    const int64_t total = h_bounds_off[n_ev];
-    if (total > cap)
-        return fail(ctx, PS_ERR_CAPACITY, "bounds capacity %lld < required %lld", static_cast<long long>(cap),
-                    static_cast<long long>(total));
-    if (d_stats) {
-        const int64_t nseg = total + n_ev;
-        if (nseg > 0) {
-            if (cfg.dtype == PS_DTYPE_F32)
-                hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_F32>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
-                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
-                                   ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
-            else
-                hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_I16>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
-                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
-                                   ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
-            HIP_TRY(ctx, hipGetLastError());
-        }
-    }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->ms[1] = ms;
-    if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->ms[2] = ms;
-    ctx->ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    return PS_OK;
+    return finish_batch(ctx, cfg, n_tj, n_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin);
 }
 
 static int single_scan(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int mode,

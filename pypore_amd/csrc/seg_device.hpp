@@ -30,7 +30,9 @@ namespace ps {
 
 constexpr int LDS_STACK = 128;   // DFS stack entries kept in LDS before spilling to HBM
 constexpr int MAX_WAVES = 16;
-constexpr int OBUF = 256;        // buffered outputs per job (int2 anchors / 2x int boundaries)
+constexpr int OBUF = 256;
+constexpr int BR_MAX = 32;        // bridge chain: anchors a seam may add before it must have joined
+constexpr int LST_MAX = 256;      // anchors of the downstream tile cached in LDS for membership tests        // buffered outputs per job (int2 anchors / 2x int boundaries)
 
 enum : int { KIND_NONE = 0, KIND_HIT = 1, KIND_EARLY = 2, KIND_LATE = 3 };
 enum : unsigned { ST_OFF_GRID = 1u, ST_OUT_OVERFLOW = 2u, ST_STACK_OVERFLOW = 4u, ST_VERIFY_MISMATCH = 8u };
@@ -53,7 +55,11 @@ struct SpineJob {           // speculative spine of one tile: rec(start, end) wi
     int32_t start, end;     // chain anchor, event length
     int32_t stop;           // stop after the first spine anchor >= stop
     int32_t out_cap;
-    int64_t out_off;        // into the private anchor scratch (int2 entries)
+    int64_t out_off;        // into the anchor list storage (int2 entries)
+    int32_t first_tile;     // global index of the event's first tile
+    int32_t ntiles;         // tiles of this event
+    int32_t tile_len;       // tile t of the event starts at t * tile_len
+    int32_t pad_;
 };
 
 struct TreeJob {            // full in-order traversal of rec(start, end), first window index j0
@@ -74,6 +80,7 @@ struct Shared {
     int bcast;
     int2 pop;
     int2 stack[LDS_STACK];
+    int lst[LST_MAX];
     int2 obuf[OBUF];        // results are buffered here and written to HBM once per job: a global
                             // store issued between scans would sit in front of the next window's
                             // staging loads (vmcnt retires in order) and stall the whole workgroup
@@ -686,6 +693,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void spine_kernel(DevCfg 
     }
     if (cnt > job.out_cap) cnt = job.out_cap;
     __syncthreads();
+    if (dense == nullptr) {                            // device-stitch pipeline: the list stays in its own region
+        for (int i = flushed + threadIdx.x; i < cnt; i += NT) out[i] = sh.obuf[i - flushed];
+        if (threadIdx.x == 0) meta[blockIdx.x] = make_int4(cnt, ended, 0, 0);
+        flush(bad, wk, status, work);
+        return;
+    }
     if (threadIdx.x == 0) {
         unsigned long long pos = atomicAdd(dense_count, static_cast<unsigned long long>(cnt));
         meta[blockIdx.x] = make_int4(cnt, ended, static_cast<int>(pos), 0);
@@ -694,6 +707,72 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void spine_kernel(DevCfg 
     __syncthreads();
     const int pos = sh.bcast;
     for (int i = threadIdx.x; i < cnt; i += NT) dense[pos + i] = i < flushed ? out[i] : sh.obuf[i - flushed];
+    flush(bad, wk, status, work);
+}
+
+// ---- phase 1b: bridge a seam -------------------------------------------------------------------
+// Tile g's chain stopped at its last anchor x >= start of tile g+1.  Assuming x lies on the true
+// spine (the assemble kernel checks that: tile g must be reachable), continue the chain from x
+// until it produces an anchor that the downstream tile's own chain also found (or is that tile's
+// start): from there on the two chains are identical.  bmeta[g] = (count, join_tile, join_idx,
+// status); status 0 nothing to do, 1 joined (continue with list[join_tile][join_idx+1..]),
+// 2 the chain reached the end of the event, 3 gave up (host fallback).
+enum : int { BR_NONE = 0, BR_JOINED = 1, BR_ENDED = 2, BR_FAIL = 3 };
+
+template <int NT, int DT>
+__global__ __launch_bounds__(NT, 4) void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+                                                       const int4 *meta, int2 *bridges, int4 *bmeta,
+                                                       unsigned *status, unsigned long long *work)
+{
+    extern __shared__ int ys[];
+    __shared__ Shared sh;
+    const int g = blockIdx.x;
+    const SpineJob job = jobs[g];
+    const int4 m = meta[g];
+    const bool last_tile = (g - job.first_tile) == job.ntiles - 1;
+    if (last_tile || m.y != 0 || m.x == 0) {           // chain already ran to the end of the event
+        if (threadIdx.x == 0) bmeta[g] = make_int4(0, -1, 0, BR_NONE);
+        return;
+    }
+    unsigned bad = 0;
+    Work wk = PS_WORK_INIT;
+    int a = lists[job.out_off + m.x - 1].x;
+    int cnt = 0, st = BR_FAIL, jt = -1, ji = 0, cached = -1, ccnt = 0;
+    for (int step = 0; step <= BR_MAX; ++step) {
+        int u = a / job.tile_len;
+        if (u > job.ntiles - 1) u = job.ntiles - 1;
+        u += job.first_tile;
+        const SpineJob uj = jobs[u];
+        if (u != cached) {                             // cache the downstream list's positions in LDS
+            ccnt = meta[u].x;
+            __syncthreads();
+            for (int i = threadIdx.x; i < ccnt && i < LST_MAX; i += NT) sh.lst[i] = lists[uj.out_off + i].x;
+            __syncthreads();
+            cached = u;
+        }
+        int found = -2;                                // -1: a is the tile start, >=0: index in its list
+        if (a == uj.start) found = -1;
+        else {
+            int lo = 0, hi = ccnt - 1;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const int v = mid < LST_MAX ? sh.lst[mid] : lists[uj.out_off + mid].x;
+                if (v == a) { found = mid; break; }
+                if (v < a) lo = mid + 1; else hi = mid - 1;
+            }
+        }
+        if (found != -2 && u != g) { st = BR_JOINED; jt = u; ji = found; break; }
+        if (step == BR_MAX) break;
+        int kind;
+        const int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
+        if (kind == KIND_NONE) { st = BR_ENDED; break; }
+        if (threadIdx.x == 0) sh.obuf[cnt] = make_int2(s, kind);
+        ++cnt;
+        a = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += NT) bridges[static_cast<int64_t>(g) * BR_MAX + i] = sh.obuf[i];
+    if (threadIdx.x == 0) bmeta[g] = make_int4(cnt, jt, ji, st);
     flush(bad, wk, status, work);
 }
 
@@ -706,6 +785,7 @@ __global__ __launch_bounds__(NT, 4) void tree_kernel(DevCfg c, const TreeJob *jo
     extern __shared__ int ys[];
     __shared__ Shared sh;
     const TreeJob job = jobs[blockIdx.x];
+    if (job.out_cap == 0) return;                      // spine anchor without a left subtree (device stitch)
     int32_t *out = scratch + job.out_off;
     int2 *sp_glob = spill + job.out_off;
     unsigned bad = 0;
@@ -849,6 +929,159 @@ __global__ void event_offsets_kernel(const int64_t *pos, const int64_t *first_it
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e <= n_ev) bounds_off[e] = pos[first_item[e]];
+}
+
+
+// ---- device-side stitch: true spine, tree jobs and items from the tile lists and bridges ----------
+struct AsmHeader { long long n_items, n_jobs, tscratch; int fail, pad; };
+
+// exclusive scan of two values over one 1024-thread workgroup chunk with running carries
+__device__ __forceinline__ void chunk_exscan2(long long v1, long long v2, long long &e1, long long &e2,
+                                              long long *wsum /*[32]*/, long long *carry /*[2]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long i1 = v1, i2 = v2;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long u1 = __shfl_up(i1, d), u2 = __shfl_up(i2, d);
+        if (lane >= d) { i1 += u1; i2 += u2; }
+    }
+    if (lane == 63) { wsum[wave] = i1; wsum[16 + wave] = i2; }
+    __syncthreads();
+    long long b1 = carry[0], b2 = carry[1];
+    for (int w = 0; w < wave; ++w) { b1 += wsum[w]; b2 += wsum[16 + w]; }
+    e1 = b1 + i1 - v1; e2 = b2 + i2 - v2;
+    __syncthreads();
+    if (threadIdx.x == 1023) { carry[0] = b1 + i1; carry[1] = b2 + i2; }
+    __syncthreads();
+}
+
+// Stitch, part 1 (one workgroup): which tiles lie on the true spine, where the true path enters
+// them, how many anchors each contributes.  The per-tile arrays live in LDS when they fit
+// (use_lds), otherwise in HBM scratch.
+__global__ __launch_bounds__(1024) void assemble_tiles_kernel(
+    int n_tiles, const int4 *meta, const int4 *bmeta, const int64_t *ev_first_tile, int n_ev,
+    int *g_reach, int *g_jump_a, int *g_jump_b, int *entry_out, long long *sp_off_out,
+    int64_t *first_item, AsmHeader *hdr, long long max_items, int use_lds)
+{
+    extern __shared__ long long dyn_lds[];
+    __shared__ long long wsum[32];
+    __shared__ long long carry[2];
+    __shared__ int fail_s;
+    const int tid = threadIdx.x;
+    long long *sp_off = use_lds ? dyn_lds : sp_off_out;
+    int *lds_i = reinterpret_cast<int *>(dyn_lds + (n_tiles + 1));
+    int *reach = use_lds ? lds_i : g_reach;
+    int *ja = use_lds ? lds_i + n_tiles : g_jump_a;
+    int *jb = use_lds ? lds_i + 2 * n_tiles : g_jump_b;
+    int *entry = use_lds ? lds_i + 3 * n_tiles : entry_out;
+    if (tid == 0) { fail_s = 0; carry[0] = 0; carry[1] = 0; }
+    // A. forward pointers and roots
+    for (int g = tid; g < n_tiles; g += 1024) {
+        reach[g] = 0;
+        entry[g] = 0;
+        const int4 b = bmeta[g];
+        ja[g] = b.w == BR_JOINED ? b.y : -1;
+    }
+    __syncthreads();
+    for (int e = tid; e < n_ev; e += 1024)
+        if (ev_first_tile[e] < ev_first_tile[e + 1]) reach[ev_first_tile[e]] = 1;
+    __syncthreads();
+    // B. reachability from the roots by pointer doubling: after round k every tile within 2^k
+    //    joins of a root is marked
+    int rounds = 1;
+    while ((1 << rounds) < n_tiles) ++rounds;
+    for (int r = 0; r <= rounds; ++r) {
+        for (int g = tid; g < n_tiles; g += 1024) {
+            const int j = ja[g];
+            if (j >= 0 && reach[g]) reach[j] = 1;
+            jb[g] = j >= 0 ? ja[j] : -1;
+        }
+        __syncthreads();
+        int *t = ja; ja = jb; jb = t;
+    }
+    // C. entry index of every reached tile; failed bridges on the path
+    for (int g = tid; g < n_tiles; g += 1024) {
+        if (!reach[g]) continue;
+        const int4 b = bmeta[g];
+        if (b.w == BR_JOINED) entry[b.y] = b.z + 1;
+        if (b.w == BR_FAIL) fail_s = 1;
+    }
+    __syncthreads();
+    // D. contribution of every tile and its offset in the true spine
+    for (int g0 = 0; g0 < n_tiles; g0 += 1024) {
+        const int g = g0 + tid;
+        long long n = 0;
+        if (g < n_tiles && reach[g]) {
+            const int c = meta[g].x - entry[g];
+            n = static_cast<long long>(c) + bmeta[g].x;
+            if (c < 0) fail_s = 1;
+        }
+        long long e1, e2;
+        chunk_exscan2(n, 0, e1, e2, wsum, carry);
+        if (g < n_tiles) sp_off[g] = e1;
+    }
+    const long long n_items = carry[0];
+    if (tid == 0) sp_off[n_tiles] = n_items;
+    __syncthreads();
+    for (int e = tid; e <= n_ev; e += 1024) first_item[e] = sp_off[ev_first_tile[e]];
+    if (use_lds)
+        for (int g = tid; g <= n_tiles; g += 1024) {
+            sp_off_out[g] = sp_off[g];
+            if (g < n_tiles) entry_out[g] = entry[g];
+        }
+    if (tid == 0) {
+        hdr->n_items = n_items;
+        hdr->n_jobs = n_items;
+        hdr->tscratch = 0;
+        hdr->fail = (fail_s || n_items > max_items) ? 1 : 0;
+    }
+}
+
+// Stitch, part 2 (grid over the true spine): element i belongs to the tile g with
+// sp_off[g] <= i < sp_off[g+1].  Writes the item (anchor) and its tree job: job index = item
+// index, output region = (global sample index of the predecessor)/min_width + i, which is
+// monotone and non-overlapping without any scan ((a+b)/m >= a/m + b/m for integers).
+__global__ __launch_bounds__(256) void assemble_items_kernel(
+    const SpineJob *jobs, int n_tiles, const int4 *meta, const int2 *lists, const int2 *bridges,
+    const int *entry, const long long *sp_off, long long n_items, int mw, int W,
+    TreeJob *tjobs, Item *items, int32_t *counts)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n_items) return;
+    int lo = 0, hi = n_tiles - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sp_off[mid + 1] > i) hi = mid; else lo = mid + 1;
+    }
+    const int g = lo;
+    const int k = static_cast<int>(i - sp_off[g]);
+    const int en = entry[g], cnt = meta[g].x;
+    const SpineJob jb2 = jobs[g];
+    int2 el;
+    int pred;
+    if (k < cnt - en) {
+        el = lists[jb2.out_off + en + k];
+        pred = (en + k) > 0 ? lists[jb2.out_off + en + k - 1].x : jb2.start;
+    } else {
+        const int kb = k - (cnt - en);
+        el = bridges[static_cast<long long>(g) * BR_MAX + kb];
+        pred = kb > 0 ? bridges[static_cast<long long>(g) * BR_MAX + kb - 1].x : lists[jb2.out_off + cnt - 1].x;
+    }
+    const bool has = el.y == KIND_HIT || el.y == KIND_LATE;
+    Item it;
+    it.anchor = el.x;
+    it.job = has ? static_cast<int32_t>(i) : -1;
+    items[i] = it;
+    TreeJob tj;
+    tj.base = jb2.base;
+    tj.start = pred;
+    tj.end = el.x;
+    tj.j0 = left_child_j0(pred, el.x, W, W / 2);
+    tj.out_cap = has ? (el.x - pred) / mw + 1 : 0;       // 0 marks "no left subtree": the tree kernel skips it
+    tj.out_off = (jb2.base + pred) / mw + i;
+    tjobs[i] = tj;
+    counts[i] = 0;
 }
 
 // ---- K2: per-segment statistics, core.py:209-223 ------------------------------------------------

@@ -39,6 +39,9 @@ class Context(object):
     def set_tiling(self, tile_len=0, halo=0):
         _lib.check(self.L.ps_set_tiling(self.handle, int(tile_len), int(halo)), self.handle)
 
+    def set_option(self, name, value):
+        _lib.check(self.L.ps_set_option(self.handle, name.encode(), int(value)), self.handle)
+
     def timings(self):
         ms = (ctypes.c_double * 5)()
         cnt = (ctypes.c_int64 * 6)()

@@ -55,20 +55,40 @@ def test_parse_int16_and_float32_inputs(case, ctx):
     np.testing.assert_array_equal(_bounds(p2.parse(synth.counts_to_pa(counts, np.float64))), g)
 
 
-@pytest.mark.parametrize("tile,halo", [(20000, 10000), (50000, 20000), (100000, 40000), (30000, 1)])
+@pytest.mark.parametrize("stitch_host", [0, 1])
+@pytest.mark.parametrize("tile,halo", [(20000, 10000), (50000, 20000), (100000, 40000), (30000, 1), (7000, 1)])
 @pytest.mark.parametrize("name", ["G8_full", "G9_rd_2M", "G9_rd_short_dwell", "G9_rd_long_dwell", "G9_cutoff",
                                   "G4_forced_flat", "G4_forced_mixed", "G4_big_window", "G4_small_windows"])
-def test_tiled_spines_stitch_to_the_same_result(name, tile, halo, ctx):
-    """Speculative tiles + stitching (incl. seam repairs when the halo is too short) must not
-    change a single boundary."""
+def test_tiled_spines_stitch_to_the_same_result(name, tile, halo, stitch_host, ctx):
+    """Speculative tiles + stitching must not change a single boundary: device stitch (bridged seams,
+    assemble kernel; falls back to the host when a bridge gives up) and host stitch (halo tiles,
+    seam repairs when the halo is too short)."""
     from pypore_amd.parsers import SpeedyStatSplit
     (case,) = [c for c in cases("parse") if c["name"] == name]
     ctx.set_tiling(tile, halo)
+    ctx.set_option("stitch_host", stitch_host)
     try:
         segs = SpeedyStatSplit(quantum=synth.QUANTUM, **case["params"]).parse(input_pa(case, np.float32))
     finally:
         ctx.set_tiling(0, 0)
+        ctx.set_option("stitch_host", 0)
     np.testing.assert_array_equal(_bounds(segs), npz()[name + "/bounds"])
+
+
+def test_verify_mode_screen_agrees_with_exact_scan(ctx):
+    """mode 2: every window is scanned by the fp32 screen AND the exact fp64 path; any disagreement
+    raises.  Run on the config-2 batch shape and a 2e6-sample trace."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    ctx.set_option("mode", 2)
+    try:
+        p = SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM)
+        out = p.parse_batch([synth.config2_event(ev, dtype=np.float32) for ev in range(200, 232)])
+        assert sum(len(s) for s in out) >= 32 * 5
+        (case,) = [c for c in cases("parse") if c["name"] == "G9_rd_2M"]
+        segs = p.parse(input_pa(case, np.float32))
+        np.testing.assert_array_equal(_bounds(segs), npz()["G9_rd_2M/bounds"])
+    finally:
+        ctx.set_option("mode", 0)
 
 
 @pytest.mark.parametrize("case", cases("score_window"), ids=case_ids("score_window"))
