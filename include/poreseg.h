@@ -118,6 +118,17 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
                      int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off,
                      ps_segstat *d_stats);
 
+/* ps_segment_batch plus one more output: d_is_spine (nullable device out, capacity `cap` bytes) is 1
+ * for breakpoints found by the top-level chain of right recursions rec(a, len) ("spine anchors"),
+ * 0 for breakpoints of left subtrees.  Two runs over overlapping pieces of one trace are identical
+ * after any common spine anchor; pypore_amd/dist.py uses that to stitch a trace sharded across
+ * GPUs (BASELINE config 5).  No reference counterpart. */
+int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                        const int64_t *h_ev_off, int32_t n_ev,
+                        const ps_split_params *params,
+                        int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off,
+                        ps_segstat *d_stats, uint8_t *d_is_spine);
+
 /* Upper bound on the number of breakpoints ps_segment_batch can emit for these events
  * (sum over events of len/min_width): a safe `cap`. */
 int64_t ps_bounds_capacity(const int64_t *h_ev_off, int32_t n_ev, int32_t min_width);

@@ -34,6 +34,9 @@ def lib():
         L.so_parse.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                ctypes.c_double, ip, ctypes.c_long, ctypes.POINTER(ctypes.c_longlong)]
         L.so_parse.restype = ctypes.c_long
+        L.so_parse_flags.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ip,
+                                     ctypes.POINTER(ctypes.c_ubyte), ctypes.c_long]
+        L.so_parse_flags.restype = ctypes.c_long
         L.so_best_single_split.argtypes = [dp, ctypes.c_int, dp, ip]
         L.so_best_single_split.restype = ctypes.c_int
         L.so_score_window.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp]
@@ -78,6 +81,22 @@ def parse(x, min_width=100, max_width=1000000, window_width=10000, min_gain=None
         raise RuntimeError("oracle so_parse failed (%d)" % n)
     b = out[:n].copy()
     return (b, (int(st[0]), int(st[1]))) if stats else b
+
+
+def parse_flags(x, min_width=100, max_width=1000000, window_width=10000, min_gain=None, **kw):
+    """(breakpoints, is_spine flags) -- spine anchors are the breakpoints of the top-level chain."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if min_gain is None:
+        min_gain = globals()["min_gain"](min_width, max_width, window_width, **kw)
+    cap = max(16, x.size // max(1, int(min_width)) + 16)
+    out = np.empty(cap, dtype=np.int32)
+    fl = np.zeros(cap, dtype=np.uint8)
+    n = lib().so_parse_flags(_dptr(x), x.size, int(min_width), int(max_width), int(window_width), float(min_gain),
+                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                             fl.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), cap)
+    if n < 0 or n > cap:
+        raise RuntimeError("oracle so_parse_flags failed (%d)" % n)
+    return out[:n].copy(), fl[:n].copy()
 
 
 def best_single_split(x):

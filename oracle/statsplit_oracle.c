@@ -110,7 +110,7 @@ static int push(so_stack *s, int kind, int a, int b)
 }
 
 /* ---- cparsers.pyx:180-203  _recursive_split, same output order, no C recursion ---- */
-static long recursive_split(so_ctx *k, int start0, int end0, int *out, long cap)
+static long recursive_split(so_ctx *k, int start0, int end0, int *out, long cap, unsigned char *flags)
 {
     so_stack st = {0, 0, 0};
     long cnt = 0;
@@ -118,7 +118,7 @@ static long recursive_split(so_ctx *k, int start0, int end0, int *out, long cap)
     push(&st, 0, start0, end0);
     while (st.n) {
         so_item it = st.v[--st.n];
-        if (it.kind == 1) { if (cnt < cap) out[cnt] = it.a; cnt++; continue; }
+        if (it.kind == 1) { if (cnt < cap) { out[cnt] = it.a; if (flags) flags[cnt] = (unsigned char)it.b; } cnt++; continue; }
         int start = it.a, end = it.b, split_at = -1, forced_early = 0;
         for (long ps = start; ps < (long)end - 2 * mw; ps += W / 2) {      /* :188 */
             if (ps > (long)start + maxw) {                                 /* :189-191 */
@@ -133,7 +133,7 @@ static long recursive_split(so_ctx *k, int start0, int end0, int *out, long cap)
         }
         if (forced_early) {                   /* [split] + rec(split, end): right side only */
             push(&st, 0, split_at, end);
-            push(&st, 1, split_at, 0);
+            push(&st, 1, split_at, end == end0);
             continue;
         }
         if (split_at == -1) {                                              /* :198-201 */
@@ -142,7 +142,7 @@ static long recursive_split(so_ctx *k, int start0, int end0, int *out, long cap)
             split_at = a <= b ? a : b;
         }
         push(&st, 0, split_at, end);          /* rec(start,split) + [split] + rec(split,end) */
-        push(&st, 1, split_at, 0);
+        push(&st, 1, split_at, end == end0);  /* spine anchor: found by a frame rec(a, END) of the top-level chain */
         push(&st, 0, start, split_at);
     }
     free(st.v);
@@ -161,8 +161,23 @@ long so_parse(const double *x, int n, int min_width, int max_width, int window_w
     if (!c || !c2) { free(c); free(c2); return -1; }
     prefix_sums(x, n, c, c2);
     so_ctx k = { c, c2, min_width, max_width, window_width, min_gain, 0, 0 };
-    long cnt = recursive_split(&k, 0, n, out, cap);
+    long cnt = recursive_split(&k, 0, n, out, cap, 0);
     if (stats) { stats[0] = k.n_evals; stats[1] = k.n_windows; }
+    free(c); free(c2);
+    return cnt;
+}
+
+/* so_parse plus flags[i] = 1 when breakpoint i was found by the top-level chain of right
+ * recursions rec(a, n) (a "spine anchor"); test counterpart of ps_segment_batch_ex. */
+long so_parse_flags(const double *x, int n, int min_width, int max_width, int window_width,
+                    double min_gain, int *out, unsigned char *flags, long cap)
+{
+    double *c = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *c2 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (!c || !c2) { free(c); free(c2); return -1; }
+    prefix_sums(x, n, c, c2);
+    so_ctx k = { c, c2, min_width, max_width, window_width, min_gain, 0, 0 };
+    long cnt = recursive_split(&k, 0, n, out, cap, flags);
     free(c); free(c2);
     return cnt;
 }

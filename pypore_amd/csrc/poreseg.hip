@@ -68,6 +68,7 @@ struct ps_ctx {
     int mode = MODE_FAST, spine_nt = 512, tree_nt = 256;
     int lds_max_samples = 0;
     int rep_eval = 1, rep_stage = 1, rep_sum = 1;
+    uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
     HostBuf h_hdr;
@@ -272,7 +273,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (n_items) {
         hipLaunchKernelGGL(gather_kernel, dim3(static_cast<unsigned>(n_items)), dim3(64), 0, ctx->stream,
                            ctx->items.as<Item>(), ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(),
-                           ctx->tree_scratch.as<int32_t>(), ctx->item_pos.as<int64_t>(), n_items, d_bounds, cap);
+                           ctx->tree_scratch.as<int32_t>(), ctx->item_pos.as<int64_t>(), n_items, d_bounds, cap, ctx->d_is_spine);
         HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(event_offsets_kernel, dim3((n_ev + 1 + 255) / 256), dim3(256), 0, ctx->stream,
@@ -599,7 +600,16 @@ int ps_segment_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
                      const int64_t *h_ev_off, int32_t n_ev, const ps_split_params *params,
                      int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats)
 {
+    return ps_segment_batch_ex(ctx, d_samples, fmt, h_ev_off, n_ev, params, d_bounds, cap, h_bounds_off, d_stats, nullptr);
+}
+
+int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                        const int64_t *h_ev_off, int32_t n_ev, const ps_split_params *params,
+                        int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
+                        uint8_t *d_is_spine)
+{
     if (!ctx) return PS_ERR_ARG;
+    ctx->d_is_spine = d_is_spine;
     const auto t_begin = std::chrono::steady_clock::now();
     if (!h_ev_off || !params || !h_bounds_off || n_ev < 0 || cap < 0 || (cap > 0 && !d_bounds))
         return fail(ctx, PS_ERR_ARG, "null/negative argument");

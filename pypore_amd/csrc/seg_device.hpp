@@ -907,7 +907,7 @@ __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, cons
 __global__ __launch_bounds__(64) void gather_kernel(const Item *items, const TreeJob *jobs,
                                                     const int32_t *counts, const int32_t *scratch,
                                                     const int64_t *pos, int64_t n_items,
-                                                    int32_t *bounds, int64_t cap)
+                                                    int32_t *bounds, int64_t cap, uint8_t *is_spine)
 {
     const int64_t it = blockIdx.x;
     if (it >= n_items) return;
@@ -918,9 +918,9 @@ __global__ __launch_bounds__(64) void gather_kernel(const Item *items, const Tre
         cnt = counts[item.job];
         const int32_t *src = scratch + jobs[item.job].out_off;
         for (int i = threadIdx.x; i < cnt; i += 64)
-            if (p + i < cap) bounds[p + i] = src[i];
+            if (p + i < cap) { bounds[p + i] = src[i]; if (is_spine) is_spine[p + i] = 0; }
     }
-    if (threadIdx.x == 0 && p + cnt < cap) bounds[p + cnt] = item.anchor;
+    if (threadIdx.x == 0 && p + cnt < cap) { bounds[p + cnt] = item.anchor; if (is_spine) is_spine[p + cnt] = 1; }
 }
 
 // bounds_off[e] = pos[first_item[e]]

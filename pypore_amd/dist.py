@@ -68,3 +68,64 @@ def segment_units_sharded(unit_lengths, segment_fn, device=None, group=None):
         for k, u in enumerate(shards[r]):
             out[u] = p[offs[k]:offs[k + 1]].copy()
     return out
+
+
+# ---- one long trace sharded across GPUs (BASELINE config 5) ---------------------------------------
+# rec(a, N) depends only on (a, N, data): two segmentations of overlapping pieces of one trace are
+# identical after any common SPINE anchor (a breakpoint of the top-level chain of right recursions),
+# provided the windows that found it did not touch the end of the piece.  So every rank segments
+# its piece [S_r, S_{r+1} + halo) as if it were a whole trace (no sample exchange between GPUs), and
+# the pieces are joined at the first spine anchor that rank r (trusted part) and rank r+1 share.
+
+def shard_ranges(n, world_size, halo):
+    """Piece of every rank: (lo, hi) with hi = min(n, next shard start + halo)."""
+    starts = [(r * n) // world_size for r in range(world_size + 1)]
+    return [(starts[r], min(n, starts[r + 1] + (halo if r < world_size - 1 else 0))) for r in range(world_size)]
+
+
+def stitch_pieces(pieces, n, window_width, min_width):
+    """pieces: per rank (lo, hi, bounds_local int32, is_spine uint8), rank order.  Returns the global
+    breakpoint array.  Raises RuntimeError when a seam finds no common trusted spine anchor
+    (halo too short for this signal)."""
+    out = []
+    enter = -1                                   # global position after which the current piece is valid
+    for r, (lo, hi, b, f) in enumerate(pieces):
+        g = np.asarray(b, dtype=np.int64) + lo
+        f = np.asarray(f, dtype=bool)
+        last = r == len(pieces) - 1
+        if last:
+            out.append(g[g > enter])
+            break
+        nlo, nhi, nb, nf = pieces[r + 1]
+        ng = np.asarray(nb, dtype=np.int64) + nlo
+        nspine = set(ng[np.asarray(nf, dtype=bool)].tolist())
+        # spine anchors of this piece found by windows that cannot have touched its end
+        trust_limit = hi - 2 * window_width - 2 * min_width if hi < n else n
+        cand = g[f & (g >= nlo) & (g > enter) & (g <= trust_limit)]
+        join = next((int(a) for a in cand if int(a) in nspine), None)
+        if join is None:
+            raise RuntimeError("sharded trace: pieces %d and %d share no spine anchor inside the halo "
+                               "(increase halo)" % (r, r + 1))
+        out.append(g[(g > enter) & (g <= join)])
+        enter = join
+    return np.concatenate(out).astype(np.int64) if out else np.zeros(0, np.int64)
+
+
+def segment_trace_sharded(n, segment_piece_fn, window_width, min_width, halo=None, device=None, group=None):
+    """Segments ONE trace of n samples across the ranks of `group`.
+
+    segment_piece_fn(lo, hi) -> (bounds_local int32, is_spine uint8): the local segmenter applied to
+    samples [lo, hi) as a stand-alone trace (ps_segment_batch_ex with d_is_spine on this rank's GPU).
+    Every rank returns the full global breakpoint array.  Collectives: the boundary gather only."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if halo is None:
+        halo = 8 * window_width
+    ranges = shard_ranges(n, world, halo)
+    lo, hi = ranges[rank]
+    b, f = segment_piece_fn(lo, hi)
+    dev = device if device is not None else torch.device("cpu")
+    allb = gather_varlen(torch.from_numpy(np.ascontiguousarray(b, dtype=np.int32)).to(dev), group)
+    allf = gather_varlen(torch.from_numpy(np.ascontiguousarray(f, dtype=np.uint8)).to(dev), group)
+    pieces = [(ranges[r][0], ranges[r][1], allb[r].cpu().numpy(), allf[r].cpu().numpy()) for r in range(world)]
+    return stitch_pieces(pieces, n, window_width, min_width)

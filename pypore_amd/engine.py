@@ -51,7 +51,8 @@ class Context(object):
                     exact_rescans=cnt[5])
 
     # ---- the hot path ---------------------------------------------------------------------------
-    def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None):
+    def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None,
+                      want_spine=False):
         """ps_segment_batch on device-resident `samples` (torch float32 or int16 CUDA tensor).
         Returns (bounds int32 CUDA tensor [total], bounds_off int64 numpy [n_ev+1],
         stats float64 CUDA tensor [total+n_ev, 4] or None)."""
@@ -75,12 +76,16 @@ class Context(object):
         stats = torch.empty((max(cap, 1) + n_ev, 4), dtype=torch.float64, device=dev) if want_stats else None
         boff = np.zeros(n_ev + 1, dtype=np.int64)
         torch.cuda.current_stream(dev).synchronize()      # inputs produced on torch's stream are ready
-        rc = self.L.ps_segment_batch(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), off_p,
-                                     n_ev, ctypes.byref(params), ctypes.c_void_p(bounds.data_ptr()), cap,
-                                     boff.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
-                                     ctypes.c_void_p(stats.data_ptr()) if want_stats else None)
+        spine = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev) if want_spine else None
+        rc = self.L.ps_segment_batch_ex(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), off_p,
+                                        n_ev, ctypes.byref(params), ctypes.c_void_p(bounds.data_ptr()), cap,
+                                        boff.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                        ctypes.c_void_p(stats.data_ptr()) if want_stats else None,
+                                        ctypes.c_void_p(spine.data_ptr()) if want_spine else None)
         _lib.check(rc, self.handle)
         total = int(boff[-1])
+        if want_spine:
+            return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None), spine[:total]
         return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None)
 
     def best_single_split(self, samples, quantum, offset_counts=0):

@@ -74,3 +74,71 @@ def test_shard_units_balanced_and_deterministic():
     assert max(loads) - min(loads) <= max(lens)
     assert s == shard_units(lens, 3)
     assert shard_units([], 2) == [[], []]
+
+
+@pytest.mark.parametrize("world,halo", [(2, 80000), (4, 60000), (8, 80000)])
+def test_sharded_trace_stitch_equals_whole_trace(world, halo):
+    """BASELINE config 5 logic on the CPU: pieces segmented independently (oracle as the per-rank
+    segmenter) and joined at common spine anchors reproduce the whole-trace result bit for bit."""
+    import oracle
+    from pypore_amd import synth
+    from pypore_amd.dist import shard_ranges, stitch_pieces
+    n = 1_600_000
+    x = synth.counts_to_pa(synth.random_dwell_counts(n, 61), np.float64)
+    ref = oracle.parse(x, prior_segments_per_second=10.)
+    pieces = []
+    for lo, hi in shard_ranges(n, world, halo):
+        b, f = oracle.parse_flags(x[lo:hi], prior_segments_per_second=10.)
+        pieces.append((lo, hi, b, f))
+    got = stitch_pieces(pieces, n, 10000, 100)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_sharded_trace_too_short_halo_fails_loudly():
+    import oracle
+    from pypore_amd import synth
+    from pypore_amd.dist import shard_ranges, stitch_pieces
+    n = 600_000
+    x = synth.counts_to_pa(synth.random_dwell_counts(n, 62, 30000, 90000), np.float64)
+    pieces = []
+    for lo, hi in shard_ranges(n, 3, 21000):
+        b, f = oracle.parse_flags(x[lo:hi], prior_segments_per_second=10.)
+        pieces.append((lo, hi, b, f))
+    with pytest.raises(RuntimeError, match="halo"):
+        stitch_pieces(pieces, n, 10000, 100)
+
+
+def _worker_trace(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from pypore_amd import dist as pdist
+        from pypore_amd import synth
+        n = 700_000
+        x = synth.counts_to_pa(synth.random_dwell_counts(n, 63), np.float64)
+
+        def seg(lo, hi):
+            return oracle.parse_flags(x[lo:hi], prior_segments_per_second=10.)
+
+        got = pdist.segment_trace_sharded(n, seg, 10000, 100, halo=80000)
+        q.put((rank, bool(np.array_equal(got, oracle.parse(x, prior_segments_per_second=10.)))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_trace_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_trace, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

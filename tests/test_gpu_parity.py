@@ -227,3 +227,26 @@ def test_1e8_trace_digest(ctx):
     assert hashlib.sha256(b.tobytes()).hexdigest() == case["sha256"]
     # size-independent properties: sorted, strictly increasing, >= min_width apart, inside the trace
     assert np.all(np.diff(b) >= case["params"]["min_width"]) and b[0] >= 100 and b[-1] <= n - 100
+
+
+def test_spine_flags_and_sharded_trace_on_device(ctx):
+    """ps_segment_batch_ex's spine flags equal the oracle's, and a trace cut into 4 pieces that are
+    segmented independently on the GPU stitches back to the whole-trace golden (config 5 logic)."""
+    import torch
+    from pypore_amd import _lib
+    from pypore_amd.dist import shard_ranges, stitch_pieces
+    (case,) = [c for c in cases("parse") if c["name"] == "G9_rd_2M"]
+    x = input_pa(case, np.float32)
+    n = len(x)
+    params = _lib.split_params(**case["params"])
+    t = torch.from_numpy(x).cuda()
+    b, _, _, f = ctx.segment_batch(t, np.array([0, n]), params, synth.QUANTUM, want_stats=False, want_spine=True)
+    rb, rf = oracle.parse_flags(x.astype(np.float64), **case["params"])
+    np.testing.assert_array_equal(b.cpu().numpy(), rb)
+    np.testing.assert_array_equal(f.cpu().numpy(), rf)
+    pieces = []
+    for lo, hi in shard_ranges(n, 4, 80000):
+        pb, _, _, pf = ctx.segment_batch(t[lo:hi].contiguous(), np.array([0, hi - lo]), params, synth.QUANTUM,
+                                         want_stats=False, want_spine=True)
+        pieces.append((lo, hi, pb.cpu().numpy(), pf.cpu().numpy()))
+    np.testing.assert_array_equal(stitch_pieces(pieces, n, 10000, 100), npz()["G9_rd_2M/bounds"])
