@@ -69,6 +69,7 @@ struct ps_ctx {
     int lds_max_samples = 0;
     int rep_eval = 1, rep_stage = 1, rep_sum = 1;
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
+    int prune = 1;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
     HostBuf h_hdr;
@@ -124,9 +125,18 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->mw = mw; c->maxw = maxw; c->W = W; c->half = W / 2;
     c->min_gain = min_gain;
     c->mode = ctx->mode;
+    c->prune = ctx->prune;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
     c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
+}
+
+// dynamic LDS of the scan kernels: window samples (+ alignment slack) and the per-block sums of
+// the pruned screen (one int2 per PBLK samples, at most one extra slot per thread)
+inline size_t lds_bytes_for(int lds_cap, int nt)
+{
+    return (((static_cast<size_t>(lds_cap) + 32) * sizeof(lds_t) + 15) & ~static_cast<size_t>(15)) +
+           (static_cast<size_t>(lds_cap) / PBLK + static_cast<size_t>(nt) + 8) * sizeof(int2);
 }
 
 // LDS budget: 160 KB per CU minus the static Shared block and a little slack
@@ -134,7 +144,7 @@ constexpr int LDS_BYTES_MAX = 160 * 1024 - static_cast<int>(sizeof(Shared)) - 51
 
 template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, bool list_mode = false)
 {
-    const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);   // + alignment slack of the staged region
+    const size_t lds = lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(spine_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
@@ -146,7 +156,7 @@ template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsig
 
 template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
-    const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);   // + alignment slack of the staged region
+    const size_t lds = lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
@@ -332,7 +342,7 @@ constexpr int RC_FALLBACK = 1;
 
 template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
-    const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);
+    const size_t lds = lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bridge_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
@@ -507,13 +517,14 @@ int ps_create(int device, void *stream, ps_ctx **out)
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     if (ctx->small.reserve(sizeof(SmallLayout)) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
-    ctx->lds_max_samples = LDS_BYTES_MAX / static_cast<int>(sizeof(int));
+    ctx->lds_max_samples = (LDS_BYTES_MAX - 1024 * 8 - 256) / (static_cast<int>(sizeof(lds_t)) + 1);   // samples + block sums
     if (const char *e = std::getenv("PORESEG_MODE")) ctx->mode = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_SPINE_NT")) ctx->spine_nt = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_TREE_NT")) ctx->tree_nt = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_REP_EVAL")) ctx->rep_eval = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_REP_STAGE")) ctx->rep_stage = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
@@ -553,6 +564,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     const std::string n(name);
     if (n == "mode" && value >= 0 && value <= 2) ctx->mode = static_cast<int>(value);
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
+    else if (n == "prune") ctx->prune = value != 0;
     else if (n == "spine_nt" && (value == 256 || value == 512 || value == 1024)) ctx->spine_nt = static_cast<int>(value);
     else if (n == "tree_nt" && (value == 256 || value == 512)) ctx->tree_nt = static_cast<int>(value);
     else return fail(ctx, PS_ERR_ARG, "unknown option or value: %s", name);
@@ -816,7 +828,7 @@ static int single_scan(ps_ctx *ctx, const void *d_samples, const ps_sample_forma
     int *d_idx = reinterpret_cast<int *>(d_gain + 1);
     cfg.lds_cap = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(n, ctx->lds_max_samples)));
     {
-        const size_t lds = (static_cast<size_t>(cfg.lds_cap) + 16) * sizeof(int);   // + alignment slack of the staged region
+        const size_t lds = lds_bytes_for(cfg.lds_cap, 1024);
         if (cfg.dtype == PS_DTYPE_F32) {
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(single_scan_kernel<1024, PS_DTYPE_F32>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

@@ -32,7 +32,9 @@ constexpr int LDS_STACK = 128;   // DFS stack entries kept in LDS before spillin
 constexpr int MAX_WAVES = 16;
 constexpr int OBUF = 256;
 constexpr int BR_MAX = 32;        // bridge chain: anchors a seam may add before it must have joined
-constexpr int LST_MAX = 256;      // anchors of the downstream tile cached in LDS for membership tests        // buffered outputs per job (int2 anchors / 2x int boundaries)
+constexpr int LST_MAX = 256;
+constexpr int QMAX = 256;          // blocks of candidates queued for full evaluation per window
+constexpr int PBLK = 8;            // candidates per pruning block      // anchors of the downstream tile cached in LDS for membership tests        // buffered outputs per job (int2 anchors / 2x int boundaries)
 
 enum : int { KIND_NONE = 0, KIND_HIT = 1, KIND_EARLY = 2, KIND_LATE = 3 };
 enum : unsigned { ST_OFF_GRID = 1u, ST_OUT_OVERFLOW = 2u, ST_STACK_OVERFLOW = 4u, ST_VERIFY_MISMATCH = 8u };
@@ -46,6 +48,7 @@ struct DevCfg {
     int mw, maxw, W, half;
     double min_gain;
     int mode;               // MODE_*
+    int prune;              // 1: block-bound pruning in the screen (default), 0: evaluate every candidate
     int lds_cap;            // samples that fit the dynamic LDS window buffer
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
@@ -69,6 +72,10 @@ struct TreeJob {            // full in-order traversal of rec(start, end), first
     int64_t out_off;        // into the private boundary scratch (int32) and the spill stack (int2)
 };
 
+typedef short lds_t;               // window samples in LDS: ADC counts as int16 (windows that do not fit go the exact HBM path)
+
+struct QEnt { int j, jend, p1, r1; unsigned p2, r2; int cL, cR; };
+
 struct Shared {
     double wsum1[MAX_WAVES], wsum2[MAX_WAVES];
     double wbest[MAX_WAVES];
@@ -81,6 +88,9 @@ struct Shared {
     int2 pop;
     int2 stack[LDS_STACK];
     int lst[LST_MAX];
+    float wmaxf[MAX_WAVES];
+    int qn;
+    QEnt q[QMAX];
     int2 obuf[OBUF];        // results are buffered here and written to HBM once per job: a global
                             // store issued between scans would sit in front of the next window's
                             // staging loads (vmcnt retires in order) and stall the whole workgroup
@@ -254,7 +264,7 @@ __device__ __forceinline__ int block_argmax(double g, int idx, Shared &sh, doubl
 // ---- exact scan of a staged window: cparsers.pyx:157-178 to the letter -------------------------
 // ys[0..n) hold the window's counts (LDS) or, when ys == nullptr, samples are read from HBM.
 template <int NT, int DT>
-__device__ int scan_exact(const DevCfg &c, const int *ys, int64_t g0, int ps, int n, int cand_lo,
+__device__ int scan_exact(const DevCfg &c, const lds_t *ys, int64_t g0, int ps, int n, int cand_lo,
                           int cand_hi, double thresh, double *scores, Shared &sh, unsigned &bad,
                           double *best_gain_out)
 {
@@ -342,7 +352,7 @@ __device__ __forceinline__ void top2_merge(Top2 &t, float ob, float os, int oi)
 // Returns 1 if the screen produced a final answer (result in *split), 0 if the exact path is
 // needed.  All threads return the same value.
 template <int NT>
-__device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int cand_lo, int cand_hi,
+__device__ int scan_screen(const DevCfg &c, const lds_t *ys, int ps, int n, int cand_lo, int cand_hi,
                            double thresh, int kmin, int kmax, Shared &sh, int *split, Work &wk)
 {
     constexpr int NW = NT / 64;
@@ -476,6 +486,251 @@ __device__ int scan_screen(const DevCfg &c, const int *ys, int ps, int n, int ca
     return 0;
 }
 
+
+// ---- fp32 screen with exact block pruning -----------------------------------------------------------
+// Most candidates never need an evaluation.  For a block of candidates j in [jb, je) the sums of
+// squared deviations are monotone: SS_L(j) >= SS_L(jb) (the left part only grows) and
+// SS_R(j) >= SS_R(je) (the right part only shrinks), hence with a = log2 V_L(jb) - c0,
+// b = log2 V_R(je) - c0 and log2(1+x) <= x*log2(e):
+//     G(j) <= -( nl*(a - (nl-nl_b)*log2e/nl_b) + nr*(b - (nr-nr_e)*log2e/nr_e) ),   nl = j, nr = n-j,
+// a convex function of nl, so its maximum over the block is at one of the two end candidates.
+// Only the block-boundary candidates are evaluated (one in PBLK); a block whose bound cannot reach
+// T0 = max(threshold, best boundary gain seen by the first round) minus the error margins is
+// discarded, the few others are queued in LDS and evaluated candidate by candidate by the whole
+// workgroup.  Decisions are the same as with every candidate evaluated: a discarded candidate is
+// provably below the threshold band or more than 2*delta below the winner.
+struct ScrOut { float g; f2 lg; f2 r; };
+
+__device__ __forceinline__ ScrOut screen_eval(int p1, unsigned p2, int r1, unsigned r2, f2 nv, f2 cc,
+                                              float &kguard, float &umin)
+{
+    const f2 s1 = {static_cast<float>(p1), static_cast<float>(r1)};
+    const f2 s2 = {static_cast<float>(p2), static_cast<float>(r2)};
+    const f2 ns2 = nv * s2;
+    const f2 D = __builtin_elementwise_fma(-s1, s1, ns2);
+    const f2 four = {4.0f, 4.0f};
+    const f2 g = __builtin_elementwise_fma(four, D, -ns2);
+    const f2 r = {__builtin_amdgcn_rcpf(nv.x), __builtin_amdgcn_rcpf(nv.y)};
+    const f2 u = D * r * r;
+    kguard = fminf(kguard, fminf(g.x, g.y));
+    umin = fminf(umin, fminf(u.x, u.y));
+    const f2 lgu = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+    ScrOut o;
+    o.lg = lgu - cc;
+    o.r = r;
+    const f2 t = nv * o.lg;
+    o.g = -(t.x + t.y);
+    return o;
+}
+
+template <int NT>
+__device__ int scan_screen_pruned(const DevCfg &c, const lds_t *ys, int2 *bsum, int ps, int n, int cand_lo, int cand_hi,
+                                  double thresh, int kmin, int kmax, Shared &sh, int *split, Work &wk)
+{
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ch = (((n + NT - 1) / NT) + PBLK - 1) / PBLK * PBLK + 1;   // odd stride: conflict-free reads
+    const int lo = min(n, static_cast<int>(threadIdx.x) * ch);
+    const int hi = min(n, lo + ch);
+    const int R = kmax - kmin;
+    if (R >= 23000 || static_cast<long long>(ch + 1) * (static_cast<long long>(R) * R) >= (1LL << 31)) return 0;
+    const int m0 = kmin + (R >> 1);
+
+    // pass A: per-block (PBLK samples) sums of y = k - m0 and y^2, kept in LDS for the block advance
+    // of pass 1, and the chunk totals for the workgroup scan
+    int s1 = 0;
+    unsigned s2 = 0;
+    const int kb = (ch - 1) / PBLK;                    // block slots per thread
+    int2 *mybs = bsum + static_cast<int>(threadIdx.x) * kb;
+    {
+        int j = lo, b = 0;
+        for (; j + PBLK <= hi; j += PBLK, ++b) {
+            int y[PBLK];
+#pragma unroll
+            for (int u = 0; u < PBLK; ++u) y[u] = ys[j + u] - m0;
+            int t1b = 0;
+            unsigned t2b = 0;
+#pragma unroll
+            for (int u = 0; u < PBLK; ++u) { t1b += y[u]; t2b += static_cast<unsigned>(__mul24(y[u], y[u])); }
+            mybs[b] = make_int2(t1b, static_cast<int>(t2b));
+            s1 += t1b; s2 += t2b;
+        }
+        for (; j < hi; ++j) {
+            const int y = ys[j] - m0;
+            s1 += y;
+            s2 += static_cast<unsigned>(__mul24(y, y));
+        }
+    }
+    double a1, a2, t1, t2;
+    block_exscan2<NT>(static_cast<double>(s1), static_cast<double>(s2), a1, a2, t1, t2, sh);
+
+    const double dn = static_cast<double>(n);
+    const double Dtot = dn * t2 - t1 * t1;
+    if (!(Dtot > 0.0)) return 0;
+    const float rn = __builtin_amdgcn_rcpf(static_cast<float>(n));
+    const float c0 = __builtin_amdgcn_logf(static_cast<float>(Dtot) * rn * rn);
+    const f2 cc = {c0, c0};
+    const float dlt = screen_delta_log2(n);
+    const float thr_log2 = static_cast<float>(thresh * 1.4426950408889634);
+    const float dthr = dlt + 3.0e-6f * static_cast<float>(n) + 1.0e-6f * fabsf(thr_log2);
+    const float nf = static_cast<float>(n);
+    const float LOG2E = 1.4426950408889634f;
+
+    const int clo = max(lo, cand_lo - ps), chi = min(hi, cand_hi - ps + 1);
+    const bool have = clo < chi;
+    Top2 top = {-INFINITY, -INFINITY, -1};
+    unsigned flag = 0;
+    float kguard = INFINITY, umin = INFINITY;
+    int p1 = 0, r1 = 0, cL = 0, cR = 0;
+    unsigned p2 = 0, r2 = 0;
+    const float mabs = fmaxf(fabsf(static_cast<float>(kmin)), fabsf(static_cast<float>(kmax)));
+    const float vfloor = mabs * mabs * 1.0e-9f;
+    ScrOut b0 = {-INFINITY, {0.f, 0.f}, {0.f, 0.f}};
+    if (have) {
+        for (int j = lo; j < clo; ++j) {
+            const double y = static_cast<double>(ys[j] - m0);
+            a1 += y; a2 += y * y;
+        }
+        const int nl0 = clo, nr0 = n - clo;
+        const double b1 = t1 - a1, b2 = t2 - a2;
+        const int a1i = static_cast<int>(a1), b1i = static_cast<int>(b1);
+        const int muL = __float2int_rn(static_cast<float>(a1i) * __builtin_amdgcn_rcpf(static_cast<float>(nl0)));
+        const int muR = __float2int_rn(static_cast<float>(b1i) * __builtin_amdgcn_rcpf(static_cast<float>(nr0)));
+        p1 = a1i - __mul24(nl0, muL); r1 = b1i - __mul24(nr0, muR);
+        const double p2d = a2 - static_cast<double>(muL) * (a1 + static_cast<double>(p1));
+        const double r2d = b2 - static_cast<double>(muR) * (b1 + static_cast<double>(r1));
+        const float roomf = static_cast<float>(chi - clo) * (static_cast<float>(R) + 1.0f) * (static_cast<float>(R) + 1.0f);
+        if (!(static_cast<float>(p2d) + roomf < 4.2e9f) || !(static_cast<float>(r2d) < 4.2e9f) ||
+            !(fabsf(static_cast<float>(p1)) + roomf < 2.1e9f) || !(fabsf(static_cast<float>(r1)) + roomf < 2.1e9f))
+            flag = 1;
+        p2 = static_cast<unsigned>(p2d); r2 = static_cast<unsigned>(r2d);
+        cL = m0 + muL; cR = m0 + muR;
+        if (!flag) {
+            const f2 nv = {static_cast<float>(clo), static_cast<float>(n - clo)};
+            b0 = screen_eval(p1, p2, r1, r2, nv, cc, kguard, umin);
+            top2_push(top, b0.g, clo);
+        }
+    }
+    // first round: the best gain among one boundary candidate per thread fixes the pruning level
+    float bm = b0.g;
+#define PS_STEP(CTRL, RM) { bm = fmaxf(bm, dpp_movf<CTRL, RM>(-INFINITY, bm)); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    if (lane == 63) sh.wmaxf[wave] = bm;
+    if (threadIdx.x == 0) sh.qn = 0;
+    __syncthreads();
+    bm = sh.wmaxf[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) bm = fmaxf(bm, sh.wmaxf[w]);
+    // discard a block when its bound (+ its own rounding error) is below T0
+    const float T0 = fmaxf(thr_log2 - dthr, bm - 2.0f * dlt) - 2.0f * dlt;
+
+    if (have && !flag) {
+        int j = clo;
+        float aL = b0.lg.x, rlb = b0.r.x;                 // left quantities at the block start
+        int bp1 = p1, br1 = r1;                           // moment sums at the block start
+        unsigned bp2 = p2, br2 = r2;
+        while (j < chi) {
+            const int je = min(j + PBLK, chi);
+            if (je - j == PBLK && ((j - lo) & (PBLK - 1)) == 0) {
+                // full block on the pass-A grid: shift its sums from m0 to the side centres.
+                // sum(y-mu) = S1 - 8mu ; sum(y-mu)^2 = S2 - mu*(2*S1 - 8mu)  (exact modulo 2^32)
+                const int2 bs = mybs[(j - lo) / PBLK];
+                const int muL = cL - m0, muR = cR - m0;
+                p1 += bs.x - PBLK * muL;
+                p2 += static_cast<unsigned>(bs.y) - static_cast<unsigned>(muL) * static_cast<unsigned>(2 * bs.x - PBLK * muL);
+                r1 -= bs.x - PBLK * muR;
+                r2 -= static_cast<unsigned>(bs.y) - static_cast<unsigned>(muR) * static_cast<unsigned>(2 * bs.x - PBLK * muR);
+            } else {
+                for (int m = j; m < je; ++m) {            // partial block: sample by sample
+                    const int k = ys[m];
+                    const int zl = k - cL, zr = k - cR;
+                    p1 += zl; p2 += static_cast<unsigned>(__mul24(zl, zl));
+                    r1 -= zr; r2 -= static_cast<unsigned>(__mul24(zr, zr));
+                }
+            }
+            const f2 nv = {static_cast<float>(je), static_cast<float>(n - je)};
+            ScrOut e;
+            if (je < chi) {                               // next boundary: a candidate of this thread
+                e = screen_eval(p1, p2, r1, r2, nv, cc, kguard, umin);
+                top2_push(top, e.g, je);
+            } else if (n - je >= 1) {                     // end of the thread's range: right side only matters
+                float kg2 = INFINITY, um2 = INFINITY;
+                e = screen_eval(p1, p2, r1, r2, nv, cc, kg2, um2);
+                if (!(kg2 >= 0.0f) || !(um2 >= vfloor)) e.lg.y = -INFINITY;      // unusable: keep the block
+            } else {
+                e.lg.y = -INFINITY; e.r.y = 0.0f; e.lg.x = 0.f; e.r.x = 0.f; e.g = -INFINITY;
+            }
+            const int cnt = je - j;
+            if (cnt > 1) {
+                const float nl0f = static_cast<float>(j), nlef = static_cast<float>(je - 1);
+                const float nr0f = nf - nl0f, nref = nf - nlef;
+                const float bR = e.lg.y, rre = e.r.y;
+                const float cR0 = bR - static_cast<float>(cnt) * LOG2E * rre;          // nr - nr_e = cnt at j
+                const float cR1 = bR - LOG2E * rre;                                     // nr - nr_e = 1 at je-1
+                const float cL1 = aL - static_cast<float>(cnt - 1) * LOG2E * rlb;
+                const float h0 = -fmaf(nl0f, aL, nr0f * cR0);
+                const float h1 = -fmaf(nlef, cL1, nref * cR1);
+                const float U = fmaxf(h0, h1);
+                if (!(U < T0)) {                          // cannot be discarded: queue for full evaluation
+                    const int slot = atomicAdd(&sh.qn, 1);
+                    if (slot < QMAX) {
+                        QEnt q;
+                        q.j = j; q.jend = je; q.p1 = bp1; q.r1 = br1; q.p2 = bp2; q.r2 = br2; q.cL = cL; q.cR = cR;
+                        sh.q[slot] = q;
+                    }
+                }
+            }
+            aL = e.lg.x; rlb = e.r.x;
+            bp1 = p1; br1 = r1; bp2 = p2; br2 = r2;
+            j = je;
+        }
+    }
+    __syncthreads();
+    const int qn = sh.qn;
+    if (qn > QMAX) flag = 1;                              // bound too weak on this window: decide exactly
+    else {
+        for (int idx = threadIdx.x; idx < qn * (PBLK - 1); idx += NT) {
+            const int e = idx / (PBLK - 1), t = idx - e * (PBLK - 1) + 1;
+            const QEnt q = sh.q[e];
+            const int j = q.j + t;
+            if (j < q.jend) {
+                int q1 = q.p1, q3 = q.r1;
+                unsigned q2 = q.p2, q4 = q.r2;
+                for (int m = q.j; m < j; ++m) {
+                    const int k = ys[m];
+                    const int zl = k - q.cL, zr = k - q.cR;
+                    q1 += zl; q2 += static_cast<unsigned>(__mul24(zl, zl));
+                    q3 -= zr; q4 -= static_cast<unsigned>(__mul24(zr, zr));
+                }
+                const f2 nv = {static_cast<float>(j), static_cast<float>(n - j)};
+                const ScrOut o = screen_eval(q1, q2, q3, q4, nv, cc, kguard, umin);
+                top2_push(top, o.g, j);
+            }
+        }
+    }
+    if (!(kguard >= 0.0f) || !(umin >= vfloor)) flag = 1;
+    // workgroup top-2 + flags
+#define PS_STEP(CTRL, RM) { const float ob = dpp_movf<CTRL, RM>(-INFINITY, top.b), os = dpp_movf<CTRL, RM>(-INFINITY, top.s); \
+                            const int oi = dpp_mov<CTRL, RM>(-1, top.i); const int of = dpp_mov<CTRL, RM>(0, static_cast<int>(flag)); \
+                            top2_merge(top, ob, os, oi); flag |= static_cast<unsigned>(of); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    if (lane == 63) { sh.fbest[wave] = top.b; sh.fsecond[wave] = top.s; sh.fidx[wave] = top.i; sh.wflag[wave] = flag; }
+    __syncthreads();
+    Top2 all = {sh.fbest[0], sh.fsecond[0], sh.fidx[0]};
+    unsigned anyflag = sh.wflag[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        top2_merge(all, sh.fbest[w], sh.fsecond[w], sh.fidx[w]);
+        anyflag |= sh.wflag[w];
+    }
+    if (anyflag) return 0;
+    if (all.b < thr_log2 - dthr) { *split = -1; return 1; }
+    if (all.b > thr_log2 + dthr && all.s < all.b - 2.0f * dlt) { *split = ps + all.i; return 1; }
+    return 0;
+}
+
 // ---- one window scan: cparsers.pyx:157-178 ------------------------------------------------------
 // Window [ps, pe) of the event at `base`; candidates cand_lo..cand_hi (inclusive, event-local);
 // returns the first index whose gain strictly exceeds every earlier gain and `thresh`, or -1.
@@ -505,7 +760,8 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     const int off = static_cast<int>((reinterpret_cast<uintptr_t>(addr0) & 15u) / ES);
     const int4 *vsrc = reinterpret_cast<const int4 *>(addr0 - off * ES);
     const int nv = (n + off + EPV - 1) / EPV;          // 16-byte vectors covering the window
-    int *ysw = ys + off;                               // ysw[j] = sample j of the window
+    lds_t *ys16 = reinterpret_cast<lds_t *>(ys);
+    lds_t *ysw = ys16 + off;                           // ysw[j] = sample j of the window
     int kmin = 0x7fffffff, kmax = static_cast<int>(0x80000000);
     unsigned fracbits = 0;
     // (the previous scan's last read of ys is followed by a barrier in its reduction)
@@ -559,8 +815,9 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < EPV; e += 4)
-                    *reinterpret_cast<int4 *>(&ys[v * EPV + e]) = make_int4(k[e], k[e + 1], k[e + 2], k[e + 3]);
+                for (int e = 0; e < EPV; e += 4)        // pack to int16 (range checked below), 8 bytes per 4 samples
+                    *reinterpret_cast<int2 *>(&ys16[v * EPV + e]) =
+                        make_int2((k[e] & 0xffff) | (k[e + 1] << 16), (k[e + 2] & 0xffff) | (k[e + 3] << 16));
             }
         }
     }
@@ -584,13 +841,18 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 #pragma unroll
     for (int w = 1; w < NW; ++w) { kmin = min(kmin, sh.wmin[w]); kmax = max(kmax, sh.wmax[w]); }
     if (DT == PS_DTYPE_F32 && (kmin <= -8388608 || kmax >= 8388608)) bad |= ST_OFF_GRID;   // |count| >= 2^23
+    if (kmin < -32768 || kmax > 32767) {               // counts do not fit the int16 LDS image: exact path from HBM
+        if (threadIdx.x == 0) wk.exact += 1;
+        return scan_exact<NT, DT>(c, nullptr, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
+    }
     PS_STAMP_AT(wk, 1);                                // min/max reduce + barrier
 
     const bool want_screen = c.mode != MODE_EXACT && scores == nullptr && best_gain_out == nullptr;
     int split = -1, result;
     bool decided = false;
     if (want_screen) {
-        const int done = scan_screen<NT>(c, ysw, ps, n, cand_lo, cand_hi, thresh, kmin, kmax, sh, &split, wk);
+        const int done = c.prune ? scan_screen_pruned<NT>(c, ysw, reinterpret_cast<int2 *>(reinterpret_cast<char *>(ys) + (((c.lds_cap + 32) * 2 + 15) & ~15)), ps, n, cand_lo, cand_hi, thresh, kmin, kmax, sh, &split, wk)
+                                 : scan_screen<NT>(c, ysw, ps, n, cand_lo, cand_hi, thresh, kmin, kmax, sh, &split, wk);
         if (done && c.mode == MODE_FAST) { result = split; decided = true; }
         else if (c.mode == MODE_VERIFY) {
             result = scan_exact<NT, DT>(c, ysw, g0, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);

@@ -250,3 +250,14 @@ def test_spine_flags_and_sharded_trace_on_device(ctx):
                                          want_stats=False, want_spine=True)
         pieces.append((lo, hi, pb.cpu().numpy(), pf.cpu().numpy()))
     np.testing.assert_array_equal(stitch_pieces(pieces, n, 10000, 100), npz()["G9_rd_2M/bounds"])
+
+
+def test_counts_beyond_int16_take_the_exact_path(ctx):
+    """quantum 2^-10 turns 50 pA into 51200 counts: the window does not fit the int16 LDS image and
+    is scanned by the exact fp64 path straight from HBM -- same boundaries."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    x = synth.config2_event(5)
+    ref = oracle.parse(x, prior_segments_per_second=10.)
+    segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -10).parse(x)
+    np.testing.assert_array_equal(_bounds(segs), ref)
+    assert ctx.timings()["exact_rescans"] > 0
