@@ -25,6 +25,9 @@ PARAMS = dict(min_width=100, max_width=1000000, window_width=10000, prior_segmen
               sampling_freq=1e5)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 BYTES_PER_SAMPLE = 4       # one fp32 read per input sample
+# HBM bytes of the dominant kernel per launch from the rocprofv3 PMC pass committed under profiles/
+# (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); None until measured for this build.
+PMC_TRAFFIC_BYTES = 948420608   # spine_kernel<512,0>: 2*463000 KiB fetched + 192 KiB written (profiles/r01_final_pmc_summary.txt)
 
 
 def main():
@@ -81,7 +84,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kern = dict(spine_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, total_ms=0.0)
+    kern = dict(spine_ms=0.0, bridge_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, total_ms=0.0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -120,7 +123,7 @@ def main():
                                    "min_width=100 max_width=1e6 window_width=10000 prior_segments_per_second=10" % n,
                        "samples_per_gpu": n, "boundaries": n_bounds, "segment_stats_in_step": bool(args.stats)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": PMC_TRAFFIC_BYTES,
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
                          "kernel_ms": {k: round(v, 4) for k, v in kern.items()}},
             "whole_step_frac_of_hbm_roofline": round(BYTES_PER_SAMPLE * n / (ms_per_step * 1e-3) / HBM_PEAK, 5),

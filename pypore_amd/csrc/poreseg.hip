@@ -76,8 +76,8 @@ struct ps_ctx {
     DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
         tree_counts, items, item_pos, first_item, ev_off, bounds_off, small;
     HostBuf h_meta, h_dense, h_small, h_up;
-    hipEvent_t ev[6] = {};
-    double ms[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev[8] = {};
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t counters[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -442,6 +442,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *h_ev_off,
                       ? (f32 ? launch_spine<512, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<512, PS_DTYPE_I16>(ctx, cfg, g, sm, true))
                       : (f32 ? launch_spine<1024, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<1024, PS_DTYPE_I16>(ctx, cfg, g, sm, true));
         if (lrc) return lrc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         lrc = ctx->spine_nt == 256
                   ? (f32 ? launch_bridge<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<256, PS_DTYPE_I16>(ctx, cfg, g, sm))
                   : (f32 ? launch_bridge<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<512, PS_DTYPE_I16>(ctx, cfg, g, sm));
@@ -482,7 +483,8 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *h_ev_off,
     ctx->counters[3] = hd.n_items;
     rc = finish_batch(ctx, cfg, static_cast<size_t>(hd.n_items), hd.n_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin);
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->ms[0] = ms;
+    if (nj && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[6]) == hipSuccess) ctx->ms[0] = ms;       // spine_kernel
+    if (nj && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[1]) == hipSuccess) ctx->ms[5] = ms;       // bridge_kernel
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]) == hipSuccess) ctx->ms[4] = ms;     // device stitch incl. header sync
     return rc;
 }
@@ -876,7 +878,7 @@ int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters)
 {
     if (!ctx) return PS_ERR_ARG;
-    for (int i = 0; i < n_ms && ms; ++i) ms[i] = i < 5 ? ctx->ms[i] : 0.0;
+    for (int i = 0; i < n_ms && ms; ++i) ms[i] = i < 8 ? ctx->ms[i] : 0.0;
     for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 6 ? ctx->counters[i] : 0;
     return PS_OK;
 }

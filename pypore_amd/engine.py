@@ -43,10 +43,10 @@ class Context(object):
         _lib.check(self.L.ps_set_option(self.handle, name.encode(), int(value)), self.handle)
 
     def timings(self):
-        ms = (ctypes.c_double * 5)()
+        ms = (ctypes.c_double * 8)()
         cnt = (ctypes.c_int64 * 6)()
-        _lib.check(self.L.ps_get_timings(self.handle, ms, 5, cnt, 6))
-        return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4],
+        _lib.check(self.L.ps_get_timings(self.handle, ms, 8, cnt, 6))
+        return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4], bridge_ms=ms[5],
                     windows=cnt[0], candidates=cnt[1], tiles=cnt[2], tree_jobs=cnt[3], repairs=cnt[4],
                     exact_rescans=cnt[5])
 
