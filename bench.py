@@ -39,6 +39,10 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--stats", action="store_true", help="also run the per-segment statistics kernel in the step")
+    ap.add_argument("--workload", choices=["trace", "file"], default="trace",
+                    help="trace: one SpeedyStatSplit.parse over the whole 1e8-sample fp32 trace (default); "
+                         "file: BASELINE config 3 -- int16 .abf-shaped trace, lambda_event_parser(threshold=90) "
+                         "then per-event SpeedyStatSplit, end to end on the GPU")
     args = ap.parse_args()
 
     import torch
@@ -60,21 +64,32 @@ def main():
 
     n = args.samples
     seed = 2024 + rank                                   # rank 0's trace is golden case G7
-    d = synth.dwell_table(seed, n)
-    ends = np.cumsum(d)
-    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
-    trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
-    ev_off = np.array([0, n], dtype=np.int64)
     params = _lib.split_params(**PARAMS)
-    torch.cuda.synchronize()
-
     from pypore_amd import dist as pdist
+    if args.workload == "trace":
+        d = synth.dwell_table(seed, n)
+        ends = np.cumsum(d)
+        lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+        trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
+        ev_off = np.array([0, n], dtype=np.int64)
 
-    def step():
-        b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats)
-        if world > 1:
-            pdist.gather_varlen(b)                       # the final boundary-index gather (RCCL)
-        return b, o, st
+        def step():
+            b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats)
+            if world > 1:
+                pdist.gather_varlen(b)                   # the final boundary-index gather (RCCL)
+            return b, o, st
+    else:
+        ends, lv, _ = synth.file_trace_table(n, seed)
+        trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.int16)     # what read_abf's data section holds
+        from pypore_amd import pipeline
+
+        def step():
+            st_, ln_, b, o, stt = pipeline.segment_file_trace(trace, synth.QUANTUM, params, threshold=90.0,
+                                                              want_stats=args.stats)
+            if world > 1:
+                pdist.gather_varlen(b)
+            return b, o, stt
+    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -110,35 +125,48 @@ def main():
     value = world * n / (dt / args.steps) / 1e6
 
     if rank == 0:
+        bytes_per_sample = BYTES_PER_SAMPLE if args.workload == "trace" else 2      # int16 counts in config 3
         dom = "spine_kernel" if kern["spine_ms"] >= kern["tree_ms"] else "tree_kernel"
         dom_ms = max(kern["spine_ms"], kern["tree_ms"])
-        achieved = BYTES_PER_SAMPLE * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        achieved = bytes_per_sample * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out = {
             "metric": "Msamples/sec segmented (SpeedyStatSplit, 10^8-sample trace); %HBM roofline",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "one %.0e-sample fp32 trace per GPU (5-level step signal, dwell U[1000,20000), "
-                                   "sigma 1 pA, 2^-5 pA grid), single SpeedyStatSplit.parse over the whole trace; "
-                                   "min_width=100 max_width=1e6 window_width=10000 prior_segments_per_second=10" % n,
+            "config": {"workload": ("one %.0e-sample fp32 trace per GPU (5-level step signal, dwell U[1000,20000), "
+                                    "sigma 1 pA, 2^-5 pA grid), single SpeedyStatSplit.parse over the whole trace; "
+                                    "min_width=100 max_width=1e6 window_width=10000 prior_segments_per_second=10" % n)
+                       if args.workload == "trace" else
+                       ("BASELINE config 3: one %.0e-sample int16 .abf-shaped trace per GPU @100 kHz (110 pA open channel, "
+                        "blockade events 1.5-10 s with dwells U[1000,20000)); lambda_event_parser(threshold=90) -> "
+                        "per-event SpeedyStatSplit(prior_segments_per_second=10), end to end on the GPU" % n),
                        "samples_per_gpu": n, "boundaries": n_bounds, "segment_stats_in_step": bool(args.stats)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": PMC_TRAFFIC_BYTES,
-                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": PMC_TRAFFIC_BYTES if args.workload == "trace" else None,
+                         "algorithmic_bytes_per_launch": bytes_per_sample * n,
                          "kernel_ms": {k: round(v, 4) for k, v in kern.items()}},
-            "whole_step_frac_of_hbm_roofline": round(BYTES_PER_SAMPLE * n / (ms_per_step * 1e-3) / HBM_PEAK, 5),
+            "whole_step_frac_of_hbm_roofline": round(bytes_per_sample * n / (ms_per_step * 1e-3) / HBM_PEAK, 5),
             "work": {k: tm[k] for k in ("windows", "candidates", "tiles", "tree_jobs", "repairs", "exact_rescans")},
         }
         if not args.no_cpu:
             import oracle
             m = min(n, args.cpu_samples)
             x = trace[:m].cpu().numpy().astype(np.float64)
+            if args.workload == "file":
+                x = x * synth.QUANTUM
             t1 = time.perf_counter()
-            ref = oracle.parse(x, **{k: v for k, v in PARAMS.items()})
+            if args.workload == "file":
+                es, el = oracle.lambda_events(x, threshold=90.0)
+                refs = [oracle.parse(x[a:a + l], **{k: v for k, v in PARAMS.items()}) for a, l in zip(es, el)]
+                ref = np.concatenate(refs) if refs else np.zeros(0, np.int32)
+            else:
+                ref = oracle.parse(x, **{k: v for k, v in PARAMS.items()})
             t2 = time.perf_counter()
             got = bounds.cpu().numpy()
             # prefix property: parse(x[:m]) agrees with parse(x) away from the cut
-            k = int(np.searchsorted(ref, m - 4 * PARAMS["window_width"]))
+            k = int(np.searchsorted(ref, m - 4 * PARAMS["window_width"])) if args.workload == "trace" else \
+                int(sum(len(r) for r in refs[:-1]))
             out["cpu_baseline"] = {"value": round(m / (t2 - t1) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                                    "kind": "port",
                                    "sample": "first %d samples of rank 0's trace, oracle/statsplit_oracle.c "

@@ -129,6 +129,15 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off,
                         ps_segstat *d_stats, uint8_t *d_is_spine);
 
+/* Same as ps_segment_batch_ex for events that do NOT tile the sample array: event e is
+ * [h_ev_start[e], h_ev_start[e] + h_ev_len[e]) of d_samples (the events lambda_event_parser cuts out
+ * of a file trace, parsers.py:142-155 -> Event.parse, DataTypes.py:978-984, without copying them). */
+int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                      const int64_t *h_ev_start, const int64_t *h_ev_len, int32_t n_ev,
+                      const ps_split_params *params,
+                      int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off,
+                      ps_segstat *d_stats, uint8_t *d_is_spine);
+
 /* Upper bound on the number of breakpoints ps_segment_batch can emit for these events
  * (sum over events of len/min_width): a safe `cap`. */
 int64_t ps_bounds_capacity(const int64_t *h_ev_off, int32_t n_ev, int32_t min_width);
@@ -145,6 +154,16 @@ int ps_best_single_split(ps_ctx *ctx, const void *d_samples, const ps_sample_for
 int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
                     int64_t n, int32_t min_width, double min_gain,
                     double *d_scores, int32_t *split_out);
+
+/* Replaces lambda_event_parser(threshold).parse with the default rules (parsers.py:124-155, rules
+ * :133-135): events are the maximal runs of samples on one side of `threshold` (mask = x < threshold,
+ * cut at every mask edge) that satisfy  length > min_duration,  min > min_current,  max < threshold.
+ * Reference defaults: threshold 90, min_duration 100000, min_current -0.5.  Writes the kept events'
+ * (start, length) in samples, ascending, to the host arrays; *n_events_out is the number found
+ * (PS_ERR_CAPACITY if it exceeds cap).  Streaming kernels: two passes over the trace. */
+int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                     double threshold, int64_t min_duration, double min_current,
+                     int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out);
 
 /* Timing of the most recent ps_segment_batch, measured with HIP events on the context's
  * stream: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[3] whole

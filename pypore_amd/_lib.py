@@ -14,7 +14,7 @@ PS_ERR_CAPACITY, PS_ERR_OFF_GRID, PS_ERR_HIP, PS_ERR_NO_DEVICE, PS_ERR_INTERNAL 
 PS_DTYPE_F32, PS_DTYPE_I16 = 0, 1
 
 EXPORTS = ["ps_version", "ps_device_count", "ps_create", "ps_destroy", "ps_last_error", "ps_set_tiling", "ps_set_option",
-           "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_segment_batch_ex", "ps_bounds_capacity",
+           "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_segment_batch_ex", "ps_segment_events", "ps_detect_events", "ps_bounds_capacity",
            "ps_best_single_split", "ps_score_window", "ps_get_timings", "ps_synth_trace"]
 
 
@@ -60,6 +60,8 @@ def lib():
     L.ps_min_gain.argtypes = [P(SplitParams), P(dbl)]
     L.ps_segment_batch.argtypes = [vp, vp, P(SampleFormat), P(i64), i32, P(SplitParams), vp, i64, P(i64), vp]
     L.ps_segment_batch_ex.argtypes = [vp, vp, P(SampleFormat), P(i64), i32, P(SplitParams), vp, i64, P(i64), vp, vp]
+    L.ps_segment_events.argtypes = [vp, vp, P(SampleFormat), P(i64), P(i64), i32, P(SplitParams), vp, i64, P(i64), vp, vp]
+    L.ps_detect_events.argtypes = [vp, vp, P(SampleFormat), i64, dbl, i64, dbl, P(i64), P(i64), i64, P(i64)]
     L.ps_bounds_capacity.argtypes = [P(i64), i32, i32]
     L.ps_bounds_capacity.restype = i64
     L.ps_best_single_split.argtypes = [vp, vp, P(SampleFormat), i64, P(dbl), P(i32)]

@@ -71,6 +71,7 @@ struct ps_ctx {
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
+    DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
     HostBuf h_hdr;
     DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
@@ -319,11 +320,11 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         if (nseg > 0) {
             if (cfg.dtype == PS_DTYPE_F32)
                 hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_F32>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
-                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
+                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), n_ev, d_bounds,
                                    ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
             else
                 hipLaunchKernelGGL(segstat_kernel<PS_DTYPE_I16>, dim3(static_cast<unsigned>(nseg)), dim3(STAT_NT), 0,
-                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), n_ev, d_bounds,
+                                   ctx->stream, cfg, ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), n_ev, d_bounds,
                                    ctx->bounds_off.as<int64_t>(), d_stats, reinterpret_cast<unsigned *>(&sm->status));
             HIP_TRY(ctx, hipGetLastError());
         }
@@ -357,12 +358,12 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
 // tree jobs, items) -- the host only reads a 32-byte header between phase 1 and phase 3.
 // Returns RC_FALLBACK when a seam could not be bridged on the device (rare); the caller then runs
 // the host-stitch pipeline, which repairs seams one by one.
-int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *h_ev_off, int32_t n_ev, int mw, int W,
+int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
                         std::chrono::steady_clock::time_point t_begin)
 {
-    int64_t total_len = 0;
-    for (int e = 0; e < n_ev; ++e) total_len += h_ev_off[e + 1] - h_ev_off[e];
+    int64_t total_len = 0, sample_end = 0;
+    for (int e = 0; e < n_ev; ++e) { total_len += ev_len[e]; sample_end = std::max(sample_end, ev_start[e] + ev_len[e]); }
     int64_t L = ctx->tile_len;
     if (L <= 0) L = std::max<int64_t>(8LL * W, (total_len + 1023) / 1024);
     L = std::min<int64_t>(L, 0x7fffffff);
@@ -371,13 +372,13 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *h_ev_off,
     int64_t list_entries = 0;
     for (int e = 0; e < n_ev; ++e) {
         ev_first_tile[e] = static_cast<int64_t>(jobs.size());
-        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
+        const int64_t len = ev_len[e];
         if (len == 0) continue;
         const int64_t nt = (len + L - 1) / L;
         if (static_cast<int64_t>(jobs.size()) + nt > 0x7ffffff0) return RC_FALLBACK;
         for (int64_t t = 0; t < nt; ++t) {
             SpineJob j;
-            j.base = h_ev_off[e];
+            j.base = ev_start[e];
             j.start = static_cast<int32_t>(t * L);
             j.end = static_cast<int32_t>(len);
             j.stop = static_cast<int32_t>(t == nt - 1 ? len : (t + 1) * L);
@@ -395,9 +396,10 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *h_ev_off,
     const size_t nj = jobs.size();
     ctx->counters[2] = static_cast<int64_t>(nj);
     const int64_t max_items = list_entries + static_cast<int64_t>(nj) * BR_MAX;
-    const int64_t tscratch_bound = (n_ev ? h_ev_off[n_ev] : 0) / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
+    const int64_t tscratch_bound = sample_end / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
     const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
 
+    HIP_TRY(ctx, ctx->ev_len.reserve(evb));
     HIP_TRY(ctx, ctx->spine_jobs.reserve(std::max<size_t>(1, nj) * sizeof(SpineJob)));
     HIP_TRY(ctx, ctx->spine_scratch.reserve(std::max<int64_t>(1, list_entries) * sizeof(int2)));
     HIP_TRY(ctx, ctx->spine_meta.reserve(std::max<size_t>(4, nj) * sizeof(int4)));
@@ -422,14 +424,16 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *h_ev_off,
 
     // one upload blob: [jobs | ev_first_tile | ev_off]
     const size_t jb = nj * sizeof(SpineJob);
-    HIP_TRY(ctx, ctx->h_up.reserve(jb + 2 * evb + 64));
+    HIP_TRY(ctx, ctx->h_up.reserve(jb + 3 * evb + 64));
     char *up = ctx->h_up.as<char>();
     if (nj) std::memcpy(up, jobs.data(), jb);
     std::memcpy(up + jb, ev_first_tile.data(), evb);
-    std::memcpy(up + jb + evb, h_ev_off, evb);
+    std::memcpy(up + jb + evb, ev_start, evb - sizeof(int64_t));
+    std::memcpy(up + jb + 2 * evb, ev_len, evb - sizeof(int64_t));
     if (nj) HIP_TRY(ctx, hipMemcpyAsync(ctx->spine_jobs.p, up, jb, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_first_tile.p, up + jb, evb, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_off.p, up + jb + evb, evb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_len.p, up + jb + 2 * evb, evb, hipMemcpyHostToDevice, ctx->stream));
 
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
@@ -542,7 +546,8 @@ void ps_destroy(ps_ctx *ctx)
     DevBuf *bufs[] = {&ctx->spine_jobs, &ctx->spine_scratch, &ctx->spine_dense, &ctx->spine_meta, &ctx->tree_jobs,
                       &ctx->tree_scratch, &ctx->tree_spill, &ctx->tree_counts, &ctx->items, &ctx->item_pos,
                       &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
-                      &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile};
+                      &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
+                      &ctx->det_counts, &ctx->det_tics, &ctx->det_cand};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -623,9 +628,22 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
                         uint8_t *d_is_spine)
 {
     if (!ctx) return PS_ERR_ARG;
+    if (!h_ev_off || n_ev < 0) return fail(ctx, PS_ERR_ARG, "null/negative argument");
+    std::vector<int64_t> st(static_cast<size_t>(n_ev) + 1, 0), ln(static_cast<size_t>(n_ev) + 1, 0);
+    for (int e = 0; e < n_ev; ++e) { st[e] = h_ev_off[e]; ln[e] = h_ev_off[e + 1] - h_ev_off[e]; }
+    return ps_segment_events(ctx, d_samples, fmt, st.data(), ln.data(), n_ev, params, d_bounds, cap, h_bounds_off,
+                             d_stats, d_is_spine);
+}
+
+int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                      const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, const ps_split_params *params,
+                      int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
+                      uint8_t *d_is_spine)
+{
+    if (!ctx) return PS_ERR_ARG;
     ctx->d_is_spine = d_is_spine;
     const auto t_begin = std::chrono::steady_clock::now();
-    if (!h_ev_off || !params || !h_bounds_off || n_ev < 0 || cap < 0 || (cap > 0 && !d_bounds))
+    if (!ev_start || !ev_len || !params || !h_bounds_off || n_ev < 0 || cap < 0 || (cap > 0 && !d_bounds))
         return fail(ctx, PS_ERR_ARG, "null/negative argument");
     double min_gain = 0;
     int rc = ps_min_gain(params, &min_gain);
@@ -633,11 +651,15 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
     const int mw = params->min_width, maxw = params->max_width, W = params->window_width;
     if (mw < 1 || W < 2) return fail(ctx, PS_ERR_ARG, "min_width must be >= 1 and window_width >= 2");
     for (int e = 0; e < n_ev; ++e) {
-        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
-        if (len < 0 || len > 0x7fffffff - 2LL * W - 8)
+        const int64_t len = ev_len[e];
+        if (len < 0 || ev_start[e] < 0 || len > 0x7fffffff - 2LL * W - 8)
             return fail(ctx, PS_ERR_ARG, "event %d length %lld out of range", e, static_cast<long long>(len));
     }
-    if (n_ev > 0 && !d_samples && h_ev_off[n_ev] > h_ev_off[0]) return fail(ctx, PS_ERR_ARG, "d_samples is NULL");
+    {
+        int64_t tl = 0;
+        for (int e = 0; e < n_ev; ++e) tl += ev_len[e];
+        if (tl > 0 && !d_samples) return fail(ctx, PS_ERR_ARG, "d_samples is NULL");
+    }
     DevCfg cfg;
     rc = make_cfg(ctx, d_samples, fmt, mw, maxw, W, min_gain, &cfg);
     if (rc) return rc;
@@ -647,7 +669,7 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
 
     if (!ctx->stitch_host) {
-        rc = device_stitch_batch(ctx, cfg, h_ev_off, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+        rc = device_stitch_batch(ctx, cfg, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
         if (rc != RC_FALLBACK) return rc;
         // a seam could not be bridged on the device: redo with the host stitch (halo tiles + repairs)
         for (double &m : ctx->ms) m = 0;
@@ -661,7 +683,7 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
     // (2 workgroups of 512 threads per CU on 256 CUs) so the grid runs as a single wave of blocks,
     // but never shorter than 8 windows (the halo is pure overhead).
     int64_t total_len = 0;
-    for (int e = 0; e < n_ev; ++e) total_len += h_ev_off[e + 1] - h_ev_off[e];
+    for (int e = 0; e < n_ev; ++e) total_len += ev_len[e];
     const int64_t H = ctx->halo > 0 ? ctx->halo : 4LL * W;
     int64_t L = ctx->tile_len;
     if (L <= 0) {
@@ -673,12 +695,12 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
     int64_t scratch = 0;
     for (int e = 0; e < n_ev; ++e) {
         ev_first_tile[e] = static_cast<int64_t>(jobs.size());
-        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
+        const int64_t len = ev_len[e];
         if (len == 0) continue;
         const int64_t nt = len <= L + H ? 1 : (len + L - 1) / L;
         for (int64_t t = 0; t < nt; ++t) {
             SpineJob j;
-            j.base = h_ev_off[e];
+            j.base = ev_start[e];
             j.start = static_cast<int32_t>(t * L);
             j.end = static_cast<int32_t>(len);
             const int64_t stop = (t == nt - 1) ? len : std::min(len, (t + 1) * L + H);
@@ -706,7 +728,7 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
     int64_t tscratch = 0;
     for (int e = 0; e < n_ev; ++e) {
         first_item[e] = static_cast<int64_t>(items.size());
-        const int64_t len = h_ev_off[e + 1] - h_ev_off[e];
+        const int64_t len = ev_len[e];
         const int64_t t0 = ev_first_tile[e], t1 = ev_first_tile[e + 1];
         if (t0 == t1) continue;
         int64_t cur = t0;
@@ -720,7 +742,7 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
                 // continue it from its last (true) anchor -- "seam repair"
                 const int32_t z = Lc.a.empty() ? Lc.start : Lc.a.back().pos;
                 std::vector<SpineJob> rj(1);
-                rj[0].base = h_ev_off[e];
+                rj[0].base = ev_start[e];
                 rj[0].start = z;
                 rj[0].end = static_cast<int32_t>(len);
                 const int64_t stop = std::min<int64_t>(len, static_cast<int64_t>(z) + L + H);
@@ -746,7 +768,7 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
             it.job = -1;
             if (an.kind == KIND_HIT || an.kind == KIND_LATE) {
                 TreeJob tj;
-                tj.base = h_ev_off[e];
+                tj.base = ev_start[e];
                 tj.start = prev;
                 tj.end = an.pos;
                 const int64_t d = static_cast<int64_t>(an.pos) - W - prev;
@@ -779,7 +801,7 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
 
     // ---- upload jobs/items, phase 3, gather ------------------------------------------------------
     const size_t up_bytes = n_tj * sizeof(TreeJob) + static_cast<size_t>(n_items) * sizeof(Item) +
-                            (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t) * 2;
+                            (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t) * 3;
     HIP_TRY(ctx, ctx->h_up.reserve(up_bytes + 64));
     HIP_TRY(ctx, ctx->tree_jobs.reserve(std::max<size_t>(1, n_tj) * sizeof(TreeJob)));
     HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<size_t>(1, n_tj) * sizeof(int32_t)));
@@ -789,6 +811,7 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
     HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(n_items) + 1) * sizeof(int64_t)));
     HIP_TRY(ctx, ctx->first_item.reserve((static_cast<size_t>(n_ev) + 1) * sizeof(int64_t)));
     HIP_TRY(ctx, ctx->ev_off.reserve((static_cast<size_t>(n_ev) + 1) * sizeof(int64_t)));
+    HIP_TRY(ctx, ctx->ev_len.reserve((static_cast<size_t>(n_ev) + 1) * sizeof(int64_t)));
     HIP_TRY(ctx, ctx->bounds_off.reserve((static_cast<size_t>(n_ev) + 1) * sizeof(int64_t)));
     char *up = ctx->h_up.as<char>();
     size_t o = 0;
@@ -807,8 +830,11 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
     std::memcpy(up + o, first_item.data(), evb);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->first_item.p, up + o, evb, hipMemcpyHostToDevice, ctx->stream));
     o += evb;
-    std::memcpy(up + o, h_ev_off, evb);
+    std::memcpy(up + o, ev_start, evb - sizeof(int64_t));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_off.p, up + o, evb, hipMemcpyHostToDevice, ctx->stream));
+    o += evb;
+    std::memcpy(up + o, ev_len, evb - sizeof(int64_t));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_len.p, up + o, evb, hipMemcpyHostToDevice, ctx->stream));
 
     return finish_batch(ctx, cfg, n_tj, n_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin);
 }
@@ -873,6 +899,80 @@ int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *
     if (min_width < 1) return fail(ctx, PS_ERR_ARG, "min_width must be >= 1");
     double g;
     return single_scan(ctx, d_samples, fmt, n, 0, min_width, min_gain, d_scores, &g, split_out);
+}
+
+
+// Replaces lambda_event_parser.parse with the default rules (parsers.py:124-155).
+int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                     double threshold, int64_t min_duration, double min_current,
+                     int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!n_events_out || n < 0 || n > 0x7fffffff || cap < 0 || (cap > 0 && (!h_starts || !h_lengths)))
+        return fail(ctx, PS_ERR_ARG, "bad argument");
+    *n_events_out = 0;
+    if (n == 0) return PS_OK;
+    if (!d_samples) return fail(ctx, PS_ERR_ARG, "d_samples is NULL");
+    DevCfg cfg;
+    int rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int nb = static_cast<int>((n + DET_CHUNK - 1) / DET_CHUNK);
+    const unsigned cand_cap = static_cast<unsigned>(std::min<int64_t>(n / std::max<int64_t>(1, min_duration) + 2, 0x7fffffff));
+    HIP_TRY(ctx, ctx->det_counts.reserve(static_cast<size_t>(nb) * sizeof(int) + (static_cast<size_t>(nb) + 1) * sizeof(long long) + 64));
+    HIP_TRY(ctx, ctx->det_cand.reserve(static_cast<size_t>(cand_cap) * sizeof(int2) * 2 + 64));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    int *d_counts = ctx->det_counts.as<int>();
+    long long *d_offs = reinterpret_cast<long long *>(ctx->det_counts.as<char>() + ((static_cast<size_t>(nb) * sizeof(int) + 15) & ~static_cast<size_t>(15)));
+    const bool f32 = cfg.dtype == PS_DTYPE_F32;
+    if (f32) hipLaunchKernelGGL((edge_kernel<PS_DTYPE_F32, false>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, d_counts, nullptr, nullptr);
+    else     hipLaunchKernelGGL((edge_kernel<PS_DTYPE_I16, false>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, d_counts, nullptr, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_counts, nb, d_offs);
+    HIP_TRY(ctx, hipGetLastError());
+    long long n_edges = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, d_offs + nb, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    n_edges = *ctx->h_small.as<long long>();
+    HIP_TRY(ctx, ctx->det_tics.reserve(static_cast<size_t>(std::max<long long>(1, n_edges)) * sizeof(int)));
+    if (n_edges) {
+        if (f32) hipLaunchKernelGGL((edge_kernel<PS_DTYPE_F32, true>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, nullptr, d_offs, ctx->det_tics.as<int>());
+        else     hipLaunchKernelGGL((edge_kernel<PS_DTYPE_I16, true>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, nullptr, d_offs, ctx->det_tics.as<int>());
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    int2 *d_cand = ctx->det_cand.as<int2>();
+    int2 *d_mm = d_cand + cand_cap;
+    unsigned *d_ncand = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->dense);
+    HIP_TRY(ctx, hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), ctx->stream));
+    const long long np = n_edges + 1;
+    hipLaunchKernelGGL(piece_filter_kernel, dim3(static_cast<unsigned>((np + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->det_tics.as<int>(), n_edges, n, min_duration, d_cand, d_ncand, cand_cap);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, d_ncand, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned nc = std::min(*ctx->h_small.as<unsigned>(), cand_cap);
+    if (nc == 0) return PS_OK;
+    if (f32) hipLaunchKernelGGL((piece_minmax_kernel<PS_DTYPE_F32>), dim3(nc), dim3(256), 0, ctx->stream, cfg, d_cand, d_mm);
+    else     hipLaunchKernelGGL((piece_minmax_kernel<PS_DTYPE_I16>), dim3(nc), dim3(256), 0, ctx->stream, cfg, d_cand, d_mm);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, ctx->h_dense.reserve(static_cast<size_t>(nc) * sizeof(int2) * 2));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.p, d_cand, static_cast<size_t>(nc) * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.as<int2>() + nc, d_mm, static_cast<size_t>(nc) * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int2 *hc = ctx->h_dense.as<int2>(), *hm = hc + nc;
+    std::vector<std::pair<int, int>> ev;                       // (start, index)
+    for (unsigned i = 0; i < nc; ++i) {
+        const double mn = (static_cast<double>(hm[i].x)) * cfg.q, mx = (static_cast<double>(hm[i].y)) * cfg.q;
+        if (mn > min_current && mx < threshold) ev.emplace_back(hc[i].x, static_cast<int>(i));   // parsers.py:133-135
+    }
+    std::sort(ev.begin(), ev.end());
+    *n_events_out = static_cast<int64_t>(ev.size());
+    if (static_cast<int64_t>(ev.size()) > cap) return fail(ctx, PS_ERR_CAPACITY, "event capacity %lld < %zu", static_cast<long long>(cap), ev.size());
+    for (size_t i = 0; i < ev.size(); ++i) {
+        h_starts[i] = hc[ev[i].second].x;
+        h_lengths[i] = hc[ev[i].second].y - hc[ev[i].second].x;
+    }
+    return PS_OK;
 }
 
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters)

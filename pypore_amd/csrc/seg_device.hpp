@@ -1346,12 +1346,121 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     counts[i] = 0;
 }
 
+
+// ---- K3: threshold event detector, parsers.py:124-155 ---------------------------------------------
+// mask[i] = x[i] < threshold; an edge sits at i (>= 1) when mask[i] != mask[i-1]; pieces lie between
+// consecutive edges.  Three streaming kernels: edges per 4096-sample chunk, (scan), edge positions.
+constexpr int DET_NT = 256;
+constexpr int DET_PER = 16;                         // samples per thread
+constexpr int DET_CHUNK = DET_NT * DET_PER;
+
+template <int DT>
+__device__ __forceinline__ bool below_thr(const DevCfg &c, int64_t i, double thr)
+{
+    if (DT == PS_DTYPE_F32) return static_cast<double>(static_cast<const float *>(c.samples)[i]) < thr;
+    return static_cast<double>(static_cast<int>(static_cast<const int16_t *>(c.samples)[i]) + c.off_counts) * c.q < thr;
+}
+
+// WRITE = false: counts[b] = edges in chunk b.  WRITE = true: tics[offs[b] + rank] = edge positions.
+template <int DT, bool WRITE>
+__global__ __launch_bounds__(DET_NT) void edge_kernel(DevCfg c, int64_t n, double thr, int *counts,
+                                                      const long long *offs, int *tics)
+{
+    __shared__ int wsum[DET_NT / 64];
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * DET_CHUNK + static_cast<int64_t>(threadIdx.x) * DET_PER;
+    unsigned bits = 0;                                // bit u: edge at i0 + u
+    if (i0 < n) {
+        bool prev = i0 > 0 ? below_thr<DT>(c, i0 - 1, thr) : false;
+#pragma unroll
+        for (int u = 0; u < DET_PER; ++u) {
+            const int64_t i = i0 + u;
+            if (i < n) {
+                const bool m = below_thr<DT>(c, i, thr);
+                if (i > 0 && m != prev) bits |= 1u << u;
+                prev = m;
+            }
+        }
+    }
+    const int cnt = __popc(bits);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < DET_NT / 64; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
+    if (!WRITE) {
+        if (threadIdx.x == 0) counts[blockIdx.x] = total;
+    } else {
+        long long o = offs[blockIdx.x] + base + inc - cnt;
+        for (int u = 0; u < DET_PER; ++u)
+            if (bits & (1u << u)) tics[o++] = static_cast<int>(i0 + u);
+    }
+}
+
+// exclusive scan of int counts -> long long offsets[nb + 1] (one workgroup)
+__global__ __launch_bounds__(1024) void count_scan_kernel(const int *counts, int nb, long long *offs)
+{
+    __shared__ long long wsum[32];
+    __shared__ long long carry[2];
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        long long e1, e2;
+        chunk_exscan2(b < nb ? counts[b] : 0, 0, e1, e2, wsum, carry);
+        if (b < nb) offs[b] = e1;
+    }
+    if (threadIdx.x == 0) offs[nb] = carry[0];
+}
+
+// pieces longer than min_duration -> candidate list (start, end), unordered
+__global__ void piece_filter_kernel(const int *tics, long long n_edges, int64_t n, int64_t min_duration,
+                                    int2 *cand, unsigned *n_cand, unsigned cap)
+{
+    const long long p = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (p > n_edges) return;
+    const int a = p == 0 ? 0 : tics[p - 1];
+    const int b = p == n_edges ? static_cast<int>(n) : tics[p];
+    if (static_cast<int64_t>(b) - a > min_duration) {
+        const unsigned slot = atomicAdd(n_cand, 1u);
+        if (slot < cap) cand[slot] = make_int2(a, b);
+    }
+}
+
+// min / max (in counts) of every candidate piece, one workgroup each
+template <int DT>
+__global__ __launch_bounds__(256) void piece_minmax_kernel(DevCfg c, const int2 *cand, int2 *mm)
+{
+    __shared__ int smin[4], smax[4];
+    const int2 pc = cand[blockIdx.x];
+    int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);
+    unsigned bad = 0;
+    for (int64_t i = pc.x + threadIdx.x; i < pc.y; i += 256) {
+        const int k = load_count<DT>(c, i, bad);
+        mn = min(mn, k); mx = max(mx, k);
+    }
+    wave_minmax(mn, mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) { smin[wave] = mn; smax[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mn = min(smin[0] = min(smin[0], smin[w]), mn); mx = max(smax[0] = max(smax[0], smax[w]), mx); }
+        mm[blockIdx.x] = make_int2(smin[0], smax[0]);
+    }
+}
+
 // ---- K2: per-segment statistics, core.py:209-223 ------------------------------------------------
 // One workgroup per segment.  Sums of counts and counts^2 are exact (fp64 holds the integers),
 // mean = q*S1/n, std = q*sqrt(S2/n - (S1/n)^2) (population), min/max exact.
 constexpr int STAT_NT = 256;
 template <int DT>
-__global__ __launch_bounds__(STAT_NT) void segstat_kernel(DevCfg c, const int64_t *ev_off, int32_t n_ev,
+__global__ __launch_bounds__(STAT_NT) void segstat_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev,
                                                           const int32_t *bounds, const int64_t *bounds_off,
                                                           ps_segstat *stats, unsigned *status)
 {
@@ -1369,10 +1478,10 @@ __global__ __launch_bounds__(STAT_NT) void segstat_kernel(DevCfg c, const int64_
     const int64_t boff = bounds_off[e];
     const int cnt = static_cast<int>(bounds_off[e + 1] - boff);
     const int s = static_cast<int>(g - boff - e);
-    const int n_e = static_cast<int>(ev_off[e + 1] - ev_off[e]);
+    const int n_e = static_cast<int>(ev_len[e]);
     const int a = s == 0 ? 0 : bounds[boff + s - 1];
     const int b = s == cnt ? n_e : bounds[boff + s];
-    const int64_t g0 = ev_off[e];
+    const int64_t g0 = ev_start[e];
     unsigned bad = 0;
     double s1 = 0, s2 = 0;
     int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);

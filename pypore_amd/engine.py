@@ -88,6 +88,55 @@ class Context(object):
             return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None), spine[:total]
         return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None)
 
+    def _fmt(self, samples, quantum, offset_counts):
+        if samples.dtype == torch.float32:
+            return _lib.SampleFormat(_lib.PS_DTYPE_F32, int(offset_counts), float(quantum))
+        if samples.dtype == torch.int16:
+            return _lib.SampleFormat(_lib.PS_DTYPE_I16, int(offset_counts), float(quantum))
+        raise ValueError("samples must be float32 or int16, got %s" % samples.dtype)
+
+    def detect_events(self, samples, quantum, threshold=90.0, min_duration=100000, min_current=-0.5,
+                      offset_counts=0):
+        """ps_detect_events on a device-resident trace: (starts, lengths) int64 numpy arrays of the
+        events lambda_event_parser(threshold) keeps with its default rules (parsers.py:124-155)."""
+        assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
+        fmt = self._fmt(samples, quantum, offset_counts)
+        n = samples.numel()
+        cap = n // max(1, int(min_duration)) + 2
+        st = np.zeros(cap, dtype=np.int64)
+        ln = np.zeros(cap, dtype=np.int64)
+        cnt = ctypes.c_int64()
+        torch.cuda.current_stream(samples.device).synchronize()
+        P64 = ctypes.POINTER(ctypes.c_int64)
+        _lib.check(self.L.ps_detect_events(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), n,
+                                           float(threshold), int(min_duration), float(min_current),
+                                           st.ctypes.data_as(P64), ln.ctypes.data_as(P64), cap, ctypes.byref(cnt)),
+                   self.handle)
+        return st[:cnt.value].copy(), ln[:cnt.value].copy()
+
+    def segment_events(self, samples, ev_start, ev_len, params, quantum, offset_counts=0, want_stats=False):
+        """ps_segment_events: events are sub-ranges [start, start+len) of one device-resident trace."""
+        assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
+        fmt = self._fmt(samples, quantum, offset_counts)
+        ev_start = np.ascontiguousarray(ev_start, dtype=np.int64)
+        ev_len = np.ascontiguousarray(ev_len, dtype=np.int64)
+        n_ev = ev_start.size
+        cap = int(np.sum(ev_len // int(params.min_width) + 1)) if n_ev else 0
+        dev = samples.device
+        bounds = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        stats = torch.empty((max(cap, 1) + n_ev, 4), dtype=torch.float64, device=dev) if want_stats else None
+        boff = np.zeros(n_ev + 1, dtype=np.int64)
+        P64 = ctypes.POINTER(ctypes.c_int64)
+        torch.cuda.current_stream(dev).synchronize()
+        _lib.check(self.L.ps_segment_events(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt),
+                                            ev_start.ctypes.data_as(P64), ev_len.ctypes.data_as(P64), n_ev,
+                                            ctypes.byref(params), ctypes.c_void_p(bounds.data_ptr()), cap,
+                                            boff.ctypes.data_as(P64),
+                                            ctypes.c_void_p(stats.data_ptr()) if want_stats else None, None),
+                   self.handle)
+        total = int(boff[-1])
+        return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None)
+
     def best_single_split(self, samples, quantum, offset_counts=0):
         fmt = _lib.SampleFormat(_lib.PS_DTYPE_F32 if samples.dtype == torch.float32 else _lib.PS_DTYPE_I16,
                                 int(offset_counts), float(quantum))

@@ -73,14 +73,33 @@ class lambda_event_parser(parser):
 
     def __init__(self, threshold=90, rules=None):
         self.threshold = threshold
-        self.rules = rules or [lambda event: event.duration > 100000,
-                               lambda event: event.min > -0.5,
-                               lambda event: event.max < self.threshold]
+        self._rules0 = [lambda event: event.duration > 100000,
+                        lambda event: event.min > -0.5,
+                        lambda event: event.max < self.threshold]
+        self.rules = rules or self._rules0
 
     def _lambda_select(self, events):
         return [event for event in events if np.all([rule(event) for rule in self.rules])]
 
-    def parse(self, current):
+    def _default_rules(self):
+        return self.rules is self._rules0
+
+    def parse(self, current, quantum=None, device=None):
+        """With the default rules the detection runs on the GPU (ps_detect_events: mask, edges, pieces,
+        per-piece min/max); custom rule lambdas need the pieces on the host and take the numpy route of
+        the reference.  Either way the result is the reference's: one Segment per kept piece, `current` a
+        copy, start/duration in samples."""
+        if self._default_rules():
+            from . import engine
+            host = np.asarray(current) if not hasattr(current, "is_cuda") else None
+            t, q = engine.to_device_samples(current, quantum, device)
+            st, ln = engine.context(device).detect_events(t, q, threshold=float(self.threshold))
+            if host is None:                        # device tensor in: fetch the kept pieces' values once
+                host = t.cpu().numpy().astype(np.float64)
+                if not t.dtype.is_floating_point:
+                    host = host * q
+            return [Segment(current=np.array(host[s:s + n]), copy=True, start=s, duration=n)
+                    for s, n in zip(st.tolist(), ln.tolist())]
         current = np.asarray(current)
         mask = np.where(current < self.threshold, 1, 0)
         mask = np.abs(np.diff(mask))

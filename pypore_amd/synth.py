@@ -96,6 +96,33 @@ def config2_event(ev, n=50000, dwell=10000, dtype=np.float64):
     return counts_to_pa(step_counts(n, dwell, ev), dtype)
 
 
+def file_trace_table(n, seed, gap=50000, ev_lo=150000, ev_hi=1000000, lo=1000, hi=20000):
+    """Segment table (exclusive ends, level counts) of the config-3 trace of file_trace_counts, for the
+    device generator (ps_synth_trace), plus the list of (start, length) of the blockade events."""
+    seg_end, level, events = [], [], []
+    pos = 0
+    k = 0
+    base = np.uint64(seed) ^ np.uint64(0xA0761D6478BD642F)
+    while pos < n:
+        g = min(gap, n - pos)
+        pos += g
+        seg_end.append(pos); level.append(OPEN_COUNTS)
+        if pos >= n:
+            break
+        with np.errstate(over="ignore"):
+            ln = int(splitmix64(base + np.uint64(k + 1) * GOLDEN) % np.uint64(ev_hi - ev_lo)) + ev_lo
+        k += 1
+        ln = min(ln, n - pos)
+        d = dwell_table(seed + 7919 * k, ln, lo, hi)
+        ends = np.minimum(np.cumsum(d), ln)
+        lv = LEVEL_COUNTS[(np.arange(len(d)) + k) % 5]
+        seg_end.extend((pos + ends).tolist()); level.extend(lv.tolist())
+        if pos + ln < n:
+            events.append((pos, ln))
+        pos += ln
+    return np.array(seg_end, dtype=np.int64), np.array(level, dtype=np.int32), events
+
+
 def file_trace_counts(n, seed, gap=50000, ev_lo=150000, ev_hi=1000000, lo=1000, hi=20000):
     """BASELINE config 3 trace: open channel (110 pA) for `gap` samples between events,
     events ev_lo..ev_hi samples long with interior dwells U[lo,hi).  Returns (counts int32,

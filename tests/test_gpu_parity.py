@@ -194,7 +194,7 @@ def test_event_parse_call_contract(ctx):
     z = npz()
     x = z["G6_events/input"].astype(np.float64) * synth.QUANTUM
     f = File(current=x, timestep=0.01)                       # 100 kHz
-    f.parse(parser=lambda_event_parser(threshold=90))
+    f.parse(parser=lambda_event_parser(threshold=90))          # default rules: detection on the GPU
     assert [int(round(e.start * f.second)) for e in f.events] == list(z["G6_events/starts"])
     for k, ev in enumerate(f.events):
         ev.parse(parser=SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM))
@@ -261,3 +261,45 @@ def test_counts_beyond_int16_take_the_exact_path(ctx):
     segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -10).parse(x)
     np.testing.assert_array_equal(_bounds(segs), ref)
     assert ctx.timings()["exact_rescans"] > 0
+
+
+def test_event_detector_kernel_matches_reference_parsers_py(ctx):
+    """K3: ps_detect_events against the events the reference's own lambda_event_parser found (G6) and
+    against the oracle on a longer file-shaped trace; fp32 and int16 inputs."""
+    import torch
+    z = npz()
+    counts = z["G6_events/input"]
+    for t, q in ((torch.from_numpy(synth.counts_to_pa(counts, np.float32)).cuda(), synth.QUANTUM),
+                 (torch.from_numpy(counts.astype(np.int16)).cuda(), synth.QUANTUM)):
+        st, ln = ctx.detect_events(t, q, threshold=90.0)
+        np.testing.assert_array_equal(st, z["G6_events/starts"])
+        np.testing.assert_array_equal(ln, z["G6_events/lengths"])
+    c2, evs = synth.file_trace_counts(3_000_000, 5)
+    x = synth.counts_to_pa(c2, np.float64)
+    rs, rl = oracle.lambda_events(x, threshold=90.0)
+    st, ln = ctx.detect_events(torch.from_numpy(c2.astype(np.int16)).cuda(), synth.QUANTUM)
+    np.testing.assert_array_equal(st, rs)
+    np.testing.assert_array_equal(ln, rl)
+    assert len(st) >= 3
+
+
+def test_config3_file_pipeline_on_device(ctx, tmp_path):
+    """BASELINE config 3 shape (reduced size): synthetic .abf -> events -> per-event SpeedyStatSplit,
+    all on the GPU from the raw int16 counts, against the reference-shaped CPU route (oracle)."""
+    from pypore_amd import abf, pipeline
+    from pypore_amd.parsers import lambda_event_parser
+    c, _ = synth.file_trace_counts(2_500_000, 9)
+    path = str(tmp_path / "synthetic.abf")
+    abf.write_abf(path, c.astype(np.int16))
+    dt, x = abf.read_abf(path)
+    assert dt == 0.01 and np.array_equal(x, synth.counts_to_pa(c, np.float64))
+    dt2, st, ln, bl = pipeline.parse_abf(path)
+    rs, rl = oracle.lambda_events(x, threshold=90.0)
+    np.testing.assert_array_equal(st, rs)
+    np.testing.assert_array_equal(ln, rl)
+    for e in range(len(st)):
+        ref = oracle.parse(x[st[e]:st[e] + ln[e]], prior_segments_per_second=10.)
+        np.testing.assert_array_equal(bl[e], ref)
+    # the drop-in class route gives the same events
+    evs = lambda_event_parser(threshold=90).parse(x, quantum=synth.QUANTUM)
+    assert [int(e.start) for e in evs] == list(rs) and [int(e.duration) for e in evs] == list(rl)

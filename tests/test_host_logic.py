@@ -87,7 +87,10 @@ def test_lambda_event_parser_matches_oracle_and_golden():
     from pypore_amd.parsers import lambda_event_parser
     z = npz()
     x = z["G6_events/input"].astype(np.float64) * synth.QUANTUM
-    evs = lambda_event_parser(threshold=90).parse(x)
+    # explicit rules (equal to the defaults) take the host route of the reference; the default-rule
+    # object runs on the GPU (tests/test_gpu_parity.py)
+    rules = [lambda event: event.duration > 100000, lambda event: event.min > -0.5, lambda event: event.max < 90]
+    evs = lambda_event_parser(threshold=90, rules=rules).parse(x)
     assert [int(e.start) for e in evs] == list(z["G6_events/starts"])
     assert [int(e.duration) for e in evs] == list(z["G6_events/lengths"])
 
@@ -109,3 +112,26 @@ def test_synth_generators_are_stable():
     assert hashlib.sha256(c.astype(np.int32).tobytes()).hexdigest() == \
         hashlib.sha256(synth.random_dwell_counts(100000, 2024).astype(np.int32).tobytes()).hexdigest()
     assert abs(float(np.std(synth.noise_counts(9, 0, 200000))) - 32.0) < 0.2
+
+
+def test_abf_writer_reader_round_trip(tmp_path):
+    from pypore_amd import abf
+    c = synth.step_counts(20000, 3000, 4).astype(np.int16)
+    p = str(tmp_path / "a.abf")
+    abf.write_abf(p, c)
+    dt, x = abf.read_abf(p)
+    assert dt == 0.01                                    # fADCSequenceInterval 10 us (read_abf.py:155)
+    np.testing.assert_array_equal(x, c.astype(np.float64) * 2.0 ** -5)
+    dt, k, scale, off = abf.read_abf_counts(p)
+    assert scale == 2.0 ** -5 and off == 0.0 and np.array_equal(np.asarray(k), c)
+    # a realistic non-power-of-two scale with offsets: same arithmetic as read_abf.py:202-205
+    abf.write_abf(p, c, adc_range=10.0, adc_resolution=32768, instrument_scale=0.01, instrument_offset=0.25,
+                  signal_offset=0.125)
+    _, x2 = abf.read_abf(p)
+    f32 = np.float32
+    scale = float(f32(10.0)) / float(f32(0.01)) / 1.0 / 1.0 / 32768
+    np.testing.assert_array_equal(x2, c.astype(np.float64) * scale + 0.125)
+    with open(p, "r+b") as fh:
+        fh.write(b"XXXX")
+    with pytest.raises(ValueError):
+        abf.read_abf(p)
