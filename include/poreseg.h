@@ -160,7 +160,8 @@ int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *
  * cut at every mask edge) that satisfy  length > min_duration,  min > min_current,  max < threshold.
  * Reference defaults: threshold 90, min_duration 100000, min_current -0.5.  Writes the kept events'
  * (start, length) in samples, ascending, to the host arrays; *n_events_out is the number found
- * (PS_ERR_CAPACITY if it exceeds cap).  Streaming kernels: two passes over the trace. */
+ * (PS_ERR_CAPACITY if it exceeds cap).  One streaming pass over the trace (edge positions + per-chunk
+ * min/max), then one workgroup per long piece. */
 int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
                      double threshold, int64_t min_duration, double min_current,
                      int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out);

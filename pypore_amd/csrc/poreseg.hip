@@ -918,60 +918,72 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int nb = static_cast<int>((n + DET_CHUNK - 1) / DET_CHUNK);
-    const unsigned cand_cap = static_cast<unsigned>(std::min<int64_t>(n / std::max<int64_t>(1, min_duration) + 2, 0x7fffffff));
-    HIP_TRY(ctx, ctx->det_counts.reserve(static_cast<size_t>(nb) * sizeof(int) + (static_cast<size_t>(nb) + 1) * sizeof(long long) + 64));
-    HIP_TRY(ctx, ctx->det_cand.reserve(static_cast<size_t>(cand_cap) * sizeof(int2) * 2 + 64));
-    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
-    int *d_counts = ctx->det_counts.as<int>();
-    long long *d_offs = reinterpret_cast<long long *>(ctx->det_counts.as<char>() + ((static_cast<size_t>(nb) * sizeof(int) + 15) & ~static_cast<size_t>(15)));
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
-    if (f32) hipLaunchKernelGGL((edge_kernel<PS_DTYPE_F32, false>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, d_counts, nullptr, nullptr);
-    else     hipLaunchKernelGGL((edge_kernel<PS_DTYPE_I16, false>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, d_counts, nullptr, nullptr);
-    HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_counts, nb, d_offs);
-    HIP_TRY(ctx, hipGetLastError());
-    long long n_edges = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, d_offs + nb, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    n_edges = *ctx->h_small.as<long long>();
-    HIP_TRY(ctx, ctx->det_tics.reserve(static_cast<size_t>(std::max<long long>(1, n_edges)) * sizeof(int)));
-    if (n_edges) {
-        if (f32) hipLaunchKernelGGL((edge_kernel<PS_DTYPE_F32, true>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, nullptr, d_offs, ctx->det_tics.as<int>());
-        else     hipLaunchKernelGGL((edge_kernel<PS_DTYPE_I16, true>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold, nullptr, d_offs, ctx->det_tics.as<int>());
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    unsigned *d_ntics = reinterpret_cast<unsigned *>(&sm->dense);
+    HIP_TRY(ctx, ctx->det_counts.reserve(static_cast<size_t>(nb) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    size_t tics_cap = std::max<size_t>(ctx->det_tics.cap / sizeof(int), 1u << 16);
+    std::vector<int> tics;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(ctx, ctx->det_tics.reserve(tics_cap * sizeof(int)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+        if (f32) hipLaunchKernelGGL((edge_scan_kernel<PS_DTYPE_F32>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold,
+                                    ctx->det_tics.as<int>(), d_ntics, static_cast<unsigned>(tics_cap), ctx->det_counts.as<int2>(),
+                                    reinterpret_cast<unsigned *>(&sm->status));
+        else     hipLaunchKernelGGL((edge_scan_kernel<PS_DTYPE_I16>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold,
+                                    ctx->det_tics.as<int>(), d_ntics, static_cast<unsigned>(tics_cap), ctx->det_counts.as<int2>(),
+                                    reinterpret_cast<unsigned *>(&sm->status));
         HIP_TRY(ctx, hipGetLastError());
+        // speculative copy of the first edges together with the count: one sync in the common case
+        const size_t spec = std::min<size_t>(tics_cap, 4096);
+        HIP_TRY(ctx, ctx->h_dense.reserve(std::max(spec, static_cast<size_t>(1)) * sizeof(int)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.p, ctx->det_tics.p, spec * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+        rc = check_status(ctx, static_cast<unsigned>(hs.status));
+        if (rc) return rc;
+        const size_t ne = static_cast<unsigned>(hs.dense);
+        if (ne > tics_cap) { tics_cap = ne + 1024; continue; }          // list overflowed: rerun with room for all edges
+        tics.resize(ne);
+        if (ne <= spec) std::memcpy(tics.data(), ctx->h_dense.p, ne * sizeof(int));
+        else HIP_TRY(ctx, hipMemcpy(tics.data(), ctx->det_tics.p, ne * sizeof(int), hipMemcpyDeviceToHost));
+        break;
     }
-    int2 *d_cand = ctx->det_cand.as<int2>();
-    int2 *d_mm = d_cand + cand_cap;
-    unsigned *d_ncand = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->dense);
-    HIP_TRY(ctx, hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), ctx->stream));
-    const long long np = n_edges + 1;
-    hipLaunchKernelGGL(piece_filter_kernel, dim3(static_cast<unsigned>((np + 255) / 256)), dim3(256), 0, ctx->stream,
-                       ctx->det_tics.as<int>(), n_edges, n, min_duration, d_cand, d_ncand, cand_cap);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, d_ncand, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned nc = std::min(*ctx->h_small.as<unsigned>(), cand_cap);
+    std::sort(tics.begin(), tics.end());
+    // pieces between consecutive edges; keep the ones longer than min_duration (parsers.py:133)
+    std::vector<int2> cand;
+    int a = 0;
+    for (size_t p = 0; p <= tics.size(); ++p) {
+        const int b = p == tics.size() ? static_cast<int>(n) : tics[p];
+        if (static_cast<int64_t>(b) - a > min_duration) cand.push_back(make_int2(a, b));
+        a = b;
+    }
+    const size_t nc = cand.size();
     if (nc == 0) return PS_OK;
-    if (f32) hipLaunchKernelGGL((piece_minmax_kernel<PS_DTYPE_F32>), dim3(nc), dim3(256), 0, ctx->stream, cfg, d_cand, d_mm);
-    else     hipLaunchKernelGGL((piece_minmax_kernel<PS_DTYPE_I16>), dim3(nc), dim3(256), 0, ctx->stream, cfg, d_cand, d_mm);
+    HIP_TRY(ctx, ctx->det_cand.reserve(nc * sizeof(int2) * 2));
+    HIP_TRY(ctx, ctx->h_up.reserve(nc * sizeof(int2)));
+    std::memcpy(ctx->h_up.p, cand.data(), nc * sizeof(int2));
+    int2 *d_cand = ctx->det_cand.as<int2>(), *d_mm = d_cand + nc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_cand, ctx->h_up.p, nc * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    if (f32) hipLaunchKernelGGL((piece_minmax_kernel<PS_DTYPE_F32>), dim3(static_cast<unsigned>(nc)), dim3(256), 0, ctx->stream, cfg, d_cand, static_cast<int>(nc), ctx->det_counts.as<int2>(), d_mm);
+    else     hipLaunchKernelGGL((piece_minmax_kernel<PS_DTYPE_I16>), dim3(static_cast<unsigned>(nc)), dim3(256), 0, ctx->stream, cfg, d_cand, static_cast<int>(nc), ctx->det_counts.as<int2>(), d_mm);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, ctx->h_dense.reserve(static_cast<size_t>(nc) * sizeof(int2) * 2));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.p, d_cand, static_cast<size_t>(nc) * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.as<int2>() + nc, d_mm, static_cast<size_t>(nc) * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, ctx->h_dense.reserve(nc * sizeof(int2)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.p, d_mm, nc * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int2 *hc = ctx->h_dense.as<int2>(), *hm = hc + nc;
-    std::vector<std::pair<int, int>> ev;                       // (start, index)
-    for (unsigned i = 0; i < nc; ++i) {
-        const double mn = (static_cast<double>(hm[i].x)) * cfg.q, mx = (static_cast<double>(hm[i].y)) * cfg.q;
-        if (mn > min_current && mx < threshold) ev.emplace_back(hc[i].x, static_cast<int>(i));   // parsers.py:133-135
+    const int2 *hm = ctx->h_dense.as<int2>();
+    int64_t kept = 0;
+    for (size_t i = 0; i < nc; ++i) {
+        const double mn = static_cast<double>(hm[i].x) * cfg.q, mx = static_cast<double>(hm[i].y) * cfg.q;
+        if (mn > min_current && mx < threshold) {                                        // parsers.py:134-135
+            if (kept < cap) { h_starts[kept] = cand[i].x; h_lengths[kept] = cand[i].y - cand[i].x; }
+            ++kept;
+        }
     }
-    std::sort(ev.begin(), ev.end());
-    *n_events_out = static_cast<int64_t>(ev.size());
-    if (static_cast<int64_t>(ev.size()) > cap) return fail(ctx, PS_ERR_CAPACITY, "event capacity %lld < %zu", static_cast<long long>(cap), ev.size());
-    for (size_t i = 0; i < ev.size(); ++i) {
-        h_starts[i] = hc[ev[i].second].x;
-        h_lengths[i] = hc[ev[i].second].y - hc[ev[i].second].x;
-    }
+    *n_events_out = kept;
+    if (kept > cap) return fail(ctx, PS_ERR_CAPACITY, "event capacity %lld < %lld", static_cast<long long>(cap), static_cast<long long>(kept));
     return PS_OK;
 }
 

@@ -1349,109 +1349,114 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
 
 // ---- K3: threshold event detector, parsers.py:124-155 ---------------------------------------------
 // mask[i] = x[i] < threshold; an edge sits at i (>= 1) when mask[i] != mask[i-1]; pieces lie between
-// consecutive edges.  Three streaming kernels: edges per 4096-sample chunk, (scan), edge positions.
+// consecutive edges.  ONE streaming pass over the trace (HBM-bound): 16-byte loads, edge positions
+// appended to a list with one atomic per thread that saw an edge (edges are rare; the host sorts the
+// few hundred positions), and min/max of every 4096-sample chunk, from which the min/max of the long
+// pieces follow without a second pass over their samples.
 constexpr int DET_NT = 256;
 constexpr int DET_PER = 16;                         // samples per thread
 constexpr int DET_CHUNK = DET_NT * DET_PER;
 
 template <int DT>
-__device__ __forceinline__ bool below_thr(const DevCfg &c, int64_t i, double thr)
+__device__ __forceinline__ bool below_thr(const DevCfg &c, int k, double thr)
 {
-    if (DT == PS_DTYPE_F32) return static_cast<double>(static_cast<const float *>(c.samples)[i]) < thr;
-    return static_cast<double>(static_cast<int>(static_cast<const int16_t *>(c.samples)[i]) + c.off_counts) * c.q < thr;
+    // k is the integer count; pA = k * quantum exactly (fp32 input: k = x / quantum on the grid)
+    return static_cast<double>(k) * c.q < thr;
 }
 
-// WRITE = false: counts[b] = edges in chunk b.  WRITE = true: tics[offs[b] + rank] = edge positions.
-template <int DT, bool WRITE>
-__global__ __launch_bounds__(DET_NT) void edge_kernel(DevCfg c, int64_t n, double thr, int *counts,
-                                                      const long long *offs, int *tics)
+template <int DT>
+__global__ __launch_bounds__(DET_NT) void edge_scan_kernel(DevCfg c, int64_t n, double thr, int *tics,
+                                                           unsigned *n_tics, unsigned tics_cap, int2 *chunk_mm,
+                                                           unsigned *status)
 {
-    __shared__ int wsum[DET_NT / 64];
+    __shared__ int smin[DET_NT / 64], smax[DET_NT / 64];
     const int64_t i0 = static_cast<int64_t>(blockIdx.x) * DET_CHUNK + static_cast<int64_t>(threadIdx.x) * DET_PER;
-    unsigned bits = 0;                                // bit u: edge at i0 + u
+    unsigned bits = 0, bad = 0;
+    int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);
     if (i0 < n) {
-        bool prev = i0 > 0 ? below_thr<DT>(c, i0 - 1, thr) : false;
+        int k[DET_PER];
+        constexpr int ES = static_cast<int>(sizeof(typename Raw<DT>::type));
+        const char *p = static_cast<const char *>(c.samples) + i0 * ES;
+        if (i0 + DET_PER <= n && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+            constexpr int NV = DET_PER * ES / 16;
+            int4 raw[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) raw[v] = reinterpret_cast<const int4 *>(p)[v];
+            if (DT == PS_DTYPE_F32) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float f[4] = {__int_as_float(raw[v].x), __int_as_float(raw[v].y), __int_as_float(raw[v].z), __int_as_float(raw[v].w)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) k[v * 4 + e] = to_count<DT>(c, f[e], bad);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int w[4] = {raw[v].x, raw[v].y, raw[v].z, raw[v].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        k[v * 8 + e] = ((e & 1) ? (w[e >> 1] >> 16) : static_cast<int>(static_cast<short>(w[e >> 1] & 0xffff))) + c.off_counts;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < DET_PER; ++u) k[u] = (i0 + u < n) ? load_count<DT>(c, i0 + u, bad) : 0;
+        }
+        bool prev = i0 > 0 ? below_thr<DT>(c, load_count<DT>(c, i0 - 1, bad), thr) : false;
 #pragma unroll
         for (int u = 0; u < DET_PER; ++u) {
-            const int64_t i = i0 + u;
-            if (i < n) {
-                const bool m = below_thr<DT>(c, i, thr);
-                if (i > 0 && m != prev) bits |= 1u << u;
+            if (i0 + u < n) {
+                const bool m = below_thr<DT>(c, k[u], thr);
+                if (i0 + u > 0 && m != prev) bits |= 1u << u;
                 prev = m;
+                mn = min(mn, k[u]); mx = max(mx, k[u]);
             }
         }
     }
-    const int cnt = __popc(bits);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(inc, d);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < DET_NT / 64; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
-    if (!WRITE) {
-        if (threadIdx.x == 0) counts[blockIdx.x] = total;
-    } else {
-        long long o = offs[blockIdx.x] + base + inc - cnt;
+    if (bits) {
+        const unsigned cnt = __popc(bits);
+        unsigned o = atomicAdd(n_tics, cnt);
         for (int u = 0; u < DET_PER; ++u)
-            if (bits & (1u << u)) tics[o++] = static_cast<int>(i0 + u);
-    }
-}
-
-// exclusive scan of int counts -> long long offsets[nb + 1] (one workgroup)
-__global__ __launch_bounds__(1024) void count_scan_kernel(const int *counts, int nb, long long *offs)
-{
-    __shared__ long long wsum[32];
-    __shared__ long long carry[2];
-    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
-    __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += 1024) {
-        const int b = b0 + threadIdx.x;
-        long long e1, e2;
-        chunk_exscan2(b < nb ? counts[b] : 0, 0, e1, e2, wsum, carry);
-        if (b < nb) offs[b] = e1;
-    }
-    if (threadIdx.x == 0) offs[nb] = carry[0];
-}
-
-// pieces longer than min_duration -> candidate list (start, end), unordered
-__global__ void piece_filter_kernel(const int *tics, long long n_edges, int64_t n, int64_t min_duration,
-                                    int2 *cand, unsigned *n_cand, unsigned cap)
-{
-    const long long p = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
-    if (p > n_edges) return;
-    const int a = p == 0 ? 0 : tics[p - 1];
-    const int b = p == n_edges ? static_cast<int>(n) : tics[p];
-    if (static_cast<int64_t>(b) - a > min_duration) {
-        const unsigned slot = atomicAdd(n_cand, 1u);
-        if (slot < cap) cand[slot] = make_int2(a, b);
-    }
-}
-
-// min / max (in counts) of every candidate piece, one workgroup each
-template <int DT>
-__global__ __launch_bounds__(256) void piece_minmax_kernel(DevCfg c, const int2 *cand, int2 *mm)
-{
-    __shared__ int smin[4], smax[4];
-    const int2 pc = cand[blockIdx.x];
-    int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);
-    unsigned bad = 0;
-    for (int64_t i = pc.x + threadIdx.x; i < pc.y; i += 256) {
-        const int k = load_count<DT>(c, i, bad);
-        mn = min(mn, k); mx = max(mx, k);
+            if (bits & (1u << u)) { if (o < tics_cap) tics[o] = static_cast<int>(i0 + u); ++o; }
     }
     wave_minmax(mn, mx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 63) { smin[wave] = mn; smax[wave] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) { mn = min(smin[0] = min(smin[0], smin[w]), mn); mx = max(smax[0] = max(smax[0], smax[w]), mx); }
-        mm[blockIdx.x] = make_int2(smin[0], smax[0]);
+        for (int w = 1; w < DET_NT / 64; ++w) { mn = min(mn, smin[w]); mx = max(mx, smax[w]); }
+        chunk_mm[blockIdx.x] = make_int2(min(mn, smin[0]), max(mx, smax[0]));
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+// min / max (counts) of every candidate piece [a, b): whole chunks from the table, the two ragged ends
+// sample by sample.  One workgroup per piece.
+template <int DT>
+__global__ __launch_bounds__(256) void piece_minmax_kernel(DevCfg c, const int2 *cand, int n_cand, const int2 *chunk_mm,
+                                                           int2 *mm)
+{
+    __shared__ int smin[4], smax[4];
+    if (static_cast<int>(blockIdx.x) >= n_cand) return;
+    const int2 pc = cand[blockIdx.x];
+    int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);
+    unsigned bad = 0;
+    const int64_t c0 = (static_cast<int64_t>(pc.x) + DET_CHUNK - 1) / DET_CHUNK, c1 = pc.y / DET_CHUNK;   // full chunks [c0, c1)
+    if (c0 < c1) {
+        for (int64_t b = c0 + threadIdx.x; b < c1; b += 256) { const int2 v = chunk_mm[b]; mn = min(mn, v.x); mx = max(mx, v.y); }
+        for (int64_t i = pc.x + threadIdx.x; i < c0 * DET_CHUNK; i += 256) { const int k = load_count<DT>(c, i, bad); mn = min(mn, k); mx = max(mx, k); }
+        for (int64_t i = c1 * DET_CHUNK + threadIdx.x; i < pc.y; i += 256) { const int k = load_count<DT>(c, i, bad); mn = min(mn, k); mx = max(mx, k); }
+    } else {
+        for (int64_t i = pc.x + threadIdx.x; i < pc.y; i += 256) { const int k = load_count<DT>(c, i, bad); mn = min(mn, k); mx = max(mx, k); }
+    }
+    wave_minmax(mn, mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) { smin[wave] = mn; smax[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = smin[0], b = smax[0];
+        for (int w = 1; w < 4; ++w) { a = min(a, smin[w]); b = max(b, smax[w]); }
+        mm[blockIdx.x] = make_int2(a, b);
     }
 }
 
