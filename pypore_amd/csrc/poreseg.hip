@@ -369,11 +369,13 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
     L = std::min<int64_t>(L, 0x7fffffff);
     std::vector<SpineJob> jobs;
     std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
-    int64_t list_entries = 0;
+    int64_t list_entries = 0, vb_run = 0;
     for (int e = 0; e < n_ev; ++e) {
         ev_first_tile[e] = static_cast<int64_t>(jobs.size());
         const int64_t len = ev_len[e];
         if (len == 0) continue;
+        const int64_t vbase = vb_run;
+        vb_run += len;
         const int64_t nt = (len + L - 1) / L;
         if (static_cast<int64_t>(jobs.size()) + nt > 0x7ffffff0) return RC_FALLBACK;
         for (int64_t t = 0; t < nt; ++t) {
@@ -388,6 +390,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
             j.ntiles = static_cast<int32_t>(nt);
             j.tile_len = static_cast<int32_t>(L);
             j.pad_ = 0;
+            j.vbase = vbase;
             list_entries += j.out_cap;
             jobs.push_back(j);
         }
@@ -396,7 +399,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
     const size_t nj = jobs.size();
     ctx->counters[2] = static_cast<int64_t>(nj);
     const int64_t max_items = list_entries + static_cast<int64_t>(nj) * BR_MAX;
-    const int64_t tscratch_bound = sample_end / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
+    const int64_t tscratch_bound = total_len / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
     const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
 
     HIP_TRY(ctx, ctx->ev_len.reserve(evb));
@@ -708,7 +711,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
             const int64_t capj = spine_cap(j.start, stop, mw);
             j.out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
             j.out_off = scratch;
-            j.first_tile = 0; j.ntiles = 1; j.tile_len = 0x7fffffff; j.pad_ = 0;
+            j.first_tile = 0; j.ntiles = 1; j.tile_len = 0x7fffffff; j.pad_ = 0; j.vbase = 0;
             scratch += j.out_cap;
             jobs.push_back(j);
         }
@@ -750,7 +753,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
                 const int64_t capj = spine_cap(z, stop, mw);
                 rj[0].out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
                 rj[0].out_off = 0;
-                rj[0].first_tile = 0; rj[0].ntiles = 1; rj[0].tile_len = 0x7fffffff; rj[0].pad_ = 0;
+                rj[0].first_tile = 0; rj[0].ntiles = 1; rj[0].tile_len = 0x7fffffff; rj[0].pad_ = 0; rj[0].vbase = 0;
                 std::vector<TileList> ext;
                 rc = run_spines(ctx, cfg, rj, rj[0].out_cap, ext);
                 if (rc) return rc;

@@ -63,6 +63,7 @@ struct SpineJob {           // speculative spine of one tile: rec(start, end) wi
     int32_t ntiles;         // tiles of this event
     int32_t tile_len;       // tile t of the event starts at t * tile_len
     int32_t pad_;
+    int64_t vbase;          // sum of the lengths of the preceding events (layout of the tree output regions)
 };
 
 struct TreeJob {            // full in-order traversal of rec(start, end), first window index j0
@@ -1026,7 +1027,8 @@ __global__ __launch_bounds__(NT, 4) void bridge_kernel(DevCfg c, const SpineJob 
         if (found != -2 && u != g) { st = BR_JOINED; jt = u; ji = found; break; }
         if (step == BR_MAX) break;
         int kind;
-        const int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
+        // (the samples a bridge reads were validated by the downstream tiles' own spine scans)
+        const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
         if (kind == KIND_NONE) { st = BR_ENDED; break; }
         if (threadIdx.x == 0) sh.obuf[cnt] = make_int2(s, kind);
         ++cnt;
@@ -1302,7 +1304,7 @@ __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
 
 // Stitch, part 2 (grid over the true spine): element i belongs to the tile g with
 // sp_off[g] <= i < sp_off[g+1].  Writes the item (anchor) and its tree job: job index = item
-// index, output region = (global sample index of the predecessor)/min_width + i, which is
+// index, output region = (samples of all preceding events + predecessor)/min_width + i, which is
 // monotone and non-overlapping without any scan ((a+b)/m >= a/m + b/m for integers).
 __global__ __launch_bounds__(256) void assemble_items_kernel(
     const SpineJob *jobs, int n_tiles, const int4 *meta, const int2 *lists, const int2 *bridges,
@@ -1341,7 +1343,7 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     tj.end = el.x;
     tj.j0 = left_child_j0(pred, el.x, W, W / 2);
     tj.out_cap = has ? (el.x - pred) / mw + 1 : 0;       // 0 marks "no left subtree": the tree kernel skips it
-    tj.out_off = (jb2.base + pred) / mw + i;
+    tj.out_off = (jb2.vbase + pred) / mw + i;
     tjobs[i] = tj;
     counts[i] = 0;
 }

@@ -303,3 +303,21 @@ def test_config3_file_pipeline_on_device(ctx, tmp_path):
     # the drop-in class route gives the same events
     evs = lambda_event_parser(threshold=90).parse(x, quantum=synth.QUANTUM)
     assert [int(e.start) for e in evs] == list(rs) and [int(e.duration) for e in evs] == list(rl)
+
+
+def test_events_in_arbitrary_memory_order(ctx):
+    """ps_segment_events with events that are not sorted by address (and overlap): output regions are
+    laid out by cumulative event length, not by address."""
+    import torch
+    from pypore_amd import _lib
+    c = synth.random_dwell_counts(600000, 77)
+    t = torch.from_numpy(synth.counts_to_pa(c, np.float32)).cuda()
+    starts = np.array([400000, 0, 150000, 390000], dtype=np.int64)
+    lens = np.array([200000, 120000, 60000, 100000], dtype=np.int64)
+    params = _lib.split_params(prior_segments_per_second=10.)
+    b, boff, _ = ctx.segment_events(t, starts, lens, params, synth.QUANTUM)
+    b = b.cpu().numpy()
+    x = synth.counts_to_pa(c, np.float64)
+    for e in range(4):
+        ref = oracle.parse(x[starts[e]:starts[e] + lens[e]], prior_segments_per_second=10.)
+        np.testing.assert_array_equal(b[boff[e]:boff[e + 1]], ref)
