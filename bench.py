@@ -99,7 +99,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kern = dict(spine_ms=0.0, bridge_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, total_ms=0.0)
+    kern = dict(blocksum_ms=0.0, spine_ms=0.0, bridge_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, total_ms=0.0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -147,7 +147,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_sample * n,
                          "kernel_ms": {k: round(v, 4) for k, v in kern.items()}},
             "whole_step_frac_of_hbm_roofline": round(bytes_per_sample * n / (ms_per_step * 1e-3) / HBM_PEAK, 5),
-            "work": {k: tm[k] for k in ("windows", "candidates", "tiles", "tree_jobs", "repairs", "exact_rescans")},
+            "work": {k: tm[k] for k in ("windows", "candidates", "tiles", "tree_jobs", "repairs", "exact_rescans", "full_exact_scans")},
         }
         if not args.no_cpu:
             import oracle

@@ -170,7 +170,7 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
  * stream: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[3] whole
  * call (host wall clock), ms[4] stitch (assemble kernels + header sync, or the host stitch),
  * ms[5] bridge kernel.  counters[0] window scans, [1] candidate
- * evaluations, [2] tiles, [3] tree jobs, [4] seam repairs, [5] exact (fp64) re-scans. */
+ * evaluations, [2] tiles, [3] tree jobs, [4] seam repairs, [5] windows decided in fp64 (contenders or whole window), [6] of which whole-window scans. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);
 
 /* Synthetic step-signal generator (bit-identical to pypore_amd/synth.py):

@@ -70,6 +70,8 @@ struct ps_ctx {
     int rep_eval = 1, rep_stage = 1, rep_sum = 1;
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
+    int scan_bs = 0;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
+    DevBuf bsum, ev_info, chunk_mabs, ev_boff;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
@@ -79,7 +81,7 @@ struct ps_ctx {
     HostBuf h_meta, h_dense, h_small, h_up;
     hipEvent_t ev[8] = {};
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t counters[6] = {0, 0, 0, 0, 0, 0};
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -128,6 +130,8 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->mode = ctx->mode;
     c->prune = ctx->prune;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
+    c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr;
+    c->dbg = ctx->small.as<SmallLayout>()->stamp;
     c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
 }
@@ -145,7 +149,7 @@ constexpr int LDS_BYTES_MAX = 160 * 1024 - static_cast<int>(sizeof(Shared)) - 51
 
 template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, bool list_mode = false)
 {
-    const size_t lds = lds_bytes_for(cfg.lds_cap, NT);
+    const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(spine_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
@@ -157,7 +161,7 @@ template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsig
 
 template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
-    const size_t lds = lds_bytes_for(cfg.lds_cap, NT);
+    const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
@@ -179,7 +183,11 @@ int check_status(ps_ctx *ctx, unsigned st)
 {
     if (st & ST_OFF_GRID)
         return fail(ctx, PS_ERR_OFF_GRID, "fp32 sample is not an integer multiple of quantum (or |count| >= 2^23)");
-    if (st & ST_VERIFY_MISMATCH) return fail(ctx, PS_ERR_INTERNAL, "verify mode: fp32 screen disagreed with the exact scan");
+    if (st & ST_VERIFY_MISMATCH) {
+        const SmallLayout *h = ctx->h_small.as<SmallLayout>();
+        return fail(ctx, PS_ERR_INTERNAL, "verify mode: fp32 screen disagreed with the exact scan (window [%lld,%lld): screen %lld, exact %lld)",
+                    static_cast<long long>(h->stamp[4]), static_cast<long long>(h->stamp[5]), static_cast<long long>(h->stamp[6]), static_cast<long long>(h->stamp[7]));
+    }
     if (st & ST_STACK_OVERFLOW) return fail(ctx, PS_ERR_INTERNAL, "device DFS stack overflow");
     if (st & ST_OUT_OVERFLOW) return fail(ctx, PS_ERR_INTERNAL, "device scratch overflow");
     return PS_OK;
@@ -272,7 +280,9 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (n_tj) {
         const unsigned g = static_cast<unsigned>(n_tj);
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
-        int lrc = ctx->tree_nt == 512
+        int lrc = cfg.bsum != nullptr
+                      ? (f32 ? launch_tree<64, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<64, PS_DTYPE_I16>(ctx, cfg, g, sm))
+                  : ctx->tree_nt == 512
                       ? (f32 ? launch_tree<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<512, PS_DTYPE_I16>(ctx, cfg, g, sm))
                       : (f32 ? launch_tree<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<256, PS_DTYPE_I16>(ctx, cfg, g, sm));
         if (lrc) return lrc;
@@ -300,15 +310,19 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (rc) return rc;
     ctx->counters[0] = static_cast<int64_t>(hs.work0);
     ctx->counters[1] = static_cast<int64_t>(hs.work1);
-    ctx->counters[5] = static_cast<int64_t>(hs.work2);
+    ctx->counters[5] = static_cast<int64_t>(hs.work2 & 0xffffffffULL) + static_cast<int64_t>(hs.work2 >> 32);   // exact decisions
+    ctx->counters[6] = static_cast<int64_t>(hs.work2 >> 32);                                                   // of which full fp64 window scans (block-sum scan)
 #ifdef PS_STAMP
     {
         static const char *nm[12] = {"stage_tail", "minmax", "chunksum", "scan", "eval", "top2", "exact", "outside", "ld_issue", "ld_wait", "-", "-"};
         unsigned long long tot = 0;
-        for (int i = 0; i < 12; ++i) tot += hs.stamp[i];
+        for (int i = 0; i < 9; ++i) tot += hs.stamp[i];
         fprintf(stderr, "[poreseg stamps] thread-0 cycles summed over workgroups (spine+tree):");
         for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
         fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
+        fprintf(stderr, "[poreseg stamps] (block-sum scan: top2=entry, ld_issue=block-sum loads+adds, stage_tail=wave scans+setup, minmax=boundary sweep, chunksum=drain, scan=reduce+decide, eval=contenders)\n");
+        fprintf(stderr, "[poreseg stamps] block-sum scan fallbacks: queue overflow %llu, screen guard %llu, contender overflow %llu\n",
+                hs.stamp[9], hs.stamp[10], hs.stamp[11]);
     }
 #endif
     const int64_t total = h_bounds_off[n_ev];
@@ -340,10 +354,11 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
 
 
 constexpr int RC_FALLBACK = 1;
+constexpr int RC_WIDE = 2;
 
 template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
-    const size_t lds = lds_bytes_for(cfg.lds_cap, NT);
+    const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bridge_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
@@ -358,14 +373,17 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
 // tree jobs, items) -- the host only reads a 32-byte header between phase 1 and phase 3.
 // Returns RC_FALLBACK when a seam could not be bridged on the device (rare); the caller then runs
 // the host-stitch pipeline, which repairs seams one by one.
-int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
+int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
                         std::chrono::steady_clock::time_point t_begin)
 {
+    DevCfg cfg = cfg_in;
     int64_t total_len = 0, sample_end = 0;
     for (int e = 0; e < n_ev; ++e) { total_len += ev_len[e]; sample_end = std::max(sample_end, ev_start[e] + ev_len[e]); }
     int64_t L = ctx->tile_len;
-    if (L <= 0) L = std::max<int64_t>(8LL * W, (total_len + 1023) / 1024);
+    if (L <= 0) L = use_bs ? std::max<int64_t>(4LL * W, (total_len + 2047) / 2048)
+                           : std::max<int64_t>(8LL * W, (total_len + 1023) / 1024);
+    L = (L + 7) & ~7LL;
     L = std::min<int64_t>(L, 0x7fffffff);
     std::vector<SpineJob> jobs;
     std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
@@ -389,7 +407,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
             j.first_tile = static_cast<int32_t>(ev_first_tile[e]);
             j.ntiles = static_cast<int32_t>(nt);
             j.tile_len = static_cast<int32_t>(L);
-            j.pad_ = 0;
+            j.ev = e;
             j.vbase = vbase;
             list_entries += j.out_cap;
             jobs.push_back(j);
@@ -427,7 +445,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
 
     // one upload blob: [jobs | ev_first_tile | ev_off]
     const size_t jb = nj * sizeof(SpineJob);
-    HIP_TRY(ctx, ctx->h_up.reserve(jb + 3 * evb + 64));
+    HIP_TRY(ctx, ctx->h_up.reserve(jb + 4 * evb + 64));
     char *up = ctx->h_up.as<char>();
     if (nj) std::memcpy(up, jobs.data(), jb);
     std::memcpy(up + jb, ev_first_tile.data(), evb);
@@ -440,8 +458,41 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
 
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if (use_bs && nj) {
+        // K0: chunk-prefixed block sums (one streaming pass), per-event centre m, totals + max|k| per 256 blocks
+        std::vector<int64_t> boff(static_cast<size_t>(n_ev) + 1, 0);
+        for (int e = 0; e < n_ev; ++e) boff[e + 1] = boff[e] + (ev_len[e] + 7) / 8;
+        const int64_t nb_total = boff[n_ev];
+        const unsigned k0_grid = static_cast<unsigned>((nb_total + 1 + BS_CHUNK - 1) / BS_CHUNK);   // (+1: the end boundary)
+        HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int4)));
+        HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
+        HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(k0_grid + 1) * sizeof(int4)));
+        HIP_TRY(ctx, ctx->ev_boff.reserve(evb));
+        std::memcpy(up + jb + 3 * evb, boff.data(), evb);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_boff.p, up + jb + 3 * evb, evb, hipMemcpyHostToDevice, ctx->stream));
+        if (f32) hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_F32>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
+                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev,
+                                    ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),
+                                    reinterpret_cast<unsigned *>(&sm->status));
+        else     hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_I16>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
+                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev,
+                                    ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),
+                                    reinterpret_cast<unsigned *>(&sm->status));
+        HIP_TRY(ctx, hipGetLastError());
+        cfg.bsum = ctx->bsum.as<int4>();
+        cfg.ev_info = ctx->ev_info.as<int4>();
+        cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if (nj) {
+    if (nj && use_bs) {
+        const unsigned g = static_cast<unsigned>(nj);
+        int lrc = f32 ? launch_spine<64, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16>(ctx, cfg, g, sm, true);
+        if (lrc) return lrc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        lrc = f32 ? launch_bridge<64, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<64, PS_DTYPE_I16>(ctx, cfg, g, sm);
+        if (lrc) return lrc;
+    } else if (nj) {
         const unsigned g = static_cast<unsigned>(nj);
         int lrc = ctx->spine_nt == 256
                       ? (f32 ? launch_spine<256, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<256, PS_DTYPE_I16>(ctx, cfg, g, sm, true))
@@ -474,6 +525,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+    if (use_bs && (static_cast<unsigned>(hs.status) & ST_WIDE_RANGE)) return RC_WIDE;     // counts too wide for the block sums
     int rc = check_status(ctx, static_cast<unsigned>(hs.status));
     if (rc) return rc;
     const AsmHeader hd = *ctx->h_hdr.as<AsmHeader>();
@@ -490,6 +542,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg, const int64_t *ev_start,
     ctx->counters[3] = hd.n_items;
     rc = finish_batch(ctx, cfg, static_cast<size_t>(hd.n_items), hd.n_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin);
     float ms = 0;
+    if (nj && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[0]) == hipSuccess) ctx->ms[6] = ms;       // blocksum_kernel (K0)
     if (nj && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[6]) == hipSuccess) ctx->ms[0] = ms;       // spine_kernel
     if (nj && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[1]) == hipSuccess) ctx->ms[5] = ms;       // bridge_kernel
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]) == hipSuccess) ctx->ms[4] = ms;     // device stitch incl. header sync
@@ -534,6 +587,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_STAGE")) ctx->rep_stage = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
@@ -550,7 +604,8 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->tree_scratch, &ctx->tree_spill, &ctx->tree_counts, &ctx->items, &ctx->item_pos,
                       &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
-                      &ctx->det_counts, &ctx->det_tics, &ctx->det_cand};
+                      &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
+                      &ctx->ev_boff};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -575,6 +630,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     if (n == "mode" && value >= 0 && value <= 2) ctx->mode = static_cast<int>(value);
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
+    else if (n == "scan_bs") ctx->scan_bs = value != 0;
     else if (n == "spine_nt" && (value == 256 || value == 512 || value == 1024)) ctx->spine_nt = static_cast<int>(value);
     else if (n == "tree_nt" && (value == 256 || value == 512)) ctx->tree_nt = static_cast<int>(value);
     else return fail(ctx, PS_ERR_ARG, "unknown option or value: %s", name);
@@ -672,7 +728,14 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
 
     if (!ctx->stitch_host) {
-        rc = device_stitch_batch(ctx, cfg, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+        bool use_bs = ctx->scan_bs && mw >= 8 && ctx->mode != MODE_EXACT;
+        rc = device_stitch_batch(ctx, cfg, use_bs, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+        if (rc == RC_WIDE) {                          // counts too wide for uint32 block sums: LDS-window scan instead
+            for (double &m : ctx->ms) m = 0;
+            for (int64_t &c : ctx->counters) c = 0;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+            rc = device_stitch_batch(ctx, cfg, false, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+        }
         if (rc != RC_FALLBACK) return rc;
         // a seam could not be bridged on the device: redo with the host stitch (halo tiles + repairs)
         for (double &m : ctx->ms) m = 0;
@@ -711,7 +774,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
             const int64_t capj = spine_cap(j.start, stop, mw);
             j.out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
             j.out_off = scratch;
-            j.first_tile = 0; j.ntiles = 1; j.tile_len = 0x7fffffff; j.pad_ = 0; j.vbase = 0;
+            j.first_tile = 0; j.ntiles = 1; j.tile_len = 0x7fffffff; j.ev = e; j.vbase = 0;
             scratch += j.out_cap;
             jobs.push_back(j);
         }
@@ -753,7 +816,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
                 const int64_t capj = spine_cap(z, stop, mw);
                 rj[0].out_cap = static_cast<int32_t>(std::min<int64_t>(capj, 0x7fffffff));
                 rj[0].out_off = 0;
-                rj[0].first_tile = 0; rj[0].ntiles = 1; rj[0].tile_len = 0x7fffffff; rj[0].pad_ = 0; rj[0].vbase = 0;
+                rj[0].first_tile = 0; rj[0].ntiles = 1; rj[0].tile_len = 0x7fffffff; rj[0].ev = e; rj[0].vbase = 0;
                 std::vector<TileList> ext;
                 rc = run_spines(ctx, cfg, rj, rj[0].out_cap, ext);
                 if (rc) return rc;
@@ -778,6 +841,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
                 tj.j0 = d < 0 ? 0 : static_cast<int32_t>(d / (W / 2)) + 1;
                 tj.out_cap = (an.pos - prev) / mw + 1;
                 tj.out_off = tscratch;
+                tj.ev = e; tj.pad_ = 0;
                 tscratch += tj.out_cap;
                 it.job = static_cast<int32_t>(tjobs.size());
                 tjobs.push_back(tj);
@@ -994,7 +1058,7 @@ int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counter
 {
     if (!ctx) return PS_ERR_ARG;
     for (int i = 0; i < n_ms && ms; ++i) ms[i] = i < 8 ? ctx->ms[i] : 0.0;
-    for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 6 ? ctx->counters[i] : 0;
+    for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 8 ? ctx->counters[i] : 0;
     return PS_OK;
 }
 

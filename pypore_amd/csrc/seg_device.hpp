@@ -50,6 +50,10 @@ struct DevCfg {
     int mode;               // MODE_*
     int prune;              // 1: block-bound pruning in the screen (default), 0: evaluate every candidate
     int lds_cap;            // samples that fit the dynamic LDS window buffer
+    const int4 *bsum;       // per 8-sample block: chunk-exclusive prefix of (sum (k-m), sum (k-m)^2), all events; nullptr: LDS-window scan
+    const int4 *ev_info;    // per event: (m, -, block offset lo, block offset hi)
+    const int4 *chunk_tot;  // per 256 blocks (K0 workgroup): (sum, sum of squares lo/hi, max |k|)
+    unsigned long long *dbg;  // diagnostics scratch (12 words) or nullptr
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
 
@@ -62,7 +66,7 @@ struct SpineJob {           // speculative spine of one tile: rec(start, end) wi
     int32_t first_tile;     // global index of the event's first tile
     int32_t ntiles;         // tiles of this event
     int32_t tile_len;       // tile t of the event starts at t * tile_len
-    int32_t pad_;
+    int32_t ev;             // event index
     int64_t vbase;          // sum of the lengths of the preceding events (layout of the tree output regions)
 };
 
@@ -71,34 +75,47 @@ struct TreeJob {            // full in-order traversal of rec(start, end), first
     int32_t start, end, j0;
     int32_t out_cap;
     int64_t out_off;        // into the private boundary scratch (int32) and the spill stack (int2)
+    int32_t ev, pad_;
 };
 
 typedef short lds_t;               // window samples in LDS: ADC counts as int16 (windows that do not fit go the exact HBM path)
 
 struct QEnt { int j, jend, p1, r1; unsigned p2, r2; int cL, cR; };
 
-struct Shared {
-    double wsum1[MAX_WAVES], wsum2[MAX_WAVES];
-    double wbest[MAX_WAVES];
-    int widx[MAX_WAVES];
-    float fbest[MAX_WAVES], fsecond[MAX_WAVES];
-    int fidx[MAX_WAVES];
-    int wmin[MAX_WAVES], wmax[MAX_WAVES];
-    unsigned wflag[MAX_WAVES];
+// Per-workgroup scratch in LDS.  The 64-thread (single wave) variant used by the block-sum scan
+// keeps it small so that 16 workgroups fit a CU.
+template <int NT> struct SharedT {
+    static constexpr int NWV = NT / 64;
+    static constexpr int OB = NT == 64 ? 64 : OBUF;          // buffered outputs
+    static constexpr int QN = NT == 64 ? 208 : QMAX;         // queued blocks
+    static constexpr int LN = NT == 64 ? 128 : LST_MAX;      // cached downstream anchors
+    static constexpr int SN = NT == 64 ? 64 : LDS_STACK;     // DFS stack entries before spilling
+    double wsum1[NWV], wsum2[NWV];
+    double wbest[NWV];
+    int widx[NWV];
+    float fbest[NWV], fsecond[NWV];
+    int fidx[NWV];
+    int wmin[NWV], wmax[NWV];
+    unsigned wflag[NWV];
     int bcast;
     int2 pop;
-    int2 stack[LDS_STACK];
-    int lst[LST_MAX];
-    float wmaxf[MAX_WAVES];
+    int2 stack[SN];
+    int lst[LN];
+    float wmaxf[NWV];
     int qn;
-    QEnt q[QMAX];
-    int2 obuf[OBUF];        // results are buffered here and written to HBM once per job: a global
+    QEnt q[QN];
+    int2 obuf[OB];          // results are buffered here and written to HBM once per job: a global
                             // store issued between scans would sit in front of the next window's
                             // staging loads (vmcnt retires in order) and stall the whole workgroup
 };
+typedef SharedT<1024> Shared;  // (size reference for the host-side LDS budget: the largest variant)
 
+#ifndef PS_BS_MINW
+#define PS_BS_MINW 2          // waves per SIMD the single-wave (block-sum) kernels are compiled for
+#endif
 struct Work {
     long long windows, cands, exact;
+    long long dbg[4];        // verify mode: first disagreement (ps, pe, screen result, exact result)
 #ifdef PS_STAMP
     long long t0, ph[12];
 #endif
@@ -107,10 +124,10 @@ struct Work {
 // deltas per phase of the window scan; never compiled into the product library.
 #ifdef PS_STAMP
 #define PS_STAMP_AT(wk, i) do { if (threadIdx.x == 0) { long long t_ = clock64(); (wk).ph[i] += t_ - (wk).t0; (wk).t0 = t_; } } while (0)
-#define PS_WORK_INIT {0, 0, 0, clock64(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}
+#define PS_WORK_INIT {0, 0, 0, {0, 0, 0, 0}, clock64(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}
 #else
 #define PS_STAMP_AT(wk, i) do { } while (0)
-#define PS_WORK_INIT {0, 0, 0}
+#define PS_WORK_INIT {0, 0, 0, {0, 0, 0, 0}}
 #endif
 
 // ---- sample access --------------------------------------------------------------------------
@@ -208,7 +225,7 @@ __device__ __forceinline__ void wave_minmax(int &mn, int &mx)      // result in 
 // summation order does not matter); also returns the workgroup totals.  One barrier.
 template <int NT>
 __device__ __forceinline__ void block_exscan2(double v1, double v2, double &e1, double &e2,
-                                              double &t1, double &t2, Shared &sh)
+                                              double &t1, double &t2, SharedT<NT> &sh)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -238,7 +255,7 @@ __device__ __forceinline__ bool beats(double ga, int ia, double gb, int ib)
 // Workgroup arg-max with the reference tie-break; result uniform.  One barrier (the slots it
 // writes were last read before an earlier barrier of the same scan).
 template <int NT>
-__device__ __forceinline__ int block_argmax(double g, int idx, Shared &sh, double *gain_out)
+__device__ __forceinline__ int block_argmax(double g, int idx, SharedT<NT> &sh, double *gain_out)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -266,7 +283,7 @@ __device__ __forceinline__ int block_argmax(double g, int idx, Shared &sh, doubl
 // ys[0..n) hold the window's counts (LDS) or, when ys == nullptr, samples are read from HBM.
 template <int NT, int DT>
 __device__ int scan_exact(const DevCfg &c, const lds_t *ys, int64_t g0, int ps, int n, int cand_lo,
-                          int cand_hi, double thresh, double *scores, Shared &sh, unsigned &bad,
+                          int cand_hi, double thresh, double *scores, SharedT<NT> &sh, unsigned &bad,
                           double *best_gain_out)
 {
     const int ch = ((n + NT - 1) / NT) | 1;
@@ -354,7 +371,7 @@ __device__ __forceinline__ void top2_merge(Top2 &t, float ob, float os, int oi)
 // needed.  All threads return the same value.
 template <int NT>
 __device__ int scan_screen(const DevCfg &c, const lds_t *ys, int ps, int n, int cand_lo, int cand_hi,
-                           double thresh, int kmin, int kmax, Shared &sh, int *split, Work &wk)
+                           double thresh, int kmin, int kmax, SharedT<NT> &sh, int *split, Work &wk)
 {
     constexpr int NW = NT / 64;
     const int ch = ((n + NT - 1) / NT) | 1;           // odd lane stride: conflict-free ds_read_b32
@@ -526,7 +543,7 @@ __device__ __forceinline__ ScrOut screen_eval(int p1, unsigned p2, int r1, unsig
 
 template <int NT>
 __device__ int scan_screen_pruned(const DevCfg &c, const lds_t *ys, int2 *bsum, int ps, int n, int cand_lo, int cand_hi,
-                                  double thresh, int kmin, int kmax, Shared &sh, int *split, Work &wk)
+                                  double thresh, int kmin, int kmax, SharedT<NT> &sh, int *split, Work &wk)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -675,7 +692,7 @@ __device__ int scan_screen_pruned(const DevCfg &c, const lds_t *ys, int2 *bsum, 
                 const float U = fmaxf(h0, h1);
                 if (!(U < T0)) {                          // cannot be discarded: queue for full evaluation
                     const int slot = atomicAdd(&sh.qn, 1);
-                    if (slot < QMAX) {
+                    if (slot < SharedT<NT>::QN) {
                         QEnt q;
                         q.j = j; q.jend = je; q.p1 = bp1; q.r1 = br1; q.p2 = bp2; q.r2 = br2; q.cL = cL; q.cR = cR;
                         sh.q[slot] = q;
@@ -689,7 +706,7 @@ __device__ int scan_screen_pruned(const DevCfg &c, const lds_t *ys, int2 *bsum, 
     }
     __syncthreads();
     const int qn = sh.qn;
-    if (qn > QMAX) flag = 1;                              // bound too weak on this window: decide exactly
+    if (qn > SharedT<NT>::QN) flag = 1;                              // bound too weak on this window: decide exactly
     else {
         for (int idx = threadIdx.x; idx < qn * (PBLK - 1); idx += NT) {
             const int e = idx / (PBLK - 1), t = idx - e * (PBLK - 1) + 1;
@@ -732,13 +749,17 @@ __device__ int scan_screen_pruned(const DevCfg &c, const lds_t *ys, int2 *bsum, 
     return 0;
 }
 
+}  // namespace ps
+#include "seg_bs.hpp"
+namespace ps {
+
 // ---- one window scan: cparsers.pyx:157-178 ------------------------------------------------------
 // Window [ps, pe) of the event at `base`; candidates cand_lo..cand_hi (inclusive, event-local);
 // returns the first index whose gain strictly exceeds every earlier gain and `thresh`, or -1.
 template <int NT, int DT, bool VALIDATE>
 __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
-                           double thresh, double *scores, Shared &sh, unsigned &bad, Work &wk,
-                           double *best_gain_out = nullptr, int pf_end = 0)
+                           double thresh, double *scores, SharedT<NT> &sh, unsigned &bad, Work &wk,
+                           double *best_gain_out = nullptr, int pf_end = 0, int ev = 0)
 {
     constexpr int NW = NT / 64;
     const int n = pe - ps;
@@ -747,6 +768,10 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     if (threadIdx.x == 0) {
         wk.windows += 1;
         wk.cands += (cand_hi >= cand_lo) ? (cand_hi - cand_lo + 1) : 0;
+    }
+    if constexpr (NT == 64) {                          // single-wave workgroup: block-sum scan (seg_bs.hpp)
+        if (c.bsum != nullptr && scores == nullptr && best_gain_out == nullptr)
+            return scan_window_bs<DT>(c, ev, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
     }
     if (n > c.lds_cap) {                               // window larger than LDS: exact path from HBM
         if (threadIdx.x == 0) wk.exact += 1;
@@ -876,7 +901,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 // parent frame, DESIGN.md "memoised left child").
 template <int NT, int DT, bool VALIDATE>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
-                          Shared &sh, unsigned &bad, Work &wk, long long pf_lim)
+                          SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, int ev = 0)
 {
     const long long lim = static_cast<long long>(end) - 2LL * c.mw;
     for (long long ps = static_cast<long long>(start) + static_cast<long long>(j0) * c.half; ps < lim;
@@ -893,7 +918,7 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
             s = scan_window<NT, DT, VALIDATE>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
                                 static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
                                 c.min_gain, nullptr, sh, bad, wk, nullptr,
-                                static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim));
+                                static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim), ev);
         if (s >= 0) { kind = KIND_HIT; return s; }                      // :195-196
     }
     if (static_cast<long long>(end) - start <= c.maxw) { kind = KIND_NONE; return -1; }   // :199-200
@@ -915,6 +940,7 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
         atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
         atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
         if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
+        if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
 #ifdef PS_STAMP
         for (int i = 0; i < 12; ++i) atomicAdd(&work[4 + i], static_cast<unsigned long long>(wk.ph[i]));
 #endif
@@ -926,12 +952,12 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
 // After the chain stops, the workgroup reserves `count` slots in the dense list with one
 // atomic and copies its anchors there so the host fetches a compact array.
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void spine_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch,
                                                    int2 *dense, int4 *meta, unsigned long long *dense_count,
                                                    unsigned *status, unsigned long long *work)
 {
     extern __shared__ int ys[];
-    __shared__ Shared sh;
+    __shared__ SharedT<NT> sh;
     const SpineJob job = jobs[blockIdx.x];
     int2 *out = scratch + job.out_off;
     unsigned bad = 0;
@@ -939,13 +965,13 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void spine_kernel(DevCfg 
     int a = job.start, cnt = 0, ended = 0, flushed = 0;
     for (;;) {
         int kind;
-        int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
+        int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev);
         if (kind == KIND_NONE) { ended = 1; break; }
-        if (cnt - flushed == OBUF) {                   // rare: spill the LDS buffer to the private scratch
+        if (cnt - flushed == SharedT<NT>::OB) {        // rare: spill the LDS buffer to the private scratch
             __syncthreads();
-            for (int i = threadIdx.x; i < OBUF; i += NT)
+            for (int i = threadIdx.x; i < SharedT<NT>::OB; i += NT)
                 if (flushed + i < job.out_cap) out[flushed + i] = sh.obuf[i];
-            flushed += OBUF;
+            flushed += SharedT<NT>::OB;
             __syncthreads();
         }
         if (cnt >= job.out_cap) bad |= ST_OUT_OVERFLOW;
@@ -983,12 +1009,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void spine_kernel(DevCfg 
 enum : int { BR_NONE = 0, BR_JOINED = 1, BR_ENDED = 2, BR_FAIL = 3 };
 
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, 4) void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                        const int4 *meta, int2 *bridges, int4 *bmeta,
                                                        unsigned *status, unsigned long long *work)
 {
     extern __shared__ int ys[];
-    __shared__ Shared sh;
+    __shared__ SharedT<NT> sh;
     const int g = blockIdx.x;
     const SpineJob job = jobs[g];
     const int4 m = meta[g];
@@ -1009,7 +1035,7 @@ __global__ __launch_bounds__(NT, 4) void bridge_kernel(DevCfg c, const SpineJob 
         if (u != cached) {                             // cache the downstream list's positions in LDS
             ccnt = meta[u].x;
             __syncthreads();
-            for (int i = threadIdx.x; i < ccnt && i < LST_MAX; i += NT) sh.lst[i] = lists[uj.out_off + i].x;
+            for (int i = threadIdx.x; i < ccnt && i < SharedT<NT>::LN; i += NT) sh.lst[i] = lists[uj.out_off + i].x;
             __syncthreads();
             cached = u;
         }
@@ -1019,7 +1045,7 @@ __global__ __launch_bounds__(NT, 4) void bridge_kernel(DevCfg c, const SpineJob 
             int lo = 0, hi = ccnt - 1;
             while (lo <= hi) {
                 const int mid = (lo + hi) >> 1;
-                const int v = mid < LST_MAX ? sh.lst[mid] : lists[uj.out_off + mid].x;
+                const int v = mid < SharedT<NT>::LN ? sh.lst[mid] : lists[uj.out_off + mid].x;
                 if (v == a) { found = mid; break; }
                 if (v < a) lo = mid + 1; else hi = mid - 1;
             }
@@ -1028,7 +1054,7 @@ __global__ __launch_bounds__(NT, 4) void bridge_kernel(DevCfg c, const SpineJob 
         if (step == BR_MAX) break;
         int kind;
         // (the samples a bridge reads were validated by the downstream tiles' own spine scans)
-        const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end);
+        const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev);
         if (kind == KIND_NONE) { st = BR_ENDED; break; }
         if (threadIdx.x == 0) sh.obuf[cnt] = make_int2(s, kind);
         ++cnt;
@@ -1042,12 +1068,12 @@ __global__ __launch_bounds__(NT, 4) void bridge_kernel(DevCfg c, const SpineJob 
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, 4) void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work)
 {
     extern __shared__ int ys[];
-    __shared__ Shared sh;
+    __shared__ SharedT<NT> sh;
     const TreeJob job = jobs[blockIdx.x];
     if (job.out_cap == 0) return;                      // spine anchor without a left subtree (device stitch)
     int32_t *out = scratch + job.out_off;
@@ -1056,7 +1082,7 @@ __global__ __launch_bounds__(NT, 4) void tree_kernel(DevCfg c, const TreeJob *jo
     Work wk = PS_WORK_INIT;
     int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0, flushed = 0;
     int *obuf = reinterpret_cast<int *>(sh.obuf);
-    constexpr int OB = 2 * OBUF;
+    constexpr int OB = 2 * SharedT<NT>::OB;
     auto emit = [&](int v) {
         if (cnt - flushed == OB) {                     // rare: spill the LDS buffer to the private scratch
             __syncthreads();
@@ -1071,11 +1097,11 @@ __global__ __launch_bounds__(NT, 4) void tree_kernel(DevCfg c, const TreeJob *jo
     };
     for (;;) {
         int kind;
-        int s = find_split<NT, DT, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end);
+        int s = find_split<NT, DT, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
         if (kind == KIND_NONE) {
             if (sp == 0) break;
             --sp;
-            if (threadIdx.x == 0) sh.pop = sp < LDS_STACK ? sh.stack[sp] : sp_glob[sp - LDS_STACK];
+            if (threadIdx.x == 0) sh.pop = sp < SharedT<NT>::SN ? sh.stack[sp] : sp_glob[sp - SharedT<NT>::SN];
             __syncthreads();
             const int2 top = sh.pop;
             __syncthreads();
@@ -1089,10 +1115,10 @@ __global__ __launch_bounds__(NT, 4) void tree_kernel(DevCfg c, const TreeJob *jo
             continue;
         }
         // HIT / LATE: rec(start, s) first, then emit s and continue with rec(s, end)
-        if (sp < LDS_STACK) {
+        if (sp < SharedT<NT>::SN) {
             if (threadIdx.x == 0) sh.stack[sp] = make_int2(s, end);
-        } else if (sp - LDS_STACK < job.out_cap) {
-            if (threadIdx.x == 0) sp_glob[sp - LDS_STACK] = make_int2(s, end);
+        } else if (sp - SharedT<NT>::SN < job.out_cap) {
+            if (threadIdx.x == 0) sp_glob[sp - SharedT<NT>::SN] = make_int2(s, end);
         } else {
             bad |= ST_STACK_OVERFLOW;
             break;
@@ -1118,7 +1144,7 @@ __global__ __launch_bounds__(NT) void single_scan_kernel(DevCfg c, int n, int mo
                                                          unsigned *status, unsigned long long *work)
 {
     extern __shared__ int ys[];
-    __shared__ Shared sh;
+    __shared__ SharedT<NT> sh;
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
     int r = -1;
@@ -1344,6 +1370,7 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     tj.j0 = left_child_j0(pred, el.x, W, W / 2);
     tj.out_cap = has ? (el.x - pred) / mw + 1 : 0;       // 0 marks "no left subtree": the tree kernel skips it
     tj.out_off = (jb2.vbase + pred) / mw + i;
+    tj.ev = jb2.ev; tj.pad_ = 0;
     tjobs[i] = tj;
     counts[i] = 0;
 }

@@ -253,14 +253,48 @@ def test_spine_flags_and_sharded_trace_on_device(ctx):
 
 
 def test_counts_beyond_int16_take_the_exact_path(ctx):
-    """quantum 2^-10 turns 50 pA into 51200 counts: the window does not fit the int16 LDS image and
-    is scanned by the exact fp64 path straight from HBM -- same boundaries."""
+    """LDS-window scan: quantum 2^-10 turns 50 pA into 51200 counts, the window does not fit the int16 LDS
+    image and is scanned by the exact fp64 path straight from HBM -- same boundaries.  The block-sum scan
+    (default) centres on the first sample and handles the same input without any fallback."""
     from pypore_amd.parsers import SpeedyStatSplit
     x = synth.config2_event(5)
     ref = oracle.parse(x, prior_segments_per_second=10.)
     segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -10).parse(x)
     np.testing.assert_array_equal(_bounds(segs), ref)
-    assert ctx.timings()["exact_rescans"] > 0
+    ctx.set_option("scan_bs", 0)
+    try:
+        segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -10).parse(x)
+        np.testing.assert_array_equal(_bounds(segs), ref)
+        assert ctx.timings()["exact_rescans"] > 0
+    finally:
+        ctx.set_option("scan_bs", 1)
+
+
+def test_wide_range_counts_fall_back_from_block_sums(ctx):
+    """Levels 1500 pA apart (48000 counts at 2^-5): |k - m| exceeds the uint32 block-sum range, K0 flags
+    it and the call is redone with the LDS-window scan (whose int16 image overflows too -> exact path)."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    c = synth.step_counts(60000, 7000, 91).astype(np.int64)
+    c[20000:41000] += 48000
+    x = synth.counts_to_pa(c, np.float64)
+    ref = oracle.parse(x, prior_segments_per_second=10.)
+    segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM).parse(x.astype(np.float32))
+    np.testing.assert_array_equal(_bounds(segs), ref)
+
+
+@pytest.mark.parametrize("scan_bs", [0, 1])
+def test_both_scan_implementations_on_goldens(scan_bs, ctx):
+    """The LDS-window scan and the block-sum scan give the same boundaries (subset of the goldens)."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    ctx.set_option("scan_bs", scan_bs)
+    try:
+        for name in ("G1_config1", "G2_dwell500", "G4_forced_mixed", "G4_small_windows", "G4_odd_window", "G4_big_window",
+                     "G4_minwidth2", "G9_rd_2M", "G9_rd_short_dwell", "G9_cutoff"):
+            (case,) = [c for c in cases("parse") if c["name"] == name]
+            segs = SpeedyStatSplit(quantum=synth.QUANTUM, **case["params"]).parse(input_pa(case, np.float32))
+            np.testing.assert_array_equal(_bounds(segs), npz()[name + "/bounds"])
+    finally:
+        ctx.set_option("scan_bs", 1)
 
 
 def test_event_detector_kernel_matches_reference_parsers_py(ctx):
