@@ -70,7 +70,7 @@ struct ps_ctx {
     int rep_eval = 1, rep_stage = 1, rep_sum = 1;
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
-    int scan_bs = 0;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
+    int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     DevBuf bsum, ev_info, chunk_mabs, ev_boff;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
@@ -107,7 +107,7 @@ int fail(ps_ctx *ctx, int code, const char *fmt, ...)
     } while (0)
 
 // status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..3] work, [4] dense count
-struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12]; };
+struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9]; };
 
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
              double min_gain, DevCfg *c)
@@ -321,6 +321,9 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
         fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
         fprintf(stderr, "[poreseg stamps] (block-sum scan: top2=entry, ld_issue=block-sum loads+adds, stage_tail=wave scans+setup, minmax=boundary sweep, chunksum=drain, scan=reduce+decide, eval=contenders)\n");
+        for (int k = 0; k < 3; ++k)
+            fprintf(stderr, "[poreseg stamps] %s: longest workgroup %llu cycles, windows %llu, sum of lifetimes %llu cycles\n",
+                    k == 0 ? "spine" : k == 1 ? "bridge" : "tree", hs.life[3 * k], hs.life[3 * k + 1], hs.life[3 * k + 2]);
         fprintf(stderr, "[poreseg stamps] block-sum scan fallbacks: queue overflow %llu, screen guard %llu, contender overflow %llu\n",
                 hs.stamp[9], hs.stamp[10], hs.stamp[11]);
     }
@@ -394,19 +397,22 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
         if (len == 0) continue;
         const int64_t vbase = vb_run;
         vb_run += len;
-        const int64_t nt = (len + L - 1) / L;
+        // tiles of one event share one length: the event is cut evenly (a 50k event with L = 40k: 2 x 25k)
+        const int64_t nt0 = (len + L - 1) / L;
+        const int64_t Le = std::min<int64_t>(((len + nt0 - 1) / nt0 + 7) & ~7LL, 0x7fffffff);
+        const int64_t nt = (len + Le - 1) / Le;
         if (static_cast<int64_t>(jobs.size()) + nt > 0x7ffffff0) return RC_FALLBACK;
         for (int64_t t = 0; t < nt; ++t) {
             SpineJob j;
             j.base = ev_start[e];
-            j.start = static_cast<int32_t>(t * L);
+            j.start = static_cast<int32_t>(t * Le);
             j.end = static_cast<int32_t>(len);
-            j.stop = static_cast<int32_t>(t == nt - 1 ? len : (t + 1) * L);
+            j.stop = static_cast<int32_t>(t == nt - 1 ? len : (t + 1) * Le);
             j.out_cap = static_cast<int32_t>(std::min<int64_t>((j.stop - j.start) / mw + 4, 0x7fffffff));
             j.out_off = list_entries;
             j.first_tile = static_cast<int32_t>(ev_first_tile[e]);
             j.ntiles = static_cast<int32_t>(nt);
-            j.tile_len = static_cast<int32_t>(L);
+            j.tile_len = static_cast<int32_t>(Le);
             j.ev = e;
             j.vbase = vbase;
             list_entries += j.out_cap;
@@ -467,16 +473,16 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
         const unsigned k0_grid = static_cast<unsigned>((nb_total + 1 + BS_CHUNK - 1) / BS_CHUNK);   // (+1: the end boundary)
         HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int4)));
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
-        HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(k0_grid + 1) * sizeof(int4)));
+        HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(k0_grid + 1) * 2 * sizeof(int4)));
         HIP_TRY(ctx, ctx->ev_boff.reserve(evb));
         std::memcpy(up + jb + 3 * evb, boff.data(), evb);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_boff.p, up + jb + 3 * evb, evb, hipMemcpyHostToDevice, ctx->stream));
         if (f32) hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_F32>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
-                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev,
+                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end,
                                     ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),
                                     reinterpret_cast<unsigned *>(&sm->status));
         else     hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_I16>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
-                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev,
+                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end,
                                     ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),
                                     reinterpret_cast<unsigned *>(&sm->status));
         HIP_TRY(ctx, hipGetLastError());

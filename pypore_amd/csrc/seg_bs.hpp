@@ -23,29 +23,38 @@ __device__ __forceinline__ unsigned long long u64_of(unsigned lo, unsigned hi) {
 
 // ---- K0 -----------------------------------------------------------------------------------------------
 // One thread per 8-sample block (global block index gb; event e owns blocks [ev_boff[e], ev_boff[e+1])).
-// bs[gb] = (E1, E2lo, E2hi, -): sums of the blocks of gb's chunk that precede gb (one entry past the last
-// block is written too: the end boundary of the last window).  chunk_tot[chunk] = (S1, S2lo, S2hi, max|k|).
+// bs[gb] = (E1, -, E2 as fp64): sums of the blocks of gb's chunk that precede gb (one entry past the last
+// block is written too: the end boundary of the last window).  chunk_tot[2*chunk] = (S1, -, S2 as fp64),
+// chunk_tot[2*chunk+1] = (max |k|, max |k-m|, -, -).
+// (the second moments are exact integers below 2^53 carried in fp64: the scan forms n*S2 - S1^2 there)
 // A chunk may straddle events (different m): only differences inside one event are ever formed.
 template <int DT>
 __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len,
-                                                       const int64_t *ev_boff, int n_ev, int4 *bs, int4 *ev_info,
-                                                       int4 *chunk_tot, unsigned *status)
+                                                       const int64_t *ev_boff, int n_ev, int64_t n_samples, int4 *bs,
+                                                       int4 *ev_info, int4 *chunk_tot, unsigned *status)
 {
     __shared__ double w1[4], w2[4];
-    __shared__ int smax[4];
+    __shared__ int smax[4], symax[4];
     const long long gb = blockIdx.x * 256LL + threadIdx.x;
     const long long nb_total = ev_boff[n_ev];
     unsigned bad = 0;
-    int mabs = 0;
+    int mabs = 0, ymax = 0;
     int s1 = 0;
     unsigned s2 = 0;
-    if (gb < nb_total) {
+    // event of the workgroup's first block (uniform search), then a short walk per thread
+    int e_first = 0;
+    {
+        const long long gfirst = min(blockIdx.x * 256LL, nb_total - 1);
         int lo = 0, hi = n_ev - 1;                 // event e: ev_boff[e] <= gb < ev_boff[e+1]
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (ev_boff[mid] <= gb) lo = mid; else hi = mid - 1;
+            if (ev_boff[mid] <= gfirst) lo = mid; else hi = mid - 1;
         }
-        const int e = lo;
+        e_first = lo;
+    }
+    if (gb < nb_total) {
+        int e = e_first;
+        while (ev_boff[e + 1] <= gb) ++e;           // (empty events are stepped over)
         const long long b = gb - ev_boff[e];
         const int64_t len = ev_len[e], base = ev_start[e];
         const int64_t i0 = 8 * b;
@@ -73,6 +82,21 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
                 for (int q = 0; q < 8; ++q)
                     k[q] = ((q & 1) ? (w[q >> 1] >> 16) : static_cast<int>(static_cast<short>(w[q >> 1] & 0xffff))) + c.off_counts;
             }
+        } else if (DT == PS_DTYPE_I16 && cnt == 8 && base + i0 >= 1 && base + i0 + 10 <= n_samples) {
+            // int16 block that is not 16-byte aligned (events cut out of a file trace start anywhere):
+            // dword loads, shifted by one sample when the block starts on an odd sample
+            const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+            const int *q4 = reinterpret_cast<const int *>(a & ~static_cast<uintptr_t>(3));
+            int v[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) v[q] = q4[q];            // (v[4] is inside the array: one more sample follows)
+            const bool odd = (a & 2u) != 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = odd ? static_cast<int>((static_cast<unsigned>(v[q]) >> 16) | (static_cast<unsigned>(v[q + 1]) << 16)) : v[q];
+                k[2 * q] = static_cast<int>(static_cast<short>(w & 0xffff)) + c.off_counts;
+                k[2 * q + 1] = (w >> 16) + c.off_counts;
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) k[q] = q < cnt ? load_count<DT>(c, base + i0 + q, bad) : m;
@@ -84,86 +108,86 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
             s1 += y;
             s2 += static_cast<unsigned>(y * y);
             if (q < cnt) mabs = max(mabs, k[q] < 0 ? -k[q] : k[q]);
+            ymax = max(ymax, y < 0 ? -y : y);
         }
         if (b == 0) ev_info[e] = make_int4(m, 0, static_cast<int>(ev_boff[e] & 0xffffffffLL), static_cast<int>(ev_boff[e] >> 32));
     }
     // exclusive prefix over the workgroup (exact integers in fp64)
     double i1 = static_cast<double>(s1), i2 = static_cast<double>(s2);
     wave_incl_scan2(i1, i2);
-    int mn = 0;
+    int mn = 0, mn2 = 0;
     wave_minmax(mn, mabs);                           // (mn unused) max over the wave lands in lane 63
+    wave_minmax(mn2, ymax);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) { w1[wave] = i1; w2[wave] = i2; smax[wave] = mabs; }
+    if (lane == 63) { w1[wave] = i1; w2[wave] = i2; smax[wave] = mabs; symax[wave] = ymax; }
     __syncthreads();
     double o1 = 0.0, o2 = 0.0;
     for (int w = 0; w < wave; ++w) { o1 += w1[w]; o2 += w2[w]; }
     if (gb <= nb_total) {
         const int e1 = static_cast<int>(o1 + i1) - s1;
-        const unsigned long long e2 = static_cast<unsigned long long>(o2 + i2) - s2;
-        bs[gb] = make_int4(e1, static_cast<int>(static_cast<unsigned>(e2)), static_cast<int>(static_cast<unsigned>(e2 >> 32)), 0);
+        const double e2 = (o2 + i2) - static_cast<double>(s2);
+        bs[gb] = make_int4(e1, 0, __double2loint(e2), __double2hiint(e2));
     }
     if (threadIdx.x == 255) {
-        const unsigned long long t2 = static_cast<unsigned long long>(o2 + i2);
-        chunk_tot[blockIdx.x] = make_int4(static_cast<int>(o1 + i1), static_cast<int>(static_cast<unsigned>(t2)),
-                                          static_cast<int>(static_cast<unsigned>(t2 >> 32)),
-                                          max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+        const double t2 = o2 + i2;
+        chunk_tot[2 * blockIdx.x] = make_int4(static_cast<int>(o1 + i1), 0, __double2loint(t2), __double2hiint(t2));
+        chunk_tot[2 * blockIdx.x + 1] = make_int4(max(max(smax[0], smax[1]), max(smax[2], smax[3])),
+                                                  max(max(symax[0], symax[1]), max(symax[2], symax[3])), 0, 0);
     }
     if (bad) atomicOr(status, bad);
 }
 
 // ---- screen arithmetic from window-relative sums ------------------------------------------------------
 struct BsEval { float g; f2 lg; f2 r; bool okL, okR; };
+__device__ __forceinline__ double ent2(const int4 &v) { return __hiloint2double(v.w, v.z); }
 
-// Left part: cnt = nl samples with S1 = sum (k-m), S2 = sum (k-m)^2; right part likewise.  Each side is
-// re-centred on the rounded mean of its own samples (|p1| <= n/2: D = n*p2 - p1^2 keeps kappa ~ 1).
-__device__ __forceinline__ BsEval bs_eval(int a1, unsigned long long a2, int b1, unsigned long long b2, int nl, int nr,
-                                          f2 cc, float vfloor)
+// Screened gain of the split (nl | nr) from the exact sums about m of the left part (a1, a2) and the right
+// part (b1, b2).  D = n*S2 - S1^2 is formed in fp64 (relative error kappa_m * 2^-52 with kappa_m = n*S2/D
+// below 2^24 for |k-m| < BS_WIDE and a variance above the floor), so no re-centring and no conditioning
+// guard are needed; everything after the conversion of D is fp32 (v_pk_*), as in seg_device.hpp.
+__device__ __forceinline__ BsEval bs_eval(int a1, double a2, int b1, double b2, int nl, int nr, f2 cc, float vfloor)
 {
+    const double a1d = static_cast<double>(a1), b1d = static_cast<double>(b1);
+    const double DL = fma(static_cast<double>(nl), a2, -(a1d * a1d));
+    const double DR = fma(static_cast<double>(nr), b2, -(b1d * b1d));
+    const f2 D = {static_cast<float>(DL), static_cast<float>(DR)};
     const f2 nv = {static_cast<float>(nl), static_cast<float>(nr)};
     const f2 r = {__builtin_amdgcn_rcpf(nv.x), __builtin_amdgcn_rcpf(nv.y)};
-    const int cl = __float2int_rn(static_cast<float>(a1) * r.x), cr = __float2int_rn(static_cast<float>(b1) * r.y);
-    const int p1 = a1 - __mul24(nl, cl), q1 = b1 - __mul24(nr, cr);
-    const unsigned long long p2 = a2 - static_cast<unsigned long long>(static_cast<long long>(cl) * static_cast<long long>(a1 + p1));
-    const unsigned long long q2 = b2 - static_cast<unsigned long long>(static_cast<long long>(cr) * static_cast<long long>(b1 + q1));
-    const f2 s1 = {static_cast<float>(p1), static_cast<float>(q1)};
-    const f2 s2 = {static_cast<float>(p2), static_cast<float>(q2)};
-    const f2 ns2 = nv * s2;
-    const f2 D = __builtin_elementwise_fma(-s1, s1, ns2);
-    const f2 four = {4.0f, 4.0f};
-    const f2 kg = __builtin_elementwise_fma(four, D, -ns2);          // >= 0  <=>  kappa <= 4
-    const f2 u = D * r * r;
+    const f2 u = D * r * r;                                               // variances (counts^2)
     const f2 lgu = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
     BsEval o;
     o.lg = lgu - cc;
     o.r = r;
-    o.okL = kg.x >= 0.0f && u.x >= vfloor;
-    o.okR = kg.y >= 0.0f && u.y >= vfloor;
+    o.okL = u.x >= vfloor;
+    o.okR = u.y >= vfloor;
     const f2 t = nv * o.lg;
     o.g = -(t.x + t.y);
     return o;
 }
 
-struct BsQ { int j, a1; unsigned a2lo, a2hi; };          // queued block (J-8, J): its end J, sums of [ps, J)
-struct BsC { int j, a1; unsigned a2lo, a2hi; float g; int pad; };   // contender: candidate, its exact sums, screened gain
-struct BsOff { int o1; unsigned o2lo, o2hi; int pad; };   // sums of the window's chunks before this one
+struct BsQ { int j, a1; double a2; };                     // queued block (J-8, J): its end J, sums of [ps, J)
+struct BsC { int j, a1; double a2; float g; int pad; };   // contender: candidate, its exact sums, screened gain
+struct BsOff { int o1, pad; double o2; };                 // sums of the window's chunks before this one (+ the window constant)
 constexpr int BS_NC = 64;                                 // contenders kept per window
-constexpr int BS_QN = 192;                                // queued blocks; a drain is forced above BS_QN - 64
+constexpr int BS_G = 5;                                   // rows per group (loads in flight)
+constexpr int BS_QN = 64 * BS_G + 64;                     // queued blocks; a drain is forced when a group may not fit
+constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
 static_assert(sizeof(QEnt) * SharedT<64>::QN >= sizeof(BsQ) * BS_QN + sizeof(BsC) * BS_NC + 64 * 16 + 64 * sizeof(BsOff),
               "SharedT<64>::q too small");
 
 // Exact (reference-order, fp64) gain of one candidate from its exact integer sums about m.
-__device__ __forceinline__ double bs_exact_gain(const DevCfg &c, int m, int a1, unsigned long long a2, int T1,
-                                                unsigned long long T2, int nl, int n, double var_summed)
+__device__ __forceinline__ double bs_exact_gain(const DevCfg &c, int m, int a1, double a2, int T1, double T2, int nl, int n,
+                                                double var_summed)
 {
     const double dm = static_cast<double>(m);
     // uncentred sums: sum k = a1 + nl*m ; sum k^2 = a2 + 2*m*a1 + nl*m^2   (exact integers below 2^53)
     const double l1 = static_cast<double>(a1) + static_cast<double>(nl) * dm;
-    const double l2 = static_cast<double>(a2) + 2.0 * dm * static_cast<double>(a1) + static_cast<double>(nl) * dm * dm;
+    const double l2 = a2 + 2.0 * dm * static_cast<double>(a1) + static_cast<double>(nl) * dm * dm;
     const int nr = n - nl;
     const int b1 = T1 - a1;
-    const unsigned long long b2 = T2 - a2;
+    const double b2 = T2 - a2;
     const double r1 = static_cast<double>(b1) + static_cast<double>(nr) * dm;
-    const double r2 = static_cast<double>(b2) + 2.0 * dm * static_cast<double>(b1) + static_cast<double>(nr) * dm * dm;
+    const double r2 = b2 + 2.0 * dm * static_cast<double>(b1) + static_cast<double>(nr) * dm * dm;
     const double vl = ref_var(l1, l2, nl, c.q, c.q2), vr = ref_var(r1, r2, nr, c.q, c.q2);
     return ref_gain(var_summed, nl, vl, nr, vr);
 }
@@ -172,23 +196,18 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)      // set 
 {
     return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
 }
-// Value of lane-1; lane 0 receives `first` (wave_shr:1, the GFX9 whole-wave shift).
-__device__ __forceinline__ int from_lane_below(int x, int first)
-{
-    return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ float from_lane_below(float x, float first)
-{
-    return __int_as_float(from_lane_below(__float_as_int(x), __float_as_int(first)));
-}
+// Value of lane-1 (wave_shr:1, the GFX9 whole-wave shift); lane 0 keeps its own.
+__device__ __forceinline__ int from_lane_below(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float from_lane_below(float x) { return __int_as_float(from_lane_below(__float_as_int(x))); }
 
 // One wave scans the window [ps, pe) of event `ev` (samples at c.samples[base + .]).
 //
-// Phase 0 (every window): lane L takes block boundaries t = L, L+64, ... (J = g0 + 8t): sums of
-// [ps, J) from the K0 prefix, boundary candidate evaluated, the block (J-8, J) bounded with the
-// neighbouring lane's left-side values and queued in LDS if it survives (slots from a ballot, no
-// atomics); the queue is drained -- interior candidates evaluated from raw samples -- when it may
-// overflow and at the end.  Top-2 over the wave decides.
+// Phase 0 (every window): in row r lane L takes block boundary t = 63 r + L (J = g0 + 8t; lane 0 repeats
+// the previous row's last boundary so that every block finds its left neighbour one lane below): sums of
+// [ps, J) from the K0 prefix, boundary candidate evaluated, the block (J-8, J) bounded with the lane
+// below's left-side values and queued in LDS if it survives (slots from a ballot, no atomics); the queue
+// is drained -- interior candidates evaluated from raw samples -- when it may overflow and at the end.
+// Top-2 over the wave decides.
 // Phase 1 (ambiguous windows only, ~1 %): the same sweep with the final maximum known collects the
 // contenders (screened gain within 3 delta of the decision level) and the reference's fp64 arithmetic
 // picks among them.  A whole-window fp64 scan remains for guard failures and contender overflow.
@@ -210,18 +229,19 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     const long long gb0 = ((static_cast<long long>(static_cast<unsigned>(info.w)) << 32) | static_cast<unsigned>(info.z)) + (g0 >> 3);
     const int4 *bsw = c.bsum + gb0;                                    // bsw[t]: chunk prefix at boundary t = 0..nblk
     const int c0 = static_cast<int>(gb0 >> 8), nch = static_cast<int>((gb0 + nblk) >> 8) - c0 + 1;     // chunks touched (<= 45)
+    const int gbl = static_cast<int>(gb0 & 255);                       // chunk of boundary t: (gbl + t) >> 8
     PS_STAMP_AT(wk, 5);                                // (diagnostic) entry, event info
     // everything the window needs before its first boundary, issued together
     const int nh = g0 - ps, nt = pe - g1;              // ragged head [ps, g0) and tail [g1, pe): <= 7 raw samples each
     int yht = 0;
     if (lane < nh) yht = load_count<DT>(c, base + ps + lane, bad) - m;
     if (lane >= 32 && lane - 32 < nt) yht = load_count<DT>(c, base + g1 + (lane - 32), bad) - m;
-    int4 ct = make_int4(0, 0, 0, 0);
-    if (lane < nch) ct = c.chunk_tot[c0 + lane];
+    int4 ct = make_int4(0, 0, 0, 0), cm = make_int4(0, 0, 0, 0);
+    if (lane < nch) { ct = c.chunk_tot[2 * (c0 + lane)]; cm = c.chunk_tot[2 * (c0 + lane) + 1]; }
     const int4 e0 = bsw[0], eN = bsw[nblk];
     const int nbnd = nblk + 1;
-    const int rows = (nbnd + 63) >> 6;
-    const int4 row0 = bsw[min(lane, nblk)], row1 = bsw[min(64 + lane, nblk)];
+    const int rows = (nbnd - 1 + BS_STRIDE - 1) / BS_STRIDE;           // nbnd >= 5
+    const int4 row0 = bsw[min(lane, nblk)];
     const int tS = min(nblk, lane * rows);             // one sampled boundary per lane, spread over the window
     const int4 smp = bsw[tS];
     // head/tail sums (one scan: lanes 0..31 head, 32..63 tail), chunk offsets (exclusive scan of the totals)
@@ -229,33 +249,33 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     wave_incl_scan2(hs1, hs2);
     const double H1d = __shfl(hs1, 31), H2d = __shfl(hs2, 31);
     const double TL1d = __shfl(hs1, 63) - H1d, TL2d = __shfl(hs2, 63) - H2d;
-    const double cs1 = static_cast<double>(ct.x), cs2 = static_cast<double>(u64_of(ct.y, ct.z));
+    const double cs1 = static_cast<double>(ct.x), cs2 = ent2(ct);
     double ci1 = cs1, ci2 = cs2;
     wave_incl_scan2(ci1, ci2);
-    int mabs = ct.w, mn_unused = 0;
-    wave_minmax(mn_unused, mabs);
+    int mabs = cm.x, nymax = -cm.y;                     // max |k| and max |k-m| over the chunks touched
+    wave_minmax(nymax, mabs);                          // (the min slot carries -max |k-m|)
     mabs = __shfl(mabs, 63);
+    const float ymaxf = static_cast<float>(-__shfl(nymax, 63));
     BsQ *queue = reinterpret_cast<BsQ *>(sh.q);
     BsC *cont = reinterpret_cast<BsC *>(queue + BS_QN);
     int4 *ybuf = reinterpret_cast<int4 *>(cont + BS_NC);               // 64 staged blocks of 8 int16 offsets
     BsOff *coff = reinterpret_cast<BsOff *>(ybuf + 64);
+    // a(t) = E[t] + off[chunk(t)] : sums of [ps, g0 + 8t) about m  (off includes the head and -E[0])
+    const int K1 = static_cast<int>(H1d) - e0.x;
+    const double K2 = H2d - ent2(e0);
     __syncthreads();                                  // previous user of sh.q (this wave) is done
     {
-        const unsigned long long x2 = static_cast<unsigned long long>(ci2 - cs2);
         BsOff o;
-        o.o1 = static_cast<int>(ci1 - cs1); o.o2lo = static_cast<unsigned>(x2); o.o2hi = static_cast<unsigned>(x2 >> 32); o.pad = 0;
+        o.o1 = static_cast<int>(ci1 - cs1) + K1; o.pad = 0; o.o2 = (ci2 - cs2) + K2;
         coff[lane] = o;
     }
     __syncthreads();
     const BsOff oN = coff[nch - 1];
-    // a(t) = E[t] + off[chunk(t)] + K : sums of [ps, g0 + 8t) about m
-    const int K1 = static_cast<int>(H1d) - e0.x;
-    const unsigned long long K2 = static_cast<unsigned long long>(H2d) - u64_of(e0.y, e0.z);
-    const int T1 = eN.x + oN.o1 + K1 + static_cast<int>(TL1d);
-    const unsigned long long T2 = u64_of(eN.y, eN.z) + u64_of(oN.o2lo, oN.o2hi) + K2 + static_cast<unsigned long long>(TL2d);
-    const double T1d = static_cast<double>(T1), T2d = static_cast<double>(T2);       // window totals about m
+    const int T1 = eN.x + oN.o1 + static_cast<int>(TL1d);
+    const double T2 = ent2(eN) + oN.o2 + TL2d;                        // window totals about m
+    const double T1d = static_cast<double>(T1);
     const double dn = static_cast<double>(n);
-    const double Dtot = dn * T2d - T1d * T1d;
+    const double Dtot = dn * T2 - T1d * T1d;
     if (!(Dtot > 0.0)) {
         if (lane == 0) wk.exact += 1;
         return scan_exact<64, DT>(c, nullptr, base + ps, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);
@@ -268,29 +288,28 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     const float dthr = dlt + 3.0e-6f * static_cast<float>(n) + 1.0e-6f * fabsf(thr_log2);
     const float nf = static_cast<float>(n);
     const float LOG2E = 1.4426950408889634f;
-    const float vfloor = static_cast<float>(mabs) * static_cast<float>(mabs) * 1.0e-9f;
-    PS_STAMP_AT(wk, 0);                                // loads, totals, wave scans
+    // variance floor: the reference's own fp64 rounding (mabs^2 * 2^-52 * n) and the fp64 D above (kappa_m <= 2^26)
+    const float vfloor = fmaxf(static_cast<float>(mabs) * static_cast<float>(mabs) * 1.0e-9f, ymaxf * ymaxf * 1.5e-8f);
+    const unsigned crange = static_cast<unsigned>(cand_hi - cand_lo);
 
     int result = -2;
     bool anyflag = false;
     float Tprune, Tc = INFINITY;
     {
         // pruning level from the sampled boundary candidates
-        const int J = g0 + 8 * tS, nl = J - ps, nr = pe - J;
-        const BsOff off = coff[min(static_cast<int>((gb0 + tS) >> 8) - c0, nch - 1)];
-        const int a1 = smp.x + off.o1 + K1;
-        const unsigned long long a2 = u64_of(smp.y, smp.z) + u64_of(off.o2lo, off.o2hi) + K2;
-        float bm = -INFINITY;
-        if (J >= cand_lo && J <= cand_hi) {
-            const BsEval e = bs_eval(a1, a2, T1 - a1, T2 - a2, nl, nr, cc, vfloor);
-            if (e.okL && e.okR) bm = e.g;
-        }
+        const int J = g0 + 8 * tS;
+        const BsOff off = coff[(gbl + tS) >> 8];
+        const int a1 = smp.x + off.o1;
+        const double a2 = ent2(smp) + off.o2;
+        const BsEval e = bs_eval(a1, a2, T1 - a1, T2 - a2, max(J - ps, 1), max(pe - J, 1), cc, vfloor);
+        float bm = (static_cast<unsigned>(J - cand_lo) <= crange && e.okL && e.okR) ? e.g : -INFINITY;
 #define PS_STEP(CTRL, RM) { bm = fmaxf(bm, dpp_movf<CTRL, RM>(-INFINITY, bm)); }
         PS_DPP_STEPS(PS_STEP)
 #undef PS_STEP
         bm = __shfl(bm, 63);
         Tprune = fmaxf(thr_log2 - dthr, bm - 2.0f * dlt) - 2.0f * dlt;
     }
+    PS_STAMP_AT(wk, 0);                                // loads, totals, wave scans, pruning level
     int ccount = 0;
 #define PS_COLLECT(COND, G, JJ, A1, A2)                                                                       \
     {                                                                                                         \
@@ -299,8 +318,7 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         if (cm_) {                                                                                            \
             const int cs_ = ccount + lanes_below(cm_);                                                        \
             if (cp_ && cs_ < BS_NC) {                                                                         \
-                BsC e_; e_.j = (JJ); e_.a1 = (A1); e_.a2lo = static_cast<unsigned>(A2);                       \
-                e_.a2hi = static_cast<unsigned>((A2) >> 32); e_.g = (G); e_.pad = 0; cont[cs_] = e_;          \
+                BsC e_; e_.j = (JJ); e_.a1 = (A1); e_.a2 = (A2); e_.g = (G); e_.pad = 0; cont[cs_] = e_;      \
             }                                                                                                 \
             ccount += __popcll(cm_);                                                                          \
         }                                                                                                     \
@@ -309,111 +327,127 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         Top2 top = {-INFINITY, -INFINITY, -1};
         unsigned flag = 0;
         int qcount = 0;
-        float p63_lg = 0.0f, p63_r = 0.0f;            // left-side values of the previous row's last boundary
-        int p63_ok = 0;
-        int4 cur = row0, nx1 = row1, nx2;
-        for (int row = 0;; ++row) {
-            if (row >= rows || qcount > BS_QN - 64) {
-                // drain: interior candidates of the queued blocks
+        auto drain = [&]() {
+            // drain: interior candidates of the queued blocks
+            __syncthreads();
+            PS_STAMP_AT(wk, 1);                    // boundary sweep
+            for (int r = 0; r < qcount; r += 64) {
+                // (a) one queued block per lane: its 8 samples, as int16 offsets from m, go to LDS
+                const int nb = min(64, qcount - r);
+                if (lane < nb) {
+                    const int64_t gq = base + queue[r + lane].j - 8;
+                    int y[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) y[w] = load_count<DT>(c, gq + w, bad) - m;
+                    int4 pk;
+                    pk.x = (y[0] & 0xffff) | (y[1] << 16); pk.y = (y[2] & 0xffff) | (y[3] << 16);
+                    pk.z = (y[4] & 0xffff) | (y[5] << 16); pk.w = (y[6] & 0xffff) | (y[7] << 16);
+                    ybuf[lane] = pk;
+                }
                 __syncthreads();
-                PS_STAMP_AT(wk, 1);                    // boundary sweep
-                for (int r = 0; r < qcount; r += 64) {
-                    // (a) one queued block per lane: its 8 samples, as int16 offsets from m, go to LDS
-                    const int nb = min(64, qcount - r);
-                    if (lane < nb) {
-                        const int64_t gq = base + queue[r + lane].j - 8;
-                        int y[8];
+                // (b) one (block, offset) pair per lane: candidate J - u, u = 1..7 (the block's last u samples removed)
+                for (int r0 = 0; r0 < nb * 7; r0 += 64) {
+                    const int idx = r0 + lane;
+                    const bool valid = idx < nb * 7;
+                    const int eidx = valid ? idx / 7 : 0, u = idx - (idx / 7) * 7 + 1;
+                    const BsQ q = queue[r + eidx];
+                    const int4 pk = ybuf[eidx];
+                    const int J = q.j - u;
+                    const int w4[4] = {pk.x, pk.y, pk.z, pk.w};
+                    int x1 = q.a1;
+                    unsigned sq = 0;                        // 7 * BS_WIDE^2 < 2^32
 #pragma unroll
-                        for (int w = 0; w < 8; ++w) y[w] = load_count<DT>(c, gq + w, bad) - m;
-                        int4 pk;
-                        pk.x = (y[0] & 0xffff) | (y[1] << 16); pk.y = (y[2] & 0xffff) | (y[3] << 16);
-                        pk.z = (y[4] & 0xffff) | (y[5] << 16); pk.w = (y[6] & 0xffff) | (y[7] << 16);
-                        ybuf[lane] = pk;
+                    for (int w = 1; w < 8; ++w) {
+                        const int y = (w & 1) ? (w4[w >> 1] >> 16) : static_cast<int>(static_cast<short>(w4[w >> 1] & 0xffff));
+                        if (8 - w <= u) { x1 -= y; sq += static_cast<unsigned>(y * y); }
                     }
-                    __syncthreads();
-                    // (b) one (block, offset) pair per lane: candidate J - u, u = 1..7 (the block's last u samples removed)
-                    for (int r0 = 0; r0 < nb * 7; r0 += 64) {
-                        const int idx = r0 + lane;
-                        const bool valid = idx < nb * 7;
-                        const int eidx = valid ? idx / 7 : 0, u = idx - (idx / 7) * 7 + 1;
-                        const BsQ q = queue[r + eidx];
-                        const int4 pk = ybuf[eidx];
-                        const int J = q.j - u;
-                        bool cpush = false;
-                        float gq = -INFINITY;
-                        int x1 = q.a1;
-                        unsigned long long x2 = u64_of(q.a2lo, q.a2hi);
-                        if (valid && J >= cand_lo && J <= cand_hi) {
-                            const int w4[4] = {pk.x, pk.y, pk.z, pk.w};
-                            unsigned sq = 0;                    // 7 * BS_WIDE^2 < 2^32
-#pragma unroll
-                            for (int w = 1; w < 8; ++w) {
-                                const int y = (w & 1) ? (w4[w >> 1] >> 16) : static_cast<int>(static_cast<short>(w4[w >> 1] & 0xffff));
-                                if (8 - w <= u) { x1 -= y; sq += static_cast<unsigned>(y * y); }
-                            }
-                            x2 -= sq;
-                            const BsEval o = bs_eval(x1, x2, T1 - x1, T2 - x2, J - ps, pe - J, cc, vfloor);
-                            if (o.okL && o.okR) { top2_push(top, o.g, J - ps); gq = o.g; cpush = o.g >= Tc; } else flag = 1;
-                        }
-                        if (phase) PS_COLLECT(cpush, gq, J, x1, x2)
-                    }
-                    __syncthreads();
+                    const double x2 = q.a2 - static_cast<double>(sq);
+                    const BsEval o = bs_eval(x1, x2, T1 - x1, T2 - x2, J - ps, pe - J, cc, vfloor);   // 1 <= J - ps < n here
+                    const bool inr = valid && static_cast<unsigned>(J - cand_lo) <= crange;
+                    const bool ok = o.okL && o.okR;
+                    const float gq = (inr && ok) ? o.g : -INFINITY;
+                    top2_push(top, gq, J - ps);
+                    flag |= static_cast<unsigned>(inr && !ok);
+                    if (phase) PS_COLLECT(gq >= Tc, gq, J, x1, x2)
                 }
-                qcount = 0;
-                PS_STAMP_AT(wk, 2);                    // drain
-                if (row >= rows) break;
+                __syncthreads();
             }
-            nx2 = bsw[min((row + 2) * 64 + lane, nblk)];
-            const int t = row * 64 + lane;
-            const bool act = t < nbnd;
-            const int J = g0 + 8 * t, nl = J - ps, nr = pe - J;
-            const BsOff off = coff[min(static_cast<int>((gb0 + t) >> 8) - c0, nch - 1)];
-            const int a1 = cur.x + off.o1 + K1;
-            const unsigned long long a2 = u64_of(cur.y, cur.z) + u64_of(off.o2lo, off.o2hi) + K2;
-            BsEval e;
-            e.g = -INFINITY; e.okL = false; e.okR = false; e.lg = {0.f, 0.f}; e.r = {0.f, 0.f};
-            bool cpush = false;
-            if (act && nl >= 1 && nr >= 1) {
-                e = bs_eval(a1, a2, T1 - a1, T2 - a2, nl, nr, cc, vfloor);
-                if (J >= cand_lo && J <= cand_hi) {
-                    if (e.okL && e.okR) { top2_push(top, e.g, nl); cpush = e.g >= Tc; } else flag = 1;
-                }
-            }
+            qcount = 0;
+            PS_STAMP_AT(wk, 2);                        // drain
+        };
+        // per-lane running values of the row sweep: boundary J, its chunk index source, nl as fp32 / fp64
+        int Jr = g0 + 8 * lane, gtr = gbl + lane;
+        float nlf = static_cast<float>(Jr - ps);
+        double nld = static_cast<double>(Jr - ps);
+        auto do_row = [&](bool first_row, const int4 &cur) {
+            const int J = Jr, nl = J - ps;
+            const BsOff off = coff[min(gtr >> 8, nch - 1)];
+            const int a1 = cur.x + off.o1;
+            const double a2 = ent2(cur) + off.o2;
+            // screened gain of the boundary (bs_eval, with the running nl and the right side from the totals)
+            const double a1d = static_cast<double>(a1), b1d = T1d - a1d;
+            const double DL = fma(nld, a2, -(a1d * a1d));
+            const double DR = fma(dn - nld, T2 - a2, -(b1d * b1d));
+            const float nrf = nf - nlf;
+            const f2 D = {static_cast<float>(DL), static_cast<float>(DR)};
+            const f2 nv = {nlf, nrf};
+            const f2 rr = {__builtin_amdgcn_rcpf(nlf), __builtin_amdgcn_rcpf(nrf)};
+            const f2 u = D * rr * rr;
+            const f2 lgu = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+            const f2 lg = lgu - cc;
+            const f2 tt = nv * lg;
+            const float g = -(tt.x + tt.y);
+            const bool valid = static_cast<unsigned>(nl - 1) < static_cast<unsigned>(n - 1);    // 1 <= nl <= n-1 (false past the end)
+            const bool okL = valid && u.x >= vfloor, okR = valid && u.y >= vfloor;
+            // the boundary itself as a candidate (lane 0 of rows > 0 repeats a boundary already counted)
+            const bool inr = static_cast<unsigned>(J - cand_lo) <= crange && (lane != 0 || first_row);
+            const float ge = (inr && okL && okR) ? g : -INFINITY;
+            top2_push(top, ge, nl);
+            flag |= static_cast<unsigned>(inr && !(okL && okR));
             // the block (J - 8, J): left side bounded from boundary t-1 (the lane below), right side from this one
-            const float aL = from_lane_below(e.lg.x, p63_lg), rlb = from_lane_below(e.r.x, p63_r);
-            const bool pokL = from_lane_below(static_cast<int>(e.okL), p63_ok) != 0;
-            bool keep = false;
-            if (act && t >= 1) {
-                const int P = J - 8;
-                const int ilo = max(P + 1, cand_lo), ihi = min(J - 1, cand_hi);
-                if (ilo <= ihi) {
-                    keep = true;
-                    if (pokL && e.okR && P - ps >= 1) {
-                        const float nl0f = static_cast<float>(P - ps), nlef = static_cast<float>(J - 1 - ps);
-                        const float nr0f = nf - nl0f, nref = nf - nlef;
-                        const float bR = e.lg.y, rre = e.r.y;
-                        const float cR0 = bR - 8.0f * LOG2E * rre;
-                        const float cR1 = bR - LOG2E * rre;
-                        const float cL1 = aL - 7.0f * LOG2E * rlb;
-                        const float h0 = -fmaf(nl0f, aL, nr0f * cR0);
-                        const float h1 = -fmaf(nlef, cL1, nref * cR1);
-                        keep = !(fmaxf(h0, h1) < Tprune);
-                    }
-                }
-            }
+            const float aL = from_lane_below(lg.x), rlb = from_lane_below(rr.x);
+            const bool pokL = from_lane_below(static_cast<int>(okL)) != 0;
+            const bool blk = lane >= 1 && static_cast<unsigned>(J - 1 - cand_lo) <= crange + 6u;   // has interior candidates
+            const float nl0f = nlf - 8.0f, nlef = nlf - 1.0f;
+            const float nr0f = nrf + 8.0f, nref = nrf + 1.0f;
+            const float bR = lg.y, rre = rr.y;
+            const float cR0 = bR - 8.0f * LOG2E * rre;
+            const float cR1 = bR - LOG2E * rre;
+            const float cL1 = aL - 7.0f * LOG2E * rlb;
+            const float h0 = -fmaf(nl0f, aL, nr0f * cR0);
+            const float h1 = -fmaf(nlef, cL1, nref * cR1);
+            const bool pruned = pokL && okR && nl >= 9 && fmaxf(h0, h1) < Tprune;
+            const bool keep = blk && !pruned;
             const unsigned long long km = __ballot(keep);
             if (km) {
                 if (keep) {
                     BsQ q;
-                    q.j = J; q.a1 = a1; q.a2lo = static_cast<unsigned>(a2); q.a2hi = static_cast<unsigned>(a2 >> 32);
+                    q.j = J; q.a1 = a1; q.a2 = a2;
                     queue[qcount + lanes_below(km)] = q;
                 }
                 qcount += __popcll(km);
             }
-            if (phase) PS_COLLECT(cpush, e.g, J, a1, a2)
-            p63_lg = __shfl(e.lg.x, 63); p63_r = __shfl(e.r.x, 63); p63_ok = __shfl(static_cast<int>(e.okL), 63);
-            cur = nx1; nx1 = nx2;
+            if (phase) PS_COLLECT(ge >= Tc, ge, J, a1, a2)
+            Jr += 8 * BS_STRIDE; gtr += BS_STRIDE; nlf += 8.0f * BS_STRIDE; nld += 8.0 * BS_STRIDE;
+        };
+        // rows in groups of BS_G, double-buffered: the next group's loads are in flight while this one is evaluated
+        int4 ga[BS_G], gb[BS_G];
+#pragma unroll
+        for (int i = 0; i < BS_G; ++i) ga[i] = i == 0 ? row0 : bsw[min(i * BS_STRIDE + lane, nblk)];
+        for (int r0 = 0; r0 < rows; r0 += 2 * BS_G) {
+            if (qcount > BS_QN - 64 * BS_G) drain();
+#pragma unroll
+            for (int i = 0; i < BS_G; ++i) gb[i] = bsw[min((r0 + BS_G + i) * BS_STRIDE + lane, nblk)];
+#pragma unroll
+            for (int i = 0; i < BS_G; ++i) do_row(r0 + i == 0, ga[i]);     // (rows past the end are inert)
+            if (r0 + BS_G >= rows) break;
+            if (qcount > BS_QN - 64 * BS_G) drain();
+#pragma unroll
+            for (int i = 0; i < BS_G; ++i) ga[i] = bsw[min((r0 + 2 * BS_G + i) * BS_STRIDE + lane, nblk)];
+#pragma unroll
+            for (int i = 0; i < BS_G; ++i) do_row(false, gb[i]);
         }
+        drain();
         if (phase == 1) break;
         // wave top-2 (DPP) and flags (ballot)
 #define PS_STEP(CTRL, RM) { const float ob = dpp_movf<CTRL, RM>(-INFINITY, top.b), os = dpp_movf<CTRL, RM>(-INFINITY, top.s); \
@@ -443,12 +477,12 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         __syncthreads();                              // contender stores visible to the other lanes
         const double var_summed = static_cast<double>(n) *
             log(ref_var(T1d + dn * static_cast<double>(m),
-                        T2d + 2.0 * static_cast<double>(m) * T1d + dn * static_cast<double>(m) * static_cast<double>(m), n, c.q, c.q2));
+                        T2 + 2.0 * static_cast<double>(m) * T1d + dn * static_cast<double>(m) * static_cast<double>(m), n, c.q, c.q2));
         double eg = thresh;
         int ei = -1;
         if (lane < ccount) {
             const BsC e = cont[lane];
-            const double gx = bs_exact_gain(c, m, e.a1, u64_of(e.a2lo, e.a2hi), T1, T2, e.j - ps, n, var_summed);
+            const double gx = bs_exact_gain(c, m, e.a1, e.a2, T1, T2, e.j - ps, n, var_summed);
             if (gx > eg) { eg = gx; ei = e.j; }
         }
 #pragma unroll

@@ -87,7 +87,7 @@ struct QEnt { int j, jend, p1, r1; unsigned p2, r2; int cL, cR; };
 template <int NT> struct SharedT {
     static constexpr int NWV = NT / 64;
     static constexpr int OB = NT == 64 ? 64 : OBUF;          // buffered outputs
-    static constexpr int QN = NT == 64 ? 208 : QMAX;         // queued blocks
+    static constexpr int QN = NT == 64 ? 304 : QMAX;         // queued blocks
     static constexpr int LN = NT == 64 ? 128 : LST_MAX;      // cached downstream anchors
     static constexpr int SN = NT == 64 ? 64 : LDS_STACK;     // DFS stack entries before spilling
     double wsum1[NWV], wsum2[NWV];
@@ -117,14 +117,14 @@ struct Work {
     long long windows, cands, exact;
     long long dbg[4];        // verify mode: first disagreement (ps, pe, screen result, exact result)
 #ifdef PS_STAMP
-    long long t0, ph[12];
+    long long t0, ph[12], tbeg;
 #endif
 };
 // In-kernel phase stamps (diagnostic build only, -DPS_STAMP): thread 0 accumulates s_memtime
 // deltas per phase of the window scan; never compiled into the product library.
 #ifdef PS_STAMP
 #define PS_STAMP_AT(wk, i) do { if (threadIdx.x == 0) { long long t_ = clock64(); (wk).ph[i] += t_ - (wk).t0; (wk).t0 = t_; } } while (0)
-#define PS_WORK_INIT {0, 0, 0, {0, 0, 0, 0}, clock64(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}
+#define PS_WORK_INIT {0, 0, 0, {0, 0, 0, 0}, clock64(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clock64()}
 #else
 #define PS_STAMP_AT(wk, i) do { } while (0)
 #define PS_WORK_INIT {0, 0, 0, {0, 0, 0, 0}}
@@ -933,7 +933,7 @@ __device__ __forceinline__ int left_child_j0(int start, int split, int W, int ha
     return d < 0 ? 0 : static_cast<int>(d / half) + 1;
 }
 
-__device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *status, unsigned long long *work)
+__device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *status, unsigned long long *work, int which = -1)
 {
     if (bad) atomicOr(status, bad);
     if (threadIdx.x == 0) {
@@ -942,7 +942,15 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
         if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
         if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
 #ifdef PS_STAMP
+#ifdef PS_STAMP_K
+        if (which == PS_STAMP_K)
+#endif
         for (int i = 0; i < 12; ++i) atomicAdd(&work[4 + i], static_cast<unsigned long long>(wk.ph[i]));
+        if (which >= 0) {                      // longest workgroup (cycles, windows) and the sum of lifetimes per kernel
+            atomicMax(&work[16 + 3 * which], static_cast<unsigned long long>(clock64() - wk.tbeg));
+            atomicAdd(&work[17 + 3 * which], static_cast<unsigned long long>(wk.windows));
+            atomicAdd(&work[18 + 3 * which], static_cast<unsigned long long>(clock64() - wk.tbeg));
+        }
 #endif
     }
 }
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(
     if (dense == nullptr) {                            // device-stitch pipeline: the list stays in its own region
         for (int i = flushed + threadIdx.x; i < cnt; i += NT) out[i] = sh.obuf[i - flushed];
         if (threadIdx.x == 0) meta[blockIdx.x] = make_int4(cnt, ended, 0, 0);
-        flush(bad, wk, status, work);
+        flush(bad, wk, status, work, 0);
         return;
     }
     if (threadIdx.x == 0) {
@@ -996,7 +1004,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(
     __syncthreads();
     const int pos = sh.bcast;
     for (int i = threadIdx.x; i < cnt; i += NT) dense[pos + i] = i < flushed ? out[i] : sh.obuf[i - flushed];
-    flush(bad, wk, status, work);
+    flush(bad, wk, status, work, 0);
 }
 
 // ---- phase 1b: bridge a seam -------------------------------------------------------------------
@@ -1063,7 +1071,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
     __syncthreads();
     for (int i = threadIdx.x; i < cnt; i += NT) bridges[static_cast<int64_t>(g) * BR_MAX + i] = sh.obuf[i];
     if (threadIdx.x == 0) bmeta[g] = make_int4(cnt, jt, ji, st);
-    flush(bad, wk, status, work);
+    flush(bad, wk, status, work, 1);
 }
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(D
     __syncthreads();
     for (int i = flushed + threadIdx.x; i < cnt; i += NT) out[i] = obuf[i - flushed];
     if (threadIdx.x == 0) counts[blockIdx.x] = cnt;
-    flush(bad, wk, status, work);
+    flush(bad, wk, status, work, 2);
 }
 
 // ---- single scans for the API-completeness entry points -----------------------------------------
