@@ -159,14 +159,16 @@ template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsig
     return PS_OK;
 }
 
-template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
+template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, size_t n_jobs,
+                                          const AsmHeader *d_hdr)
 {
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
                        ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
-                       ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+                       ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
+                       static_cast<long long>(n_jobs), d_hdr);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -268,33 +270,41 @@ int find_in(const TileList &t, int32_t pos)
 }  // namespace
 
 namespace {
+constexpr int RC_FALLBACK = 1;      // internal: the device stitch gave up, use the host-stitch pipeline
+constexpr int RC_WIDE = 2;          // internal: counts too wide for the block sums, use the LDS-window scan
 // Phase 3 onwards.  Expects tree_jobs / items / first_item / ev_off populated on the device.
+// d_hdr == nullptr: n_tj / n_items are the exact counts (host stitch).  Otherwise they are upper bounds used
+// to size the launches and the kernels read the counts from *d_hdr on the device; the header and the status
+// word are then checked after the single synchronisation at the end (*hdr_out receives the header).
 int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, int32_t n_ev,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
-                        std::chrono::steady_clock::time_point t_begin)
+                        std::chrono::steady_clock::time_point t_begin, const AsmHeader *d_hdr = nullptr,
+                        AsmHeader *hdr_out = nullptr, bool wide_check = false)
 {
     int rc;
     const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_tj) {
-        const unsigned g = static_cast<unsigned>(n_tj);
+        const unsigned g = static_cast<unsigned>(d_hdr ? std::min<size_t>(n_tj, 16384) : n_tj);
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
         int lrc = cfg.bsum != nullptr
-                      ? (f32 ? launch_tree<64, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<64, PS_DTYPE_I16>(ctx, cfg, g, sm))
+                      ? (f32 ? launch_tree<64, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<64, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
                   : ctx->tree_nt == 512
-                      ? (f32 ? launch_tree<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<512, PS_DTYPE_I16>(ctx, cfg, g, sm))
-                      : (f32 ? launch_tree<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_tree<256, PS_DTYPE_I16>(ctx, cfg, g, sm));
+                      ? (f32 ? launch_tree<512, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<512, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
+                      : (f32 ? launch_tree<256, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<256, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr));
         if (lrc) return lrc;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
-                       ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>());
+                       ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>(), d_hdr);
     HIP_TRY(ctx, hipGetLastError());
     if (n_items) {
-        hipLaunchKernelGGL(gather_kernel, dim3(static_cast<unsigned>(n_items)), dim3(64), 0, ctx->stream,
+        const unsigned gg = static_cast<unsigned>(d_hdr ? std::min<int64_t>(n_items, 16384) : n_items);
+        hipLaunchKernelGGL(gather_kernel, dim3(gg), dim3(64), 0, ctx->stream,
                            ctx->items.as<Item>(), ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(),
-                           ctx->tree_scratch.as<int32_t>(), ctx->item_pos.as<int64_t>(), n_items, d_bounds, cap, ctx->d_is_spine);
+                           ctx->tree_scratch.as<int32_t>(), ctx->item_pos.as<int64_t>(), n_items, d_bounds, cap, ctx->d_is_spine,
+                           d_hdr);
         HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(event_offsets_kernel, dim3((n_ev + 1 + 255) / 256), dim3(256), 0, ctx->stream,
@@ -303,11 +313,18 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     HIP_TRY(ctx, ctx->h_meta.reserve(evb));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    if (d_hdr) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr.p, d_hdr, sizeof(AsmHeader), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(h_bounds_off, ctx->h_meta.p, evb);
     const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+    if (wide_check && (static_cast<unsigned>(hs.status) & ST_WIDE_RANGE)) return RC_WIDE;    // counts too wide for the block sums
     rc = check_status(ctx, static_cast<unsigned>(hs.status));
     if (rc) return rc;
+    if (d_hdr) {
+        const AsmHeader hd = *ctx->h_hdr.as<AsmHeader>();
+        if (hdr_out) *hdr_out = hd;
+        if (hd.fail) return RC_FALLBACK;
+    }
     ctx->counters[0] = static_cast<int64_t>(hs.work0);
     ctx->counters[1] = static_cast<int64_t>(hs.work1);
     ctx->counters[5] = static_cast<int64_t>(hs.work2 & 0xffffffffULL) + static_cast<int64_t>(hs.work2 >> 32);   // exact decisions
@@ -356,8 +373,6 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
 }
 
 
-constexpr int RC_FALLBACK = 1;
-constexpr int RC_WIDE = 2;
 
 template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
@@ -527,26 +542,23 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
                        ctx->sp_off.as<long long>(), ctx->first_item.as<int64_t>(), ctx->asm_hdr.as<AsmHeader>(),
                        static_cast<long long>(max_items), use_lds);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr.p, ctx->asm_hdr.p, sizeof(AsmHeader), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
-    if (use_bs && (static_cast<unsigned>(hs.status) & ST_WIDE_RANGE)) return RC_WIDE;     // counts too wide for the block sums
-    int rc = check_status(ctx, static_cast<unsigned>(hs.status));
-    if (rc) return rc;
-    const AsmHeader hd = *ctx->h_hdr.as<AsmHeader>();
-    if (hd.fail) return RC_FALLBACK;
-    if (hd.n_items) {
-        hipLaunchKernelGGL(assemble_items_kernel, dim3(static_cast<unsigned>((hd.n_items + 255) / 256)), dim3(256), 0,
+    // no host round trip here: the downstream kernels read the item count from the header on the device
+    // (launches sized by the host-side upper bound), header and status are checked after the final sync
+    const AsmHeader *d_hdr = ctx->asm_hdr.as<AsmHeader>();
+    if (max_items > 0) {
+        const unsigned ag = static_cast<unsigned>(std::min<int64_t>((max_items + 255) / 256, 2048));
+        hipLaunchKernelGGL(assemble_items_kernel, dim3(ag), dim3(256), 0,
                            ctx->stream, ctx->spine_jobs.as<SpineJob>(), static_cast<int>(nj), ctx->spine_meta.as<int4>(),
                            ctx->spine_scratch.as<int2>(), ctx->bridges.as<int2>(), ti + 3 * njp,
-                           ctx->sp_off.as<long long>(), hd.n_items, mw, W, ctx->tree_jobs.as<TreeJob>(),
-                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>());
+                           ctx->sp_off.as<long long>(), 0LL, mw, W, ctx->tree_jobs.as<TreeJob>(),
+                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    AsmHeader hd = {};
+    int rc = finish_batch(ctx, cfg, static_cast<size_t>(max_items), max_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin,
+                          d_hdr, &hd, use_bs);
     ctx->counters[3] = hd.n_items;
-    rc = finish_batch(ctx, cfg, static_cast<size_t>(hd.n_items), hd.n_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin);
     float ms = 0;
     if (nj && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[0]) == hipSuccess) ctx->ms[6] = ms;       // blocksum_kernel (K0)
     if (nj && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[6]) == hipSuccess) ctx->ms[0] = ms;       // spine_kernel

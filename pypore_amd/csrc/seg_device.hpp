@@ -936,7 +936,7 @@ __device__ __forceinline__ int left_child_j0(int start, int split, int W, int ha
 __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *status, unsigned long long *work, int which = -1)
 {
     if (bad) atomicOr(status, bad);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && wk.windows) {
         atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
         atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
         if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
@@ -946,7 +946,12 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
         if (which == PS_STAMP_K)
 #endif
         for (int i = 0; i < 12; ++i) atomicAdd(&work[4 + i], static_cast<unsigned long long>(wk.ph[i]));
-        if (which >= 0) {                      // longest workgroup (cycles, windows) and the sum of lifetimes per kernel
+#ifdef PS_STAMP_K
+        if (which == PS_STAMP_K)
+#else
+        if (which >= 0)
+#endif
+        {                                      // longest workgroup (cycles, windows) and the sum of lifetimes per kernel
             atomicMax(&work[16 + 3 * which], static_cast<unsigned long long>(clock64() - wk.tbeg));
             atomicAdd(&work[17 + 3 * which], static_cast<unsigned long long>(wk.windows));
             atomicAdd(&work[18 + 3 * which], static_cast<unsigned long long>(clock64() - wk.tbeg));
@@ -1074,20 +1079,32 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
     flush(bad, wk, status, work, 1);
 }
 
+// Header written by assemble_tiles_kernel.  Kernels downstream of the device stitch take it as `hdr`: when
+// it is non-null the item / job count is read from it on the device (no host round trip in the middle of
+// the pipeline) and a failed stitch turns them into no-ops; when null the host-provided count is used.
+struct AsmHeader { long long n_items, n_jobs, tscratch; int fail, pad; };
+__device__ __forceinline__ long long dev_count(const AsmHeader *hdr, long long host_n)
+{
+    return hdr ? (hdr->fail ? 0 : hdr->n_items) : host_n;
+}
+
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
 template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
-                                                  unsigned long long *work)
+                                                  unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr)
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
-    const TreeJob job = jobs[blockIdx.x];
-    if (job.out_cap == 0) return;                      // spine anchor without a left subtree (device stitch)
-    int32_t *out = scratch + job.out_off;
-    int2 *sp_glob = spill + job.out_off;
+    const long long n_jobs = dev_count(hdr, n_jobs_host);
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
+    // (the grid covers the jobs when their number is known on the host; otherwise workgroups stride over them)
+    for (long long ji = blockIdx.x; ji < n_jobs; ji += gridDim.x) {
+    const TreeJob job = jobs[ji];
+    if (job.out_cap == 0) continue;                    // spine anchor without a left subtree (device stitch)
+    int32_t *out = scratch + job.out_off;
+    int2 *sp_glob = spill + job.out_off;
     int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0, flushed = 0;
     int *obuf = reinterpret_cast<int *>(sh.obuf);
     constexpr int OB = 2 * SharedT<NT>::OB;
@@ -1139,7 +1156,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(D
     if (cnt > job.out_cap) cnt = job.out_cap;
     __syncthreads();
     for (int i = flushed + threadIdx.x; i < cnt; i += NT) out[i] = obuf[i - flushed];
-    if (threadIdx.x == 0) counts[blockIdx.x] = cnt;
+    if (threadIdx.x == 0) counts[ji] = cnt;
+    __syncthreads();                                   // obuf / stack are reused by the next job
+    }
     flush(bad, wk, status, work, 2);
 }
 
@@ -1173,8 +1192,9 @@ struct Item { int32_t job; int32_t anchor; };
 
 // single-workgroup exclusive scan of (tree count + 1) per item -> pos[n_items + 1]
 __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, const int32_t *counts,
-                                                         int64_t n_items, int64_t *pos)
+                                                         int64_t n_items_host, int64_t *pos, const AsmHeader *hdr)
 {
+    const int64_t n_items = dev_count(hdr, n_items_host);
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -1204,21 +1224,22 @@ __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, cons
 
 __global__ __launch_bounds__(64) void gather_kernel(const Item *items, const TreeJob *jobs,
                                                     const int32_t *counts, const int32_t *scratch,
-                                                    const int64_t *pos, int64_t n_items,
-                                                    int32_t *bounds, int64_t cap, uint8_t *is_spine)
+                                                    const int64_t *pos, int64_t n_items_host,
+                                                    int32_t *bounds, int64_t cap, uint8_t *is_spine, const AsmHeader *hdr)
 {
-    const int64_t it = blockIdx.x;
-    if (it >= n_items) return;
-    const Item item = items[it];
-    const int64_t p = pos[it];
-    int cnt = 0;
-    if (item.job >= 0) {
-        cnt = counts[item.job];
-        const int32_t *src = scratch + jobs[item.job].out_off;
-        for (int i = threadIdx.x; i < cnt; i += 64)
-            if (p + i < cap) { bounds[p + i] = src[i]; if (is_spine) is_spine[p + i] = 0; }
+    const int64_t n_items = dev_count(hdr, n_items_host);
+    for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const Item item = items[it];
+        const int64_t p = pos[it];
+        int cnt = 0;
+        if (item.job >= 0) {
+            cnt = counts[item.job];
+            const int32_t *src = scratch + jobs[item.job].out_off;
+            for (int i = threadIdx.x; i < cnt; i += 64)
+                if (p + i < cap) { bounds[p + i] = src[i]; if (is_spine) is_spine[p + i] = 0; }
+        }
+        if (threadIdx.x == 0 && p + cnt < cap) { bounds[p + cnt] = item.anchor; if (is_spine) is_spine[p + cnt] = 1; }
     }
-    if (threadIdx.x == 0 && p + cnt < cap) { bounds[p + cnt] = item.anchor; if (is_spine) is_spine[p + cnt] = 1; }
 }
 
 // bounds_off[e] = pos[first_item[e]]
@@ -1231,8 +1252,6 @@ __global__ void event_offsets_kernel(const int64_t *pos, const int64_t *first_it
 
 
 // ---- device-side stitch: true spine, tree jobs and items from the tile lists and bridges ----------
-struct AsmHeader { long long n_items, n_jobs, tscratch; int fail, pad; };
-
 // exclusive scan of two values over one 1024-thread workgroup chunk with running carries
 __device__ __forceinline__ void chunk_exscan2(long long v1, long long v2, long long &e1, long long &e2,
                                               long long *wsum /*[32]*/, long long *carry /*[2]*/)
@@ -1342,11 +1361,11 @@ __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
 // monotone and non-overlapping without any scan ((a+b)/m >= a/m + b/m for integers).
 __global__ __launch_bounds__(256) void assemble_items_kernel(
     const SpineJob *jobs, int n_tiles, const int4 *meta, const int2 *lists, const int2 *bridges,
-    const int *entry, const long long *sp_off, long long n_items, int mw, int W,
-    TreeJob *tjobs, Item *items, int32_t *counts)
+    const int *entry, const long long *sp_off, long long n_items_host, int mw, int W,
+    TreeJob *tjobs, Item *items, int32_t *counts, const AsmHeader *hdr)
 {
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
-    if (i >= n_items) return;
+    const long long n_items = dev_count(hdr, n_items_host);
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n_items; i += gridDim.x * 256LL) {
     int lo = 0, hi = n_tiles - 1;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -1381,6 +1400,7 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     tj.ev = jb2.ev; tj.pad_ = 0;
     tjobs[i] = tj;
     counts[i] = 0;
+    }
 }
 
 
