@@ -88,9 +88,11 @@ const char *ps_last_error(const ps_ctx *ctx);
  * spines are computed speculatively and stitched.  0 keeps the default. */
 int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
 /* Diagnostic / tuning options (none changes a result): "mode" 0 screen+exact (default), 1 exact fp64
- * scans only, 2 verify (screen and exact must agree); "stitch_host" 1 forces the host-stitch
- * pipeline (halo tiles + seam repairs, otherwise only the fallback); "spine_nt" 256/512/1024,
- * "tree_nt" 256/512 workgroup sizes.  Unknown names return PS_ERR_ARG. */
+ * scans only, 2 verify (screen and exact must agree); "scan_bs" 1 (default) block-sum scan with
+ * single-wave workgroups behind the block-prefix kernel, 0 LDS-window scan; "prune" 0 switches the
+ * block pruning of the LDS-window scan off; "stitch_host" 1 forces the host-stitch pipeline (halo
+ * tiles + seam repairs, otherwise only the fallback); "spine_nt" 256/512/1024, "tree_nt" 256/512
+ * workgroup sizes of the LDS-window kernels.  Unknown names return PS_ERR_ARG. */
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);
 /* Blocks until all work submitted on the context's stream has finished. */
 int ps_synchronize(ps_ctx *ctx);
@@ -168,9 +170,10 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
 
 /* Timing of the most recent ps_segment_batch, measured with HIP events on the context's
  * stream: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[3] whole
- * call (host wall clock), ms[4] stitch (assemble kernels + header sync, or the host stitch),
- * ms[5] bridge kernel.  counters[0] window scans, [1] candidate
- * evaluations, [2] tiles, [3] tree jobs, [4] seam repairs, [5] windows decided in fp64 (contenders or whole window), [6] of which whole-window scans. */
+ * call (host wall clock), ms[4] stitch (assemble kernels, or the host stitch), ms[5] bridge kernel,
+ * ms[6] block-prefix kernel (K0; 0 for the LDS-window scan).  counters[0] window scans, [1] candidate
+ * positions covered, [2] tiles, [3] tree jobs, [4] seam repairs, [5] windows decided in fp64 (among
+ * contenders or by a whole-window scan), [6] of which whole-window scans. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);
 
 /* Synthetic step-signal generator (bit-identical to pypore_amd/synth.py):

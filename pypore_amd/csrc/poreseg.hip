@@ -1,9 +1,11 @@
 // poreseg.hip -- C ABI (include/poreseg.h) and host orchestration of libporeseg.so.
 //
-// Pipeline of ps_segment_batch:
-//   phase 1  spine_kernel   one workgroup per tile: speculative spine of rec(T, END)
-//   stitch   host           true spine per event from the tile spines (indices only)
-//   phase 3  tree_kernel    one workgroup per true spine step: rec(a_k, a_{k+1}) in order
+// Pipeline of ps_segment_batch, one stream, one host sync at the end:
+//   phase 0  blocksum_kernel   K0: chunk-prefixed sums per 8-sample block (the only pass over the samples)
+//   phase 1  spine_kernel      one workgroup per tile: speculative spine of rec(T, END)
+//   phase 1b bridge_kernel     continues each tile's chain until it meets the downstream tile's
+//   stitch   assemble_* kernels  true spine per event from the tile spines (host-side only as the fallback)
+//   phase 3  tree_kernel       one job per true spine step: rec(a_k, a_{k+1}) in order
 //   gather   item_scan + gather kernels -> contiguous, sorted boundary list per event
 //   K2       segstat_kernel (optional)
 #include <hip/hip_runtime.h>
