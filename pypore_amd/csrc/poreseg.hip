@@ -63,6 +63,7 @@ struct HostBuf {          // pinned staging memory
 
 struct ps_ctx {
     int device = 0;
+    int n_cu = 0;             // compute units (queried once)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
@@ -149,14 +150,30 @@ inline size_t lds_bytes_for(int lds_cap, int nt)
 // LDS budget: 160 KB per CU minus the static Shared block and a little slack
 constexpr int LDS_BYTES_MAX = 160 * 1024 - static_cast<int>(sizeof(Shared)) - 512 - 64;
 
+// Resident workgroups of a kernel on this device (occupancy x CUs): the scan kernels are launched with one
+// workgroup per slot and stride over their jobs.
+template <typename K> unsigned resident_slots(ps_ctx *ctx, K kernel, int nt, size_t lds)
+{
+    int per_cu = 0;
+    if (ctx->n_cu <= 0) {
+        hipDeviceProp_t prop;
+        ctx->n_cu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), nt, lds) != hipSuccess || per_cu <= 0)
+        per_cu = 1;
+    return static_cast<unsigned>(per_cu) * static_cast<unsigned>(ctx->n_cu);
+}
+
 template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, bool list_mode = false)
 {
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(spine_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
+    const unsigned grid = std::min(nj, resident_slots(ctx, spine_kernel<NT, DT>, NT, lds));
+    hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(),
-                       list_mode ? nullptr : ctx->spine_dense.as<int2>(), ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
+                       list_mode ? nullptr : ctx->spine_dense.as<int2>(), ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
+                       static_cast<int>(nj));
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -167,7 +184,8 @@ template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsign
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
+    const unsigned grid = std::min(nj, resident_slots(ctx, tree_kernel<NT, DT>, NT, lds));
+    hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
                        ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
                        static_cast<long long>(n_jobs), d_hdr);
@@ -288,7 +306,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_tj) {
-        const unsigned g = static_cast<unsigned>(d_hdr ? std::min<size_t>(n_tj, 16384) : n_tj);
+        const unsigned g = static_cast<unsigned>(std::min<size_t>(n_tj, 0x7fffffff));
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
         int lrc = cfg.bsum != nullptr
                       ? (f32 ? launch_tree<64, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<64, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
@@ -381,16 +399,17 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bridge_kernel<NT, DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(nj), dim3(NT), lds, ctx->stream, cfg,
+    const unsigned grid = std::min(nj, resident_slots(ctx, bridge_kernel<NT, DT>, NT, lds));
+    hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
                        ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
-                       &sm->work0);
+                       &sm->work0, static_cast<int>(nj));
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
 
 // Device-stitch pipeline: tile spines without halo, seam bridges, assemble kernel (true spine,
-// tree jobs, items) -- the host only reads a 32-byte header between phase 1 and phase 3.
+// tree jobs, items) -- no host round trip before the final synchronisation.
 // Returns RC_FALLBACK when a seam could not be bridged on the device (rare); the caller then runs
 // the host-stitch pipeline, which repairs seams one by one.
 int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
