@@ -317,7 +317,8 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
-                       ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>(), d_hdr);
+                       ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>(), d_hdr,
+                       ctx->first_item.as<int64_t>(), n_ev, ctx->bounds_off.as<int64_t>());
     HIP_TRY(ctx, hipGetLastError());
     if (n_items) {
         const unsigned gg = static_cast<unsigned>(d_hdr ? std::min<int64_t>(n_items, 16384) : n_items);
@@ -327,9 +328,6 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
                            d_hdr);
         HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(event_offsets_kernel, dim3((n_ev + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                       ctx->item_pos.as<int64_t>(), ctx->first_item.as<int64_t>(), n_ev, ctx->bounds_off.as<int64_t>());
-    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, ctx->h_meta.reserve(evb));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
@@ -910,7 +908,8 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
                             (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t) * 3;
     HIP_TRY(ctx, ctx->h_up.reserve(up_bytes + 64));
     HIP_TRY(ctx, ctx->tree_jobs.reserve(std::max<size_t>(1, n_tj) * sizeof(TreeJob)));
-    HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<size_t>(1, n_tj) * sizeof(int32_t)));
+    // (item_scan_kernel reads counts[item index] speculatively: cover the items as well)
+    HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<size_t>(std::max<size_t>(1, n_tj), static_cast<size_t>(n_items)) * sizeof(int32_t)));
     HIP_TRY(ctx, ctx->tree_scratch.reserve(std::max<size_t>(1, static_cast<size_t>(tscratch)) * sizeof(int32_t)));
     HIP_TRY(ctx, ctx->tree_spill.reserve(std::max<size_t>(1, static_cast<size_t>(tscratch)) * sizeof(int2)));
     HIP_TRY(ctx, ctx->items.reserve(std::max<size_t>(1, static_cast<size_t>(n_items)) * sizeof(Item)));

@@ -1197,21 +1197,36 @@ __global__ __launch_bounds__(NT) void single_scan_kernel(DevCfg c, int n, int mo
 // ---- gather: final boundary list = for every true spine anchor: [its left subtree..., anchor] ----
 struct Item { int32_t job; int32_t anchor; };
 
-// single-workgroup exclusive scan of (tree count + 1) per item -> pos[n_items + 1]
+// single-workgroup exclusive scan of (tree count + 1) per item -> pos[n_items + 1]; then the per-event
+// offsets bounds_off[e] = pos[first_item[e]].
+// Eight items per thread and trip: their loads are issued together (a trip is one memory round trip).
 __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, const int32_t *counts,
-                                                         int64_t n_items_host, int64_t *pos, const AsmHeader *hdr)
+                                                         int64_t n_items_host, int64_t *pos, const AsmHeader *hdr,
+                                                         const int64_t *first_item, int32_t n_ev, int64_t *bounds_off)
 {
+    constexpr int PER = 8;
     const int64_t n_items = dev_count(hdr, n_items_host);
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t b0 = 0; b0 < n_items; b0 += 1024) {
-        int64_t i = b0 + threadIdx.x;
-        long long v = 0;
-        if (i < n_items) v = 1 + (items[i].job >= 0 ? counts[items[i].job] : 0);
-        long long inc = v;
+    for (int64_t b0 = 0; b0 < n_items; b0 += 1024 * PER) {
+        const int64_t i0 = b0 + static_cast<int64_t>(threadIdx.x) * PER;
+        int jb[PER], cn[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const bool in = i0 + k < n_items;
+            jb[k] = in ? items[i0 + k].job : -2;
+            cn[k] = in ? counts[i0 + k] : 0;            // (the device stitch numbers jobs like items: usually the right one)
+        }
+        long long v[PER], tot = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            v[k] = jb[k] == -2 ? 0 : 1 + (jb[k] < 0 ? 0 : jb[k] == i0 + k ? cn[k] : counts[jb[k]]);
+            tot += v[k];
+        }
+        long long inc = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             long long u = __shfl_up(inc, d);
@@ -1219,14 +1234,20 @@ __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, cons
         }
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        long long basev = carry_s;
-        for (int w = 0; w < wave; ++w) basev += wsum[w];
-        if (i < n_items) pos[i] = basev + inc - v;
+        long long run = carry_s + inc - tot;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (i0 + k < n_items) pos[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = basev + inc;
+        if (threadIdx.x == 1023) carry_s = run;
         __syncthreads();
     }
     if (threadIdx.x == 0) pos[n_items] = carry_s;
+    __syncthreads();                                   // pos[] written above is read by other threads below
+    for (int e = threadIdx.x; e <= n_ev; e += 1024) bounds_off[e] = pos[first_item[e]];
 }
 
 __global__ __launch_bounds__(64) void gather_kernel(const Item *items, const TreeJob *jobs,
@@ -1249,13 +1270,6 @@ __global__ __launch_bounds__(64) void gather_kernel(const Item *items, const Tre
     }
 }
 
-// bounds_off[e] = pos[first_item[e]]
-__global__ void event_offsets_kernel(const int64_t *pos, const int64_t *first_item, int32_t n_ev,
-                                     int64_t *bounds_off)
-{
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e <= n_ev) bounds_off[e] = pos[first_item[e]];
-}
 
 
 // ---- device-side stitch: true spine, tree jobs and items from the tile lists and bridges ----------
