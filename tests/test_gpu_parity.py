@@ -355,3 +355,46 @@ def test_events_in_arbitrary_memory_order(ctx):
     for e in range(4):
         ref = oracle.parse(x[starts[e]:starts[e] + lens[e]], prior_segments_per_second=10.)
         np.testing.assert_array_equal(b[boff[e]:boff[e + 1]], ref)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_event_batches_fp32_int16_odd_offsets(seed, ctx):
+    """Small edition of tools/fuzz_gpu.py: random levels / noise (incl. noise-free) / DC offsets, 1-7 events at odd
+    offsets of one device buffer, fp32 or int16, default and verify mode: boundaries equal the oracle's."""
+    import torch
+    from pypore_amd import _lib
+    rng = np.random.RandomState(777 + seed)
+    mw = int(rng.choice([8, 20, 100, 250]))
+    W = int(max(2 * mw, rng.choice([400, 1000, 4000, 10000, 25000])))
+    params = dict(min_width=mw, max_width=int(max(rng.choice([W, 3 * W, 1000000]), mw)), window_width=W,
+                  prior_segments_per_second=float(rng.choice([1., 10., 100.])))
+    n_ev = int(rng.choice([1, 3, 7]))
+    sigma = float(rng.choice([0.0, 1.0, 4.0, 30.0, 150.0]))
+    dc = int(rng.choice([0, 500, -3000, 9000]))
+    evs, starts, pos = [], [], 0
+    for _ in range(n_ev):
+        n = int(rng.randint(3000, 120000 if n_ev == 1 else 40000))
+        lo = int(rng.randint(50, 3000)); hi = lo + int(rng.randint(100, 30000))
+        k = np.empty(n, dtype=np.int64); i = 0
+        while i < n:
+            d = int(rng.randint(lo, hi)); k[i:i + d] = int(rng.randint(-2500, 2500)); i += d
+        if sigma > 0:
+            k += np.rint(rng.normal(0.0, sigma, n)).astype(np.int64)
+        evs.append(np.clip(k + dc, -32000, 32000))
+        pos += int(rng.randint(0, 9)); starts.append(pos); pos += n
+    buf = np.zeros(pos + 16, dtype=np.int64)
+    for k, s in zip(evs, starts):
+        buf[s:s + len(k)] = k
+    dev = torch.from_numpy(buf.astype(np.int16)).cuda() if rng.randint(0, 2) else \
+        torch.from_numpy((buf * synth.QUANTUM).astype(np.float32)).cuda()
+    refs = [oracle.parse(k.astype(np.float64) * synth.QUANTUM, **params) for k in evs]
+    try:
+        for mode in (0, 2):
+            ctx.set_option("mode", mode)
+            b, boff, _ = ctx.segment_events(dev, np.array(starts), np.array([len(k) for k in evs]),
+                                            _lib.split_params(**params), synth.QUANTUM)
+            b = b.cpu().numpy()
+            for e, ref in enumerate(refs):
+                np.testing.assert_array_equal(b[boff[e]:boff[e + 1]], ref)
+    finally:
+        ctx.set_option("mode", 0)

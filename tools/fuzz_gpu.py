@@ -1,0 +1,65 @@
+"""Randomised parity fuzz (GPU box): HIP path vs the CPU oracle on many seeded traces and parameter sets, in the
+default and verify modes, fp32 and int16 input, events at odd offsets.  Not part of the pytest suite (minutes)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import oracle
+from pypore_amd import _lib, engine, synth
+
+ctx = engine.context(0)
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+t0 = time.time()
+bad = 0
+for seed in range(n_seeds):
+    rng = np.random.RandomState(10_000 + seed + int(os.environ.get("FUZZ_BASE", "0")))
+    mw = int(rng.choice([8, 20, 100, 250]))
+    W = int(max(2 * mw, rng.choice([400, 1000, 4000, 10000, 25000])))
+    maxw = int(rng.choice([W, 3 * W, 50000, 1000000]))
+    params = dict(min_width=mw, max_width=max(maxw, mw), window_width=W,
+                  prior_segments_per_second=float(rng.choice([1., 10., 100.])))
+    n_ev = int(rng.choice([1, 1, 3, 7]))
+    sigma = float(rng.choice([0.0, 1.0, 4.0, 30.0, 150.0]))
+    dc = int(rng.choice([0, 0, 500, -3000, 9000]))
+    evs = []
+    for e in range(n_ev):
+        n = int(rng.randint(3000, 300000 if n_ev == 1 else 60000))
+        lo = int(rng.randint(50, 3000)); hi = lo + int(rng.randint(100, 30000))
+        k = np.empty(n, dtype=np.int64); i = 0
+        while i < n:
+            d = int(rng.randint(lo, hi)); lvl = int(rng.randint(-2500, 2500))
+            k[i:i + d] = lvl; i += d
+        if sigma > 0:
+            k += np.rint(rng.normal(0.0, sigma, n)).astype(np.int64)
+        k = np.clip(k + dc, -32000, 32000)
+        evs.append(k)
+    use_i16 = bool(rng.randint(0, 2))
+    pad = [int(rng.randint(0, 9)) for _ in range(n_ev)]          # odd offsets between events
+    total = sum(len(k) + p for k, p in zip(evs, pad)) + 16
+    buf = np.zeros(total, dtype=np.int64); starts = []; lens = []; pos = 0
+    for k, p in zip(evs, pad):
+        pos += p; starts.append(pos); lens.append(len(k)); buf[pos:pos + len(k)] = k; pos += len(k)
+    if use_i16:
+        dev = torch.from_numpy(buf.astype(np.int16)).cuda()
+    else:
+        dev = torch.from_numpy((buf.astype(np.float64) * synth.QUANTUM).astype(np.float32)).cuda()
+    sp = _lib.split_params(**params)
+    refs = [oracle.parse(k.astype(np.float64) * synth.QUANTUM, **params) for k in evs]
+    for mode in (0, 2):
+        ctx.set_option("mode", mode)
+        try:
+            b, boff, _ = ctx.segment_events(dev, np.array(starts, dtype=np.int64), np.array(lens, dtype=np.int64), sp,
+                                            synth.QUANTUM, want_stats=False)
+            b = b.cpu().numpy()
+            for e in range(n_ev):
+                got = b[boff[e]:boff[e + 1]]
+                if not np.array_equal(got, refs[e]):
+                    bad += 1
+                    print("MISMATCH seed", seed, "mode", mode, "event", e, params, "sigma", sigma, "dc", dc, "i16", use_i16,
+                          "got", len(got), "ref", len(refs[e]))
+        except Exception as ex:
+            bad += 1
+            print("ERROR seed", seed, "mode", mode, params, "sigma", sigma, "dc", dc, "i16", use_i16, repr(ex)[:300])
+    ctx.set_option("mode", 0)
+print("fuzz: %d seeds, %d problems, %.0f s, counters %s" % (n_seeds, bad, time.time() - t0, ctx.timings()))
+sys.exit(1 if bad else 0)
