@@ -74,7 +74,7 @@ struct ps_ctx {
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
-    DevBuf bsum, ev_info, chunk_mabs, ev_boff;
+    DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
@@ -133,7 +133,7 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->mode = ctx->mode;
     c->prune = ctx->prune;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
-    c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr;
+    c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr;
     c->dbg = ctx->small.as<SmallLayout>()->stamp;
     c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
@@ -328,6 +328,22 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
                            d_hdr);
         HIP_TRY(ctx, hipGetLastError());
     }
+    const bool stats_from_digest = d_stats != nullptr && cfg.bsum != nullptr && cfg.blk_mm != nullptr;
+    if (stats_from_digest) {
+        // K2 from the K0 digest: launched before the sync, the segment count is read on the device
+        const int64_t scap = cap + n_ev;
+        const unsigned sg = static_cast<unsigned>(std::min<int64_t>(std::max<int64_t>(scap, 1), 8192));
+        if (cfg.dtype == PS_DTYPE_F32)
+            hipLaunchKernelGGL(segstat_bs_kernel<PS_DTYPE_F32>, dim3(sg), dim3(64), 0, ctx->stream, cfg, ctx->ev_off.as<int64_t>(),
+                               ctx->ev_len.as<int64_t>(), n_ev, d_bounds, ctx->bounds_off.as<int64_t>(), d_stats, scap,
+                               reinterpret_cast<unsigned *>(&sm->status), d_hdr);
+        else
+            hipLaunchKernelGGL(segstat_bs_kernel<PS_DTYPE_I16>, dim3(sg), dim3(64), 0, ctx->stream, cfg, ctx->ev_off.as<int64_t>(),
+                               ctx->ev_len.as<int64_t>(), n_ev, d_bounds, ctx->bounds_off.as<int64_t>(), d_stats, scap,
+                               reinterpret_cast<unsigned *>(&sm->status), d_hdr);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    }
     HIP_TRY(ctx, ctx->h_meta.reserve(evb));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
@@ -367,7 +383,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (total > cap)
         return fail(ctx, PS_ERR_CAPACITY, "bounds capacity %lld < required %lld", static_cast<long long>(cap),
                     static_cast<long long>(total));
-    if (d_stats) {
+    if (d_stats && !stats_from_digest) {
         const int64_t nseg = total + n_ev;
         if (nseg > 0) {
             if (cfg.dtype == PS_DTYPE_F32)
@@ -381,8 +397,10 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
             HIP_TRY(ctx, hipGetLastError());
         }
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!stats_from_digest) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->ms[1] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->ms[2] = ms;
@@ -509,6 +527,10 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
         HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(k0_grid + 1) * 2 * sizeof(int4)));
         HIP_TRY(ctx, ctx->ev_boff.reserve(evb));
+        if (d_stats) {                                 // per-block min/max for the statistics kernel (4 B per block)
+            HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int)));
+            cfg.blk_mm = ctx->blk_mm.as<int>();
+        }
         std::memcpy(up + jb + 3 * evb, boff.data(), evb);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_boff.p, up + jb + 3 * evb, evb, hipMemcpyHostToDevice, ctx->stream));
         if (f32) hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_F32>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
@@ -642,7 +664,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
-                      &ctx->ev_boff};
+                      &ctx->ev_boff, &ctx->blk_mm};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);

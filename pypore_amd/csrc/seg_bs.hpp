@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
     int mabs = 0, ymax = 0;
     int s1 = 0;
     unsigned s2 = 0;
+    int bmin = 0x7fff, bmax = -0x8000;
     // event of the workgroup's first block (uniform search), then a short walk per thread
     int e_first = 0;
     {
@@ -107,9 +108,10 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
             if (y >= BS_WIDE || y <= -BS_WIDE) bad |= ST_WIDE_RANGE;
             s1 += y;
             s2 += static_cast<unsigned>(y * y);
-            if (q < cnt) mabs = max(mabs, k[q] < 0 ? -k[q] : k[q]);
+            if (q < cnt) { mabs = max(mabs, k[q] < 0 ? -k[q] : k[q]); bmin = min(bmin, y); bmax = max(bmax, y); }
             ymax = max(ymax, y < 0 ? -y : y);
         }
+        if (c.blk_mm) c.blk_mm[gb] = (bmin & 0xffff) | (bmax << 16);     // (|y| < BS_WIDE fits int16; otherwise the call is redone)
         if (b == 0) ev_info[e] = make_int4(m, 0, static_cast<int>(ev_boff[e] & 0xffffffffLL), static_cast<int>(ev_boff[e] >> 32));
     }
     // exclusive prefix over the workgroup (exact integers in fp64)
@@ -510,6 +512,96 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         return ex;
     }
     return result;
+}
+
+// ---- K2 from the K0 digest: per-segment statistics without a second pass over the samples ------------------
+// Segment.mean/std/min/max (core.py:209-223).  One wave per segment (workgroups stride over the segments):
+// S1, S2 of the full blocks inside the segment from the chunk prefix and the chunk totals, min/max from the per-block
+// table, the ragged ends (<= 7 samples each) from the samples.  mean = (m + S1/n) q, std = sqrt(S2/n - (S1/n)^2) q
+// (population; formed about m, so nothing cancels), min/max exact.  n_seg = bounds_off[n_ev] + n_ev is read on the
+// device; `stats_cap` bounds the writes.
+template <int DT>
+__global__ __launch_bounds__(64) void segstat_bs_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev,
+                                                        const int32_t *bounds, const int64_t *bounds_off, ps_segstat *stats,
+                                                        int64_t stats_cap, unsigned *status, const AsmHeader *hdr)
+{
+    const int lane = threadIdx.x;
+    // a failed stitch or a refused digest leaves no valid boundaries: the host redoes the call on another path
+    if ((hdr && hdr->fail) || (*status & ~ST_VERIFY_MISMATCH) != 0u) return;
+    const int64_t n_seg = min(bounds_off[n_ev] + n_ev, stats_cap);
+    unsigned bad = 0;
+    for (int64_t g = blockIdx.x; g < n_seg; g += gridDim.x) {
+        int lo = 0, hi = n_ev - 1;                 // event e: bounds_off[e] + e <= g < bounds_off[e+1] + e + 1
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (bounds_off[mid] + mid <= g) lo = mid; else hi = mid - 1;
+        }
+        const int e = lo;
+        const int64_t boff = bounds_off[e];
+        const int cnt = static_cast<int>(bounds_off[e + 1] - boff);
+        const int sidx = static_cast<int>(g - boff - e);
+        const int a = sidx == 0 ? 0 : bounds[boff + sidx - 1];
+        const int b = sidx == cnt ? static_cast<int>(ev_len[e]) : bounds[boff + sidx];
+        const int64_t base = ev_start[e];
+        const int4 info = c.ev_info[e];
+        const int m = info.x;
+        const long long eb = (static_cast<long long>(static_cast<unsigned>(info.w)) << 32) | static_cast<unsigned>(info.z);
+        const int n = b - a;
+        if (a < 0 || b < a || b > ev_len[e]) continue;                     // (never with valid boundaries)
+        double s1 = 0.0, s2 = 0.0;                 // sums of y = k - m and y^2 (exact integers)
+        int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);
+        const int b0 = (a + 7) >> 3, b1 = b >> 3;  // full blocks [b0, b1) of the event
+        if (n < 32 || b0 >= b1) {
+            for (int i = a + lane; i < b; i += 64) {
+                const int y = load_count<DT>(c, base + i, bad) - m;
+                s1 += static_cast<double>(y); s2 += static_cast<double>(y) * static_cast<double>(y);
+                mn = min(mn, y); mx = max(mx, y);
+            }
+        } else {
+            const long long gb0 = eb + b0, gb1 = eb + b1;
+            // ragged ends from the samples: lanes 0..6 the head [a, 8 b0), lanes 32..38 the tail [8 b1, b)
+            int y = 0;
+            bool have = false;
+            if (lane < 8 * b0 - a) { y = load_count<DT>(c, base + a + lane, bad) - m; have = true; }
+            if (lane >= 32 && lane - 32 < b - 8 * b1) { y = load_count<DT>(c, base + 8 * b1 + (lane - 32), bad) - m; have = true; }
+            if (have) { s1 = static_cast<double>(y); s2 = static_cast<double>(y) * static_cast<double>(y); mn = y; mx = y; }
+            // chunk totals between the two boundaries, min/max of the full blocks
+            const long long c0 = gb0 >> 8, c1 = gb1 >> 8;
+            for (long long cc = c0 + lane; cc < c1; cc += 64) {
+                const int4 t = c.chunk_tot[2 * cc];
+                s1 += static_cast<double>(t.x); s2 += ent2(t);
+            }
+            for (long long gb = gb0 + lane; gb < gb1; gb += 64) {
+                const int w = c.blk_mm[gb];
+                mn = min(mn, static_cast<int>(static_cast<short>(w & 0xffff))); mx = max(mx, w >> 16);
+            }
+            if (lane == 0) {
+                const int4 p0 = c.bsum[gb0], p1 = c.bsum[gb1];
+                s1 += static_cast<double>(p1.x) - static_cast<double>(p0.x);
+                s2 += ent2(p1) - ent2(p0);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            s1 += __shfl_down(s1, d); s2 += __shfl_down(s2, d);
+            mn = min(mn, __shfl_down(mn, d)); mx = max(mx, __shfl_down(mx, d));
+        }
+        if (lane == 0) {
+            ps_segstat r;
+            if (n > 0) {
+                const double dn = static_cast<double>(n);
+                const double my = s1 / dn;
+                double var = s2 / dn - my * my;
+                if (var < 0) var = 0;
+                r.mean = (static_cast<double>(m) + my) * c.q; r.std = sqrt(var) * c.q;
+                r.min = static_cast<double>(m + mn) * c.q; r.max = static_cast<double>(m + mx) * c.q;
+            } else {
+                r.mean = r.std = r.min = r.max = __builtin_nan("");
+            }
+            stats[g] = r;
+        }
+    }
+    if (bad) atomicOr(status, bad);
 }
 
 }  // namespace ps

@@ -52,7 +52,8 @@ struct DevCfg {
     int lds_cap;            // samples that fit the dynamic LDS window buffer
     const int4 *bsum;       // per 8-sample block: chunk-exclusive prefix of (sum (k-m), sum (k-m)^2), all events; nullptr: LDS-window scan
     const int4 *ev_info;    // per event: (m, -, block offset lo, block offset hi)
-    const int4 *chunk_tot;  // per 256 blocks (K0 workgroup): (sum, sum of squares lo/hi, max |k|)
+    const int4 *chunk_tot;  // per 256 blocks (K0 workgroup): (S1, -, S2 fp64), (max |k|, max |k-m|, -, -)
+    int *blk_mm;            // per block: min / max of k-m as two int16 (written by K0 when statistics are wanted) or nullptr
     unsigned long long *dbg;  // diagnostics scratch (12 words) or nullptr
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
@@ -750,6 +751,15 @@ __device__ int scan_screen_pruned(const DevCfg &c, const lds_t *ys, int2 *bsum, 
 }
 
 }  // namespace ps
+// Header written by assemble_tiles_kernel.  Kernels downstream of the device stitch take it as `hdr`: when
+// it is non-null the item / job count is read from it on the device (no host round trip in the middle of
+// the pipeline) and a failed stitch turns them into no-ops; when null the host-provided count is used.
+struct AsmHeader { long long n_items, n_jobs, tscratch; int fail, pad; };
+__device__ __forceinline__ long long dev_count(const AsmHeader *hdr, long long host_n)
+{
+    return hdr ? (hdr->fail ? 0 : hdr->n_items) : host_n;
+}
+
 #include "seg_bs.hpp"
 namespace ps {
 
@@ -1083,15 +1093,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
         __syncthreads();                               // obuf / lst are reused by the next tile
     }
     flush(bad, wk, status, work, 1);
-}
-
-// Header written by assemble_tiles_kernel.  Kernels downstream of the device stitch take it as `hdr`: when
-// it is non-null the item / job count is read from it on the device (no host round trip in the middle of
-// the pipeline) and a failed stitch turns them into no-ops; when null the host-provided count is used.
-struct AsmHeader { long long n_items, n_jobs, tscratch; int fail, pad; };
-__device__ __forceinline__ long long dev_count(const AsmHeader *hdr, long long host_n)
-{
-    return hdr ? (hdr->fail ? 0 : hdr->n_items) : host_n;
 }
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------

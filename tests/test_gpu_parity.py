@@ -391,10 +391,20 @@ def test_randomised_event_batches_fp32_int16_odd_offsets(seed, ctx):
     try:
         for mode in (0, 2):
             ctx.set_option("mode", mode)
-            b, boff, _ = ctx.segment_events(dev, np.array(starts), np.array([len(k) for k in evs]),
-                                            _lib.split_params(**params), synth.QUANTUM)
+            b, boff, st = ctx.segment_events(dev, np.array(starts), np.array([len(k) for k in evs]),
+                                             _lib.split_params(**params), synth.QUANTUM, want_stats=(mode == 0))
             b = b.cpu().numpy()
             for e, ref in enumerate(refs):
                 np.testing.assert_array_equal(b[boff[e]:boff[e + 1]], ref)
+            if st is not None:                           # per-segment statistics (K2 from the K0 digest) against numpy
+                st = st.cpu().numpy()
+                for e, (k, ref) in enumerate(zip(evs, refs)):
+                    edges = [0] + list(ref) + [len(k)]
+                    for i, (a0, b0) in enumerate(zip(edges, edges[1:])):
+                        seg = k[a0:b0].astype(np.float64) * synth.QUANTUM
+                        got = st[boff[e] + e + i]
+                        assert got[2] == seg.min() and got[3] == seg.max()
+                        np.testing.assert_allclose(got[0], seg.mean(), rtol=1e-5, atol=1e-12)
+                        np.testing.assert_allclose(got[1], seg.std(), rtol=1e-5, atol=1e-9)
     finally:
         ctx.set_option("mode", 0)
