@@ -168,6 +168,14 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
                      double threshold, int64_t min_duration, double min_current,
                      int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out);
 
+/* Replaces Event.filter (DataTypes.py:258-274) for the reference's default order: scipy.signal.bessel(1,
+ * cutoff / (sampling_freq / 2), btype='low', analog=0) applied with scipy.signal.filtfilt (forward and backward,
+ * odd extension by padlen = 6, initial state lfilter_zi * first value).  Input as for the segmenter (fp32 on the
+ * grid or int16 counts, n samples), output d_out[n] in pA as fp64 (the reference replaces Event.current by the
+ * float64 result).  order != 1 and n <= 6 return PS_ERR_ARG (scipy raises ValueError for the latter). */
+int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int32_t order,
+                     double cutoff, double sampling_freq, double *d_out);
+
 /* Timing of the most recent ps_segment_batch, measured with HIP events on the context's
  * stream: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[3] whole
  * call (host wall clock), ms[4] stitch (assemble kernels, or the host stitch), ms[5] bridge kernel,

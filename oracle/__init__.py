@@ -46,6 +46,8 @@ def lib():
         L.so_lambda_events.argtypes = [dp, ctypes.c_long, ctypes.c_double, ctypes.c_long,
                                        ctypes.c_double, lp, lp, ctypes.c_long]
         L.so_lambda_events.restype = ctypes.c_long
+        L.so_bessel1_filtfilt.argtypes = [dp, ctypes.c_long, ctypes.c_double, ctypes.c_double, dp]
+        L.so_bessel1_filtfilt.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -134,3 +136,14 @@ def lambda_events(x, threshold=90.0, min_duration=100000, min_current=-0.5):
         if n <= cap:
             return st[:n].copy(), ln[:n].copy()
         cap = n
+
+
+def bessel_filtfilt(x, cutoff=2000.0, second=1.0e5):
+    """Event.filter with the reference's default order 1 (DataTypes.py:258-274): float64 in, float64 out."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    rc = lib().so_bessel1_filtfilt(_dptr(x), x.size, float(cutoff), float(second), _dptr(out))
+    if rc != 0:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is 6." if x.size <= 6
+                         else "cutoff must lie strictly between 0 and the Nyquist frequency")
+    return out

@@ -260,3 +260,37 @@ long so_lambda_events(const double *x, long n, double threshold, long min_durati
     }
     return cnt;
 }
+
+/* ---- Event.filter, DataTypes.py:258-274 (order 1) ------------------------------------------------------------
+ * (b, a) = scipy.signal.bessel(1, cutoff / (second / 2), btype='low', analog=0, output='ba'); current =
+ * scipy.signal.filtfilt(b, a, current).  scipy is a third-party dependency of the reference (setup.py asks for
+ * scipy, no pin; 1.15.3 is installed where the golden vectors were recorded); its published algorithm, restated:
+ *   bessel, N = 1: analog prototype pole -1, gain 1; low-pass to the pre-warped frequency wo = 2 fs tan(pi Wn / fs)
+ *   with fs = 2; bilinear transform  =>  b = [wo, wo] / (4 + wo), a = [1, (wo - 4) / (wo + 4)].
+ *   filtfilt (method "pad", padtype "odd", padlen = 3 max(len a, len b) = 6): ext = odd extension of x by 6
+ *   samples at both ends; zi = lfilter_zi(b, a) = (b1 - a1 b0) / (1 + a1); forward lfilter over ext with initial
+ *   delay zi * ext[0]; lfilter over the reversed result with initial delay zi * (its first value); reverse; drop
+ *   the extension.  lfilter (direct form II transposed): y = b0 x + z; z = b1 x - a1 y.
+ * Returns 0, or -1 when n <= 6 (scipy raises ValueError) or the cutoff is not inside (0, Nyquist). */
+int so_bessel1_filtfilt(const double *x, long n, double cutoff, double second, double *out)
+{
+    const double wn = cutoff / (second / 2.0);
+    if (n <= 6 || !(wn > 0.0) || !(wn < 1.0)) return -1;
+    const double wo = 4.0 * tan(3.14159265358979323846 * wn / 2.0);
+    const double b0 = wo / (4.0 + wo), b1 = b0, a1 = (wo - 4.0) / (wo + 4.0);
+    const double zi = (b1 - a1 * b0) / (1.0 + a1);
+    const long m = n + 12;
+    double *ext = (double *)malloc(sizeof(double) * (size_t)m);
+    if (!ext) return -2;
+    for (long i = 0; i < m; ++i) {
+        const long j = i - 6;
+        ext[i] = j < 0 ? 2.0 * x[0] - x[-j] : j >= n ? 2.0 * x[n - 1] - x[2 * (n - 1) - j] : x[j];
+    }
+    double z = zi * ext[0];
+    for (long i = 0; i < m; ++i) { const double y = b0 * ext[i] + z; z = b1 * ext[i] - a1 * y; ext[i] = y; }
+    z = zi * ext[m - 1];
+    for (long i = m - 1; i >= 0; --i) { const double y = b0 * ext[i] + z; z = b1 * ext[i] - a1 * y; ext[i] = y; }
+    for (long j = 0; j < n; ++j) out[j] = ext[j + 6];
+    free(ext);
+    return 0;
+}

@@ -15,7 +15,7 @@ PS_DTYPE_F32, PS_DTYPE_I16 = 0, 1
 
 EXPORTS = ["ps_version", "ps_device_count", "ps_create", "ps_destroy", "ps_last_error", "ps_set_tiling", "ps_set_option",
            "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_segment_batch_ex", "ps_segment_events", "ps_detect_events", "ps_bounds_capacity",
-           "ps_best_single_split", "ps_score_window", "ps_get_timings", "ps_synth_trace"]
+           "ps_best_single_split", "ps_score_window", "ps_get_timings", "ps_synth_trace", "ps_filter_bessel"]
 
 
 class SplitParams(ctypes.Structure):
@@ -68,6 +68,7 @@ def lib():
     L.ps_score_window.argtypes = [vp, vp, P(SampleFormat), i64, i32, dbl, vp, P(i32)]
     L.ps_get_timings.argtypes = [vp, P(dbl), i32, P(i64), i32]
     L.ps_synth_trace.argtypes = [vp, vp, i32, i64, ctypes.c_uint64, P(i64), P(i32), i64]
+    L.ps_filter_bessel.argtypes = [vp, vp, P(SampleFormat), i64, i32, dbl, dbl, vp]
     _lib = L
     return L
 

@@ -74,7 +74,7 @@ struct ps_ctx {
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
-    DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm;
+    DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
@@ -664,7 +664,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
-                      &ctx->ev_boff, &ctx->blk_mm};
+                      &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -787,7 +787,9 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
 
     if (!ctx->stitch_host) {
-        bool use_bs = ctx->scan_bs && mw >= 8 && ctx->mode != MODE_EXACT;
+        // block-sum scan: candidates must avoid the ragged ends of a window (min_width >= 8) and a window must fit
+        // the single-wave sweep (W <= 90 000); otherwise the LDS-window kernels take the call
+        bool use_bs = ctx->scan_bs && mw >= 8 && W <= 90000 && ctx->mode != MODE_EXACT;
         rc = device_stitch_batch(ctx, cfg, use_bs, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
         if (rc == RC_WIDE) {                          // counts too wide for uint32 block sums: LDS-window scan instead
             for (double &m : ctx->ms) m = 0;
@@ -1141,6 +1143,51 @@ int ps_synth_trace(ps_ctx *ctx, void *d_out, int32_t dtype, int64_t n, uint64_t 
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PS_OK;
+}
+
+int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int32_t order,
+                     double cutoff, double sampling_freq, double *d_out)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!d_samples || !d_out) return fail(ctx, PS_ERR_ARG, "null pointer");
+    if (order != 1) return fail(ctx, PS_ERR_ARG, "only the first-order Bessel filter (the reference default) runs on the device");
+    if (n <= FILT_PAD) return fail(ctx, PS_ERR_ARG, "the length of the input must be greater than padlen, which is %d", FILT_PAD);
+    const double wn = cutoff / (sampling_freq / 2.0);
+    if (!(wn > 0.0) || !(wn < 1.0)) return fail(ctx, PS_ERR_ARG, "cutoff must lie strictly between 0 and the Nyquist frequency");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevCfg cfg;
+    int rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);
+    if (rc) return rc;
+    // scipy.signal.bessel(1, wn, 'low', analog=False): one real pole, bilinear transform with pre-warping (fs = 2)
+    FiltCoef f;
+    const double wo = 4.0 * std::tan(3.14159265358979323846 * wn / 2.0);
+    f.b0 = wo / (4.0 + wo); f.b1 = f.b0; f.a1 = (wo - 4.0) / (wo + 4.0);
+    f.alpha = -f.a1; f.beta = f.b1 - f.a1 * f.b0;
+    f.zi = (f.b1 - f.a1 * f.b0) / (1.0 + f.a1);        // lfilter_zi: steady state of the delay for a unit step input
+    const int64_t total = n + 2 * FILT_PAD;
+    const int64_t n_chunks = (total + FILT_CHUNK - 1) / FILT_CHUNK;
+    HIP_TRY(ctx, ctx->filt_fwd.reserve(static_cast<size_t>(total) * sizeof(double)));
+    HIP_TRY(ctx, ctx->filt_agg.reserve(static_cast<size_t>(n_chunks) * sizeof(double2)));
+    HIP_TRY(ctx, ctx->filt_zin.reserve(static_cast<size_t>(n_chunks) * sizeof(double)));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    unsigned *st = reinterpret_cast<unsigned *>(&sm->status);
+    double *fwd = ctx->filt_fwd.as<double>();
+    double2 *agg = ctx->filt_agg.as<double2>();
+    double *zin = ctx->filt_zin.as<double>();
+    const dim3 grid(static_cast<unsigned>(n_chunks));
+#define PS_FILT_PASS(PASS, DT, OUT)                                                                                     \
+    hipLaunchKernelGGL((filt_local_kernel<PASS, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, n, agg, st);      \
+    hipLaunchKernelGGL((filt_carry_kernel<PASS, DT>), dim3(1), dim3(1024), 0, ctx->stream, cfg, f, fwd, n, agg, n_chunks, zin); \
+    hipLaunchKernelGGL((filt_apply_kernel<PASS, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, n, zin, OUT, st);
+    if (cfg.dtype == PS_DTYPE_F32) { PS_FILT_PASS(0, PS_DTYPE_F32, fwd) PS_FILT_PASS(1, PS_DTYPE_F32, d_out) }
+    else                           { PS_FILT_PASS(0, PS_DTYPE_I16, fwd) PS_FILT_PASS(1, PS_DTYPE_I16, d_out) }
+#undef PS_FILT_PASS
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
 }
 
 }  // extern "C"

@@ -751,6 +751,8 @@ __device__ int scan_screen_pruned(const DevCfg &c, const lds_t *ys, int2 *bsum, 
 }
 
 }  // namespace ps
+
+#include "seg_filter.hpp"
 // Header written by assemble_tiles_kernel.  Kernels downstream of the device stitch take it as `hdr`: when
 // it is non-null the item / job count is read from it on the device (no host round trip in the middle of
 // the pipeline) and a failed stitch turns them into no-ops; when null the host-provided count is used.
@@ -1635,3 +1637,5 @@ __global__ void synth_kernel(void *out, int dtype, int64_t n, unsigned long long
 }
 
 }  // namespace ps
+
+#include "seg_filter.hpp"

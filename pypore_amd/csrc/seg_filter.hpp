@@ -1,0 +1,236 @@
+// seg_filter.hpp -- K5: Event.filter (DataTypes.py:258-274), the order-1 Bessel low-pass applied forward and
+// backward (scipy.signal.filtfilt, method "pad": odd extension by padlen = 6 samples, initial state zi * first value).
+//
+// A first-order section in direct form II transposed is  y[i] = b0 x[i] + z,  z <- b1 x[i] - a1 y[i], i.e. the state
+// obeys the linear recurrence  z <- alpha z + beta x[i]  with alpha = -a1, beta = b1 - a1 b0.  Affine maps compose, so
+// the recurrence is a scan: every workgroup folds its 4 096-sample chunk into one map (filt_local_kernel), one
+// workgroup runs the maps of all chunks to get the state entering each chunk (filt_carry_kernel), and a last pass
+// replays the chunks from their true entry state and writes the output (filt_apply_kernel).  All arithmetic is
+// fp64; the result differs from a sequential evaluation only by the re-association of the scan (~1e-16 relative).
+// The same three kernels run twice: over the extended input (forward) and over the reversed intermediate (backward).
+//
+// Included by seg_device.hpp (DevCfg, load_count).
+#pragma once
+
+namespace ps {
+
+constexpr int FILT_NT = 256;
+constexpr int FILT_PER = 16;                        // consecutive samples per thread
+constexpr int FILT_CHUNK = FILT_NT * FILT_PER;
+constexpr int FILT_PAD = 6;                         // scipy: padlen = 3 * max(len(a), len(b)) for a first-order section
+
+struct FiltCoef { double b0, b1, a1, alpha, beta, zi; };
+
+// Element i (0 <= i < n + 12) of the sequence a pass runs over.
+//   PASS 0 (forward): the odd extension of the samples, in pA:  j = i - 6;  j < 0: 2 x[0] - x[-j];
+//                     j >= n: 2 x[n-1] - x[2(n-1) - j];  else x[j]
+//   PASS 1 (backward): the forward output read back to front
+template <int PASS, int DT>
+__device__ __forceinline__ double filt_src(const DevCfg &c, const double *fwd, int64_t n, int64_t i, unsigned &bad)
+{
+    if (PASS == 1) return fwd[n + 2 * FILT_PAD - 1 - i];
+    const int64_t j = i - FILT_PAD;
+    if (j < 0) return (2.0 * load_count<DT>(c, 0, bad) - static_cast<double>(load_count<DT>(c, -j, bad))) * c.q;
+    if (j >= n) return (2.0 * load_count<DT>(c, n - 1, bad) - static_cast<double>(load_count<DT>(c, 2 * (n - 1) - j, bad))) * c.q;
+    return static_cast<double>(load_count<DT>(c, j, bad)) * c.q;
+}
+
+struct Affine { double a, s; };                     // z -> a z + s
+__device__ __forceinline__ Affine after(const Affine &second, const Affine &first)      // second o first
+{
+    return {second.a * first.a, fma(second.a, first.s, second.s)};
+}
+
+// Exclusive scan of the per-thread maps over the workgroup (thread order); returns the map of everything before
+// this thread and, in `total`, the map of the whole workgroup.
+__device__ __forceinline__ Affine filt_block_exscan(Affine mine, Affine &total, Affine *wsum /*[FILT_NT/64]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Affine inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Affine lo;
+        lo.a = __shfl_up(inc.a, d); lo.s = __shfl_up(inc.s, d);
+        if (lane >= d) inc = after(inc, lo);
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    Affine before = {1.0, 0.0};
+    for (int w = 0; w < wave; ++w) before = after(wsum[w], before);
+    total = before;
+    for (int w = wave; w < FILT_NT / 64; ++w) total = after(wsum[w], total);
+    // exclusive for this thread: everything before the wave, then the lanes below
+    Affine ex;
+    ex.a = __shfl_up(inc.a, 1); ex.s = __shfl_up(inc.s, 1);
+    if (lane == 0) ex = {1.0, 0.0};
+    __syncthreads();
+    return after(ex, before);
+}
+
+// LDS image of a chunk: element e at e + e/FILT_PER (one pad per thread run: few conflicts when threads read consecutive values
+// per thread, coalesced global accesses on the other side).
+constexpr int FILT_LDS = FILT_CHUNK + FILT_CHUNK / FILT_PER;
+__device__ __forceinline__ int filt_slot(int e) { return e + e / FILT_PER; }
+
+// Coalesced load of the workgroup's chunk into LDS, then the thread's 16 consecutive samples and the map they apply
+// to the state.
+template <int PASS, int DT>
+__device__ __forceinline__ Affine filt_thread_map(const DevCfg &c, const FiltCoef &f, const double *fwd, int64_t n, int64_t chunk0,
+                                                  int64_t total, double *lds, double *x, unsigned &bad)
+{
+    // All loads of the thread are issued before the first use: indices are clamped / reflected with selects, the odd
+    // extension and the end of the sequence are applied to the loaded values afterwards (a branch per element would
+    // serialise sixteen memory round trips).
+    double v[FILT_PER];
+    double x_first = 0.0, x_last = 0.0;
+    if (PASS == 0) {
+        x_first = static_cast<double>(load_count<DT>(c, 0, bad));
+        x_last = static_cast<double>(load_count<DT>(c, n - 1, bad));
+    }
+#pragma unroll
+    for (int k = 0; k < FILT_PER; ++k) {
+        // the backward pass walks memory downwards: lane order is flipped there so that a wave still reads ascending addresses
+        const int e = PASS == 0 ? k * FILT_NT + threadIdx.x : FILT_CHUNK - 1 - (k * FILT_NT + threadIdx.x);
+        const int64_t i = min(chunk0 + e, total - 1);
+        if (PASS == 1) v[k] = fwd[total - 1 - i];
+        else {
+            const int64_t j = i - FILT_PAD;
+            const int64_t idx = j < 0 ? -j : (j >= n ? 2 * (n - 1) - j : j);
+            v[k] = static_cast<double>(load_count<DT>(c, idx, bad));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FILT_PER; ++k) {
+        const int e = PASS == 0 ? k * FILT_NT + threadIdx.x : FILT_CHUNK - 1 - (k * FILT_NT + threadIdx.x);
+        const int64_t i = chunk0 + e;
+        double val = v[k];
+        if (PASS == 0) {
+            const int64_t j = i - FILT_PAD;
+            val = (j < 0 ? 2.0 * x_first - val : (j >= n ? 2.0 * x_last - val : val)) * c.q;
+        }
+        lds[filt_slot(e)] = i < total ? val : 0.0;
+    }
+    __syncthreads();
+    Affine m = {1.0, 0.0};
+    const int e0 = threadIdx.x * FILT_PER;
+#pragma unroll
+    for (int k = 0; k < FILT_PER; ++k) {
+        x[k] = lds[filt_slot(e0 + k)];
+        if (chunk0 + e0 + k < total) { m.s = fma(f.alpha, m.s, f.beta * x[k]); m.a *= f.alpha; }
+    }
+    return m;
+}
+
+template <int PASS, int DT>
+__global__ __launch_bounds__(FILT_NT) void filt_local_kernel(DevCfg c, FiltCoef f, const double *fwd, int64_t n, double2 *agg,
+                                                             unsigned *status)
+{
+    __shared__ Affine wsum[FILT_NT / 64];
+    __shared__ double lds[FILT_LDS];
+    const int64_t total = n + 2 * FILT_PAD;
+    // (the backward pass takes its chunks in descending order: consecutive workgroups then walk memory upwards)
+    const int64_t chunk = PASS == 0 ? blockIdx.x : gridDim.x - 1 - blockIdx.x;
+    const int64_t chunk0 = chunk * FILT_CHUNK;
+    unsigned bad = 0;
+    double x[FILT_PER];
+    const Affine mine = filt_thread_map<PASS, DT>(c, f, fwd, n, chunk0, total, lds, x, bad);
+    Affine all;
+    (void)filt_block_exscan(mine, all, wsum);
+    if (threadIdx.x == 0) agg[chunk] = make_double2(all.a, all.s);
+    if (bad) atomicOr(status, bad);
+}
+
+// zin[chunk] = state entering the chunk.  The entry state of the whole pass is zi * (first element).
+template <int PASS, int DT>
+__global__ __launch_bounds__(1024) void filt_carry_kernel(DevCfg c, FiltCoef f, const double *fwd, int64_t n,
+                                                          const double2 *__restrict__ agg, int64_t n_chunks, double *__restrict__ zin)
+{
+    __shared__ Affine tsum[1024];
+    unsigned bad = 0;
+    const double z0 = f.zi * filt_src<PASS, DT>(c, fwd, n, 0, bad);
+    const int64_t per = (n_chunks + 1023) / 1024;
+    const int64_t c0 = static_cast<int64_t>(threadIdx.x) * per, c1 = min(n_chunks, c0 + per);
+    constexpr int B = 8;                               // maps loaded per trip (independent loads, one round trip)
+    Affine m = {1.0, 0.0};
+    for (int64_t k0 = c0; k0 < c1; k0 += B) {
+        double2 g[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) g[i] = agg[min(k0 + i, n_chunks - 1)];
+#pragma unroll
+        for (int i = 0; i < B; ++i) if (k0 + i < c1) m = after({g[i].x, g[i].y}, m);
+    }
+    tsum[threadIdx.x] = m;
+    __syncthreads();
+    // exclusive scan of the 1 024 thread maps: wave scans, then the 16 wave totals serially
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        Affine inc = m;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            Affine lo;
+            lo.a = __shfl_up(inc.a, d); lo.s = __shfl_up(inc.s, d);
+            if (lane >= d) inc = after(inc, lo);
+        }
+        __shared__ Affine wtot[16];
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        Affine before = {1.0, 0.0};
+        for (int w = 0; w < wave; ++w) before = after(wtot[w], before);
+        Affine ex;
+        ex.a = __shfl_up(inc.a, 1); ex.s = __shfl_up(inc.s, 1);
+        if (lane == 0) ex = {1.0, 0.0};
+        m = after(ex, before);                         // everything before this thread's chunks
+    }
+    double z = fma(m.a, z0, m.s);
+    for (int64_t k0 = c0; k0 < c1; k0 += B) {
+        double2 g[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) g[i] = agg[min(k0 + i, n_chunks - 1)];
+#pragma unroll
+        for (int i = 0; i < B; ++i) if (k0 + i < c1) { zin[k0 + i] = z; z = fma(g[i].x, z, g[i].y); }
+    }
+}
+
+// PASS 0 writes the forward output (n + 12 values); PASS 1 writes out[j], j = 0..n-1 (the extension is dropped and the
+// order restored).
+template <int PASS, int DT>
+__global__ __launch_bounds__(FILT_NT) void filt_apply_kernel(DevCfg c, FiltCoef f, const double *fwd, int64_t n, const double *zin,
+                                                             double *out, unsigned *status)
+{
+    __shared__ Affine wsum[FILT_NT / 64];
+    __shared__ double lds[FILT_LDS];
+    const int64_t total = n + 2 * FILT_PAD;
+    // (the backward pass takes its chunks in descending order: consecutive workgroups then walk memory upwards)
+    const int64_t chunk = PASS == 0 ? blockIdx.x : gridDim.x - 1 - blockIdx.x;
+    const int64_t chunk0 = chunk * FILT_CHUNK;
+    unsigned bad = 0;
+    double x[FILT_PER];
+    const Affine mine = filt_thread_map<PASS, DT>(c, f, fwd, n, chunk0, total, lds, x, bad);
+    Affine all;
+    const Affine before = filt_block_exscan(mine, all, wsum);
+    double z = fma(before.a, zin[chunk], before.s);
+    const int e0 = threadIdx.x * FILT_PER;
+#pragma unroll
+    for (int k = 0; k < FILT_PER; ++k) {
+        const double y = fma(f.b0, x[k], z);
+        z = fma(-f.a1, y, f.b1 * x[k]);
+        lds[filt_slot(e0 + k)] = y;                    // (each thread overwrites its own slots)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FILT_PER; ++k) {               // coalesced write-out (ascending addresses in both passes)
+        const int e = PASS == 0 ? k * FILT_NT + threadIdx.x : FILT_CHUNK - 1 - (k * FILT_NT + threadIdx.x);
+        const int64_t i = chunk0 + e;
+        if (i < total) {
+            const double y = lds[filt_slot(e)];
+            if (PASS == 0) out[i] = y;
+            else {
+                const int64_t j = total - 1 - i - FILT_PAD;   // position in the original order
+                if (j >= 0 && j < n) out[j] = y;
+            }
+        }
+    }
+    if (PASS == 0 && bad) atomicOr(status, bad);
+}
+
+}  // namespace ps

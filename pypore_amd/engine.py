@@ -158,6 +158,18 @@ class Context(object):
                                           ctypes.c_void_p(scores.data_ptr()), ctypes.byref(i)), self.handle)
         return i.value, scores[:samples.numel()]
 
+    def filter_bessel(self, samples, quantum, cutoff=2000., sampling_freq=1.e5, order=1, offset_counts=0):
+        """ps_filter_bessel: Event.filter (DataTypes.py:258-274) -- order-1 Bessel low-pass, forward and backward
+        (scipy filtfilt semantics); returns the filtered current in pA as a float64 CUDA tensor."""
+        assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
+        fmt = self._fmt(samples, quantum, offset_counts)
+        out = torch.empty(max(1, samples.numel()), dtype=torch.float64, device=samples.device)
+        torch.cuda.current_stream(samples.device).synchronize()
+        _lib.check(self.L.ps_filter_bessel(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt),
+                                           samples.numel(), int(order), float(cutoff), float(sampling_freq),
+                                           ctypes.c_void_p(out.data_ptr())), self.handle)
+        return out[:samples.numel()]
+
     def synth_trace(self, n, seed, seg_end, level_counts, dtype=torch.float32):
         """Synthetic step trace generated directly in HBM (csrc synth_kernel == pypore_amd.synth)."""
         out = torch.empty(n, dtype=dtype, device="cuda:%d" % self.device)

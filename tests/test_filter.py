@@ -1,0 +1,112 @@
+"""Event.filter: order-1 Bessel filtfilt.  Golden vectors come from scipy (what the reference calls
+at DataTypes.py:258-274) and from the compiled reference run on the filtered current (tests/golden/make_golden_filter.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from pypore_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAN = json.load(open(os.path.join(HERE, "golden", "manifest_filter.json")))
+NPZ = np.load(os.path.join(HERE, "golden", "golden_filter.npz"))
+TOL = 1e-11          # relative to max |y|: re-association of the scan / coefficient rounding, fp64 throughout
+
+
+def _counts(gen):
+    if gen["kind"] == "config2_event":
+        return np.rint(synth.config2_event(gen["ev"], n=gen["n"], dtype=np.float64) / synth.QUANTUM).astype(np.int64)
+    return synth.random_dwell_counts(gen["n"], gen["seed"], gen["lo"], gen["hi"])
+
+
+@pytest.mark.parametrize("case", MAN["cases"], ids=[c["name"] for c in MAN["cases"]])
+def test_oracle_filter_matches_scipy_golden(case):
+    x = _counts(case["gen"]).astype(np.float64) * synth.QUANTUM
+    ref = NPZ[case["name"] + "/filtered"]
+    got = oracle.bessel_filtfilt(x, case["cutoff"], case["second"])
+    assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+
+
+def test_oracle_filter_rejects_what_scipy_rejects():
+    with pytest.raises(ValueError):
+        oracle.bessel_filtfilt(np.ones(6), 2000., 1e5)          # len(x) must exceed padlen = 6
+    with pytest.raises(ValueError):
+        oracle.bessel_filtfilt(np.ones(100), 60000., 1e5)       # cutoff above Nyquist
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "i16"])
+@pytest.mark.parametrize("case", MAN["cases"], ids=[c["name"] for c in MAN["cases"]])
+def test_filter_kernel_matches_scipy_golden(case, dtype):
+    import torch
+    from pypore_amd import engine
+    ctx = engine.context(0)
+    k = _counts(case["gen"])
+    dev = torch.from_numpy(k.astype(np.int16)).cuda() if dtype == "i16" else \
+        torch.from_numpy((k * synth.QUANTUM).astype(np.float32)).cuda()
+    got = ctx.filter_bessel(dev, synth.QUANTUM, cutoff=case["cutoff"], sampling_freq=case["second"]).cpu().numpy()
+    ref = NPZ[case["name"] + "/filtered"]
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+    # and against the oracle on the same input (same tolerance)
+    assert np.max(np.abs(got - oracle.bessel_filtfilt(k * synth.QUANTUM, case["cutoff"], case["second"]))) <= TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.gpu
+def test_filter_large_trace_against_oracle():
+    """2e7 samples (4 883 chunks: the carry pass matters), slow and fast cutoffs."""
+    import torch
+    from pypore_amd import engine
+    ctx = engine.context(0)
+    k = synth.random_dwell_counts(20_000_000, 9, 1000, 20000)
+    dev = torch.from_numpy(k.astype(np.int16)).cuda()
+    for cutoff in (2000., 5.):
+        got = ctx.filter_bessel(dev, synth.QUANTUM, cutoff=cutoff, sampling_freq=1e5).cpu().numpy()
+        ref = oracle.bessel_filtfilt(k * synth.QUANTUM, cutoff, 1e5)
+        assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))
+
+
+@pytest.mark.gpu
+def test_event_filter_contract_and_parse_of_filtered_event():
+    """Event.filter replaces current by the float64 result and records the filter (DataTypes.py:270-274).  Event.parse
+    of a filtered event (centred, rounded to a 2**-18 pA grid, see DataTypes.Event.parse) finds the boundaries the
+    compiled reference finds on the unrounded float64 current (golden), and segments expose views / statistics of the
+    unrounded current."""
+    from pypore_amd.DataTypes import Event, File
+    from pypore_amd.parsers import SpeedyStatSplit
+    for case in MAN["cases"]:
+        if case["n"] < 1000:
+            continue
+        x = _counts(case["gen"]).astype(np.float64) * synth.QUANTUM
+        f = File(current=x, timestep=1000. / case["second"])
+        ev = Event(current=x.copy(), start=0., end=len(x) / f.second, duration=len(x) / f.second, second=f.second, file=f)
+        ev.filter(cutoff=case["cutoff"])                   # order=1
+        assert ev.filtered and ev.filter_order == 1 and ev.filter_cutoff == case["cutoff"]
+        ref_y = NPZ[case["name"] + "/filtered"]
+        assert ev.current.dtype == np.float64
+        assert np.max(np.abs(ev.current - ref_y)) <= TOL * np.max(np.abs(ref_y))
+        ev.parse(SpeedyStatSplit(prior_segments_per_second=10, sampling_freq=case["second"]))
+        got = np.array([int(round(s.start * f.second)) for s in ev.segments[1:]])
+        np.testing.assert_array_equal(got, NPZ[case["name"] + "/ref_bounds_on_filtered"])
+        seg = ev.segments[len(ev.segments) // 2]
+        a, b = int(round(seg.start * f.second)), int(round(seg.end * f.second))
+        np.testing.assert_array_equal(seg.current, ev.current[a:b])
+        assert seg.mean == pytest.approx(float(np.mean(ev.current[a:b])), rel=1e-12)
+    with pytest.raises(ValueError):
+        Event(current=x.copy(), second=f.second, file=f).filter(order=2)
+
+
+@pytest.mark.gpu
+def test_filter_rejects_bad_arguments():
+    import torch
+    from pypore_amd import engine
+    ctx = engine.context(0)
+    dev = torch.zeros(100, dtype=torch.int16, device="cuda")
+    with pytest.raises(ValueError):
+        ctx.filter_bessel(dev[:6].contiguous(), 1.0)
+    with pytest.raises(ValueError):
+        ctx.filter_bessel(dev, 1.0, order=3)
+    with pytest.raises(ValueError):
+        ctx.filter_bessel(dev, 1.0, cutoff=60000., sampling_freq=1e5)
