@@ -1,11 +1,35 @@
 """File / Event containers: the call contract of DataTypes.py that sits on either side of the
-segmenter (File.parse :589-602, Event.parse :276-289,:333).  Plotting, HMM merging, JSON/MySQL
-persistence and Experiment are out of scope.
+segmenter (File.parse :589-602, Event.parse :276-289,:333, Event.filter :258-274) and the JSON
+persistence of the results (Event :480-545, File :683-796).  Plotting, HMM
+merging, MySQL and Experiment are out of scope.
 """
+import json
+
 import numpy as np
 
-from .core import Segment
-from .parsers import SpeedyStatSplit, lambda_event_parser
+from .core import MetaSegment, Segment, _jsonable, ignored
+from .parsers import SpeedyStatSplit, lambda_event_parser, parser as _parser_base
+
+
+def _json_dict(d):
+    """numpy scalars -> Python numbers (the reference relied on Python-2 json accepting them)."""
+    return {k: _jsonable(v) for k, v in d.items()}
+
+
+class MetaEvent(MetaSegment):
+    """DataTypes.py:49-80: an event without its current."""
+
+    def __init__(self, **kwargs):
+        MetaSegment.__init__(self, **kwargs)
+
+    def delete(self):
+        with ignored(AttributeError):
+            del self.state_parser
+        for segment in getattr(self, "segments", []):
+            segment.delete()
+        with ignored(AttributeError):
+            del self.segments
+        del self
 
 
 class Event(Segment):
@@ -72,6 +96,80 @@ class Event(Segment):
         except Exception:
             return 0
 
+    # ---- persistence (DataTypes.py:335-347, :480-545) ------------------------------------------------
+    def delete(self):
+        with ignored(AttributeError):
+            del self.current
+        with ignored(AttributeError):
+            del self.state_parser
+        for segment in getattr(self, "segments", []):
+            segment.delete()
+        with ignored(AttributeError):
+            del self.segments
+        del self
+
+    def to_meta(self):
+        """:480-491: freeze the statistics, drop the current (also of the segments), become a MetaEvent."""
+        for prop in ['mean', 'std', 'duration', 'start', 'min', 'max', 'end', 'start']:
+            with ignored(AttributeError, KeyError, ValueError):
+                self.__dict__[prop] = getattr(self, prop)
+        with ignored(AttributeError):
+            del self.current
+        self.__dict__.pop('_gpu_stats', None)
+        for segment in self.segments:
+            segment.to_meta()
+        self.__class__ = type("MetaEvent", (MetaEvent,), self.__dict__)
+
+    def to_dict(self):
+        keys = ['mean', 'std', 'min', 'max', 'start', 'end', 'duration', 'filtered',
+                'filter_order', 'filter_cutoff', 'n', 'state_parser', 'segments']
+        d = {}
+        for i in keys:
+            with ignored(AttributeError, ValueError):
+                d[i] = getattr(self, i)
+        d['name'] = self.__class__.__name__
+        return d
+
+    def to_json(self, filename=None):
+        d = self.to_dict()
+        with ignored(KeyError, AttributeError):
+            d['segments'] = [seg.to_dict() for seg in d['segments']]
+        with ignored(KeyError, AttributeError):
+            d['state_parser'] = d['state_parser'].to_dict()
+        _json = json.dumps(_json_dict(d), indent=4, separators=(',', ' : '))
+        if filename:
+            with open(filename, 'w') as out:
+                out.write(_json)
+        return _json
+
+    @classmethod
+    def from_json(cls, _json):
+        """:516-529: a JSON without `current` gives a MetaEvent carrying the stored attributes."""
+        if _json.endswith(".json"):
+            with open(_json, 'r') as infile:
+                _json = ''.join(line for line in infile)
+        d = json.loads(_json)
+        event = MetaSegment()
+        if 'current' not in d.keys():
+            event.__class__ = type("MetaEvent", (MetaEvent,), d)
+        else:
+            event = cls(d['current'], start=d['start'])
+        return event
+
+    @classmethod
+    def from_segments(cls, segments):
+        """:532-545."""
+        try:
+            current = np.concatenate([seg.current for seg in segments])
+            return cls(current=current, start=0, segments=segments)
+        except AttributeError:
+            dur = sum(seg.duration for seg in segments)
+            mean = np.mean([seg.mean * seg.duration for seg in segments]) / dur
+            std = np.sqrt(sum(seg.std ** 2 * seg.duration for seg in segments) / dur)
+            self = cls(current=np.array([seg.mean for seg in segments]), start=0, segments=segments, mean=mean, std=std)
+            self.__class__ = type("MetaEvent", (Event,), self.__dict__)
+            return self
+
 
 class File(Segment):
     """DataTypes.py:567-602."""
@@ -121,3 +219,91 @@ class File(Segment):
     @property
     def n(self):
         return len(self.events)
+
+    # ---- persistence (DataTypes.py:611-626, :683-796) ------------------------------------------------
+    def delete(self):
+        with ignored(AttributeError):
+            del self.current
+        with ignored(AttributeError):
+            del self.event_parser
+        for event in self.events:
+            event.delete()
+        del self
+
+    def to_meta(self):
+        with ignored(AttributeError):
+            del self.current
+        for event in self.events:
+            event.to_meta()
+
+    def to_dict(self):
+        keys = ['filename', 'n', 'event_parser', 'mean', 'std', 'duration', 'start', 'end', 'events']
+        if not hasattr(self, 'end') and (hasattr(self, 'start') and hasattr(self, 'duration')):
+            setattr(self, 'end', self.start + self.duration)
+        d = {}
+        for i in keys:
+            with ignored(AttributeError, ValueError):
+                d[i] = getattr(self, i)
+        d['name'] = self.__class__.__name__
+        return d
+
+    def to_json(self, filename=None):
+        """:708-736: the file, its event parser, every event with its segments and state parser."""
+        d = self.to_dict()
+        devents = []
+        for event in d['events']:
+            devent = event.to_dict()
+            try:
+                devent['segments'] = [_json_dict(state.to_dict()) for state in devent['segments']]
+                devent['state_parser'] = devent['state_parser'].to_dict()
+            except Exception:
+                with ignored(KeyError, AttributeError):
+                    del devent['segments']
+                    del devent['state_parser']
+            devents.append(_json_dict(devent))
+        d['events'] = devents
+        d['event_parser'] = d['event_parser'].to_dict()
+        _json = json.dumps(_json_dict(d), indent=4, separators=(',', ' : '))
+        if filename:
+            with open(filename, 'w') as outfile:
+                outfile.write(_json)
+        return _json
+
+    @classmethod
+    def from_json(cls, _json):
+        """:739-796: rebuilds the file and its events; with the .abf at hand the events and segments get views of the
+        current again (filtered events are re-filtered), otherwise everything comes back as Meta* objects."""
+        if _json.endswith(".json"):
+            with open(_json, 'r') as infile:
+                _json = ''.join(line for line in infile)
+        d = json.loads(_json)
+        if d['name'] != "File":
+            raise TypeError("JSON does not encode a file")
+        try:
+            file = File(filename=d['filename'] + ".abf")
+            meta = False
+        except Exception:
+            file = File(current=[], timestep=1)
+            meta = True
+        file.event_parser = _parser_base.from_json(json.dumps(d['event_parser']))
+        file.events = []
+        for ej in d['events']:
+            s, e = int(ej['start'] * file.second), int(ej['end'] * file.second)
+            if meta:
+                event = MetaEvent(**ej)
+            else:
+                event = Event(current=file.current[s:e], start=s / file.second, end=e / file.second,
+                              duration=(e - s) / file.second, second=file.second, file=file)
+            if ej['filtered']:
+                if not meta:
+                    event.filter(order=ej['filter_order'], cutoff=ej['filter_cutoff'])
+            if meta:
+                event.segments = [MetaSegment(**sj) for sj in ej['segments']]
+            else:
+                event.segments = [Segment(current=event.current[int(sj['start'] * file.second):int(sj['end'] * file.second)],
+                                          second=file.second, event=event, **sj)
+                                  for sj in ej['segments']]
+            event.state_parser = _parser_base.from_json(json.dumps(ej['state_parser']))
+            event.filtered = ej['filtered']
+            file.events.append(event)
+        return file
