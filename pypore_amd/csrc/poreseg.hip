@@ -1164,26 +1164,30 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     f.b0 = wo / (4.0 + wo); f.b1 = f.b0; f.a1 = (wo - 4.0) / (wo + 4.0);
     f.alpha = -f.a1; f.beta = f.b1 - f.a1 * f.b0;
     f.zi = (f.b1 - f.a1 * f.b0) / (1.0 + f.a1);        // lfilter_zi: steady state of the delay for a unit step input
-    const int64_t total = n + 2 * FILT_PAD;
-    const int64_t n_chunks = (total + FILT_CHUNK - 1) / FILT_CHUNK;
-    HIP_TRY(ctx, ctx->filt_fwd.reserve(static_cast<size_t>(total) * sizeof(double)));
-    HIP_TRY(ctx, ctx->filt_agg.reserve(static_cast<size_t>(n_chunks) * sizeof(double2)));
+    FiltGeom g;
+    g.n = n; g.total = n + 2 * FILT_PAD;
+    const int64_t n_chunks = (g.total + FILT_CHUNK - 1) / FILT_CHUNK;
+    g.padded = n_chunks * FILT_CHUNK;                  // the intermediate is stored behind a lead-in (seg_filter.hpp)
+    g.lead = g.padded - g.total;
+    HIP_TRY(ctx, ctx->filt_fwd.reserve(static_cast<size_t>(g.padded) * sizeof(double)));
+    HIP_TRY(ctx, ctx->filt_agg.reserve(static_cast<size_t>(n_chunks) * 2 * sizeof(double2)));
     HIP_TRY(ctx, ctx->filt_zin.reserve(static_cast<size_t>(n_chunks) * sizeof(double)));
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     unsigned *st = reinterpret_cast<unsigned *>(&sm->status);
     double *fwd = ctx->filt_fwd.as<double>();
-    double2 *agg = ctx->filt_agg.as<double2>();
+    double2 *agg = ctx->filt_agg.as<double2>(), *agg_b = agg + n_chunks;
     double *zin = ctx->filt_zin.as<double>();
     const dim3 grid(static_cast<unsigned>(n_chunks));
-#define PS_FILT_PASS(PASS, DT, OUT)                                                                                     \
-    hipLaunchKernelGGL((filt_local_kernel<PASS, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, n, agg, st);      \
-    hipLaunchKernelGGL((filt_carry_kernel<PASS, DT>), dim3(1), dim3(1024), 0, ctx->stream, cfg, f, fwd, n, agg, n_chunks, zin); \
-    hipLaunchKernelGGL((filt_apply_kernel<PASS, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, n, zin, OUT, st);
-    if (cfg.dtype == PS_DTYPE_F32) { PS_FILT_PASS(0, PS_DTYPE_F32, fwd) PS_FILT_PASS(1, PS_DTYPE_F32, d_out) }
-    else                           { PS_FILT_PASS(0, PS_DTYPE_I16, fwd) PS_FILT_PASS(1, PS_DTYPE_I16, d_out) }
-#undef PS_FILT_PASS
+#define PS_FILT(DT)                                                                                                          \
+    hipLaunchKernelGGL((filt_local_kernel<DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, agg, st);                     \
+    hipLaunchKernelGGL((filt_carry_kernel<0, DT>), dim3(1), dim3(1024), 0, ctx->stream, cfg, f, fwd, g, agg, n_chunks, zin);   \
+    hipLaunchKernelGGL((filt_apply_kernel<0, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, g, zin, fwd, agg_b, st); \
+    hipLaunchKernelGGL((filt_carry_kernel<1, DT>), dim3(1), dim3(1024), 0, ctx->stream, cfg, f, fwd, g, agg_b, n_chunks, zin); \
+    hipLaunchKernelGGL((filt_apply_kernel<1, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, g, zin, d_out, agg_b, st);
+    if (cfg.dtype == PS_DTYPE_F32) { PS_FILT(PS_DTYPE_F32) } else { PS_FILT(PS_DTYPE_I16) }
+#undef PS_FILT
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

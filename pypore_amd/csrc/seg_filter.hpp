@@ -7,7 +7,11 @@
 // workgroup runs the maps of all chunks to get the state entering each chunk (filt_carry_kernel), and a last pass
 // replays the chunks from their true entry state and writes the output (filt_apply_kernel).  All arithmetic is
 // fp64; the result differs from a sequential evaluation only by the re-association of the scan (~1e-16 relative).
-// The same three kernels run twice: over the extended input (forward) and over the reversed intermediate (backward).
+// The pass over the extended input (forward) is followed by the same scan over the reversed intermediate (backward).
+// The intermediate is stored with a lead-in that makes its length a multiple of the chunk, so that backward chunk k is
+// forward chunk K-1-k in memory: the forward apply kernel, which has its chunk's output in LDS anyway, also folds it in
+// reverse order into the backward map of that chunk, and the backward pass needs no separate fold (one 8 B/sample
+// read less).
 //
 // Included by seg_device.hpp (DevCfg, load_count).
 #pragma once
@@ -21,20 +25,10 @@ constexpr int FILT_PAD = 6;                         // scipy: padlen = 3 * max(l
 
 struct FiltCoef { double b0, b1, a1, alpha, beta, zi; };
 
-// Element i (0 <= i < n + 12) of the sequence a pass runs over.
-//   PASS 0 (forward): the odd extension of the samples, in pA:  j = i - 6;  j < 0: 2 x[0] - x[-j];
-//                     j >= n: 2 x[n-1] - x[2(n-1) - j];  else x[j]
-//   PASS 1 (backward): the forward output read back to front
-template <int PASS, int DT>
-__device__ __forceinline__ double filt_src(const DevCfg &c, const double *fwd, int64_t n, int64_t i, unsigned &bad)
-{
-    if (PASS == 1) return fwd[n + 2 * FILT_PAD - 1 - i];
-    const int64_t j = i - FILT_PAD;
-    if (j < 0) return (2.0 * load_count<DT>(c, 0, bad) - static_cast<double>(load_count<DT>(c, -j, bad))) * c.q;
-    if (j >= n) return (2.0 * load_count<DT>(c, n - 1, bad) - static_cast<double>(load_count<DT>(c, 2 * (n - 1) - j, bad))) * c.q;
-    return static_cast<double>(load_count<DT>(c, j, bad)) * c.q;
-}
-
+// Sequence element i (0 <= i < total = n + 12) of a pass.
+//   PASS 0 (forward): the odd extension of the samples (in counts; scaled by the caller):  j = i - 6;
+//                     j < 0: 2 x[0] - x[-j];  j >= n: 2 x[n-1] - x[2(n-1) - j];  else x[j]
+//   PASS 1 (backward): the forward output read back to front; it is stored at fwd[lead + i_forward]
 struct Affine { double a, s; };                     // z -> a z + s
 __device__ __forceinline__ Affine after(const Affine &second, const Affine &first)      // second o first
 {
@@ -67,48 +61,50 @@ __device__ __forceinline__ Affine filt_block_exscan(Affine mine, Affine &total, 
     return after(ex, before);
 }
 
-// LDS image of a chunk: element e at e + e/FILT_PER (one pad per thread run: few conflicts when threads read consecutive values
-// per thread, coalesced global accesses on the other side).
+// LDS image of a chunk: element e at e + e/FILT_PER (one pad per thread run: few conflicts when threads read
+// consecutive values, coalesced global accesses on the other side).
 constexpr int FILT_LDS = FILT_CHUNK + FILT_CHUNK / FILT_PER;
 __device__ __forceinline__ int filt_slot(int e) { return e + e / FILT_PER; }
 
-// Coalesced load of the workgroup's chunk into LDS, then the thread's 16 consecutive samples and the map they apply
-// to the state.
+// Geometry of a pass.  Chunk space u = chunk * FILT_CHUNK + e; sequence index i = u - lead (forward: lead >= 0 pads the
+// front so that total + lead is a multiple of the chunk; backward: lead = 0, the padding falls behind the sequence).
+struct FiltGeom { int64_t n, total, lead, padded; };      // padded = total + (forward lead) = n_chunks * FILT_CHUNK
+
+// Coalesced load of the workgroup's chunk into LDS (all loads issued before the first use: indices are clamped /
+// reflected with selects, the odd extension is applied to the loaded values), then the thread's consecutive samples
+// x[] and the map they apply to the state.  Elements outside the sequence are identity.
 template <int PASS, int DT>
-__device__ __forceinline__ Affine filt_thread_map(const DevCfg &c, const FiltCoef &f, const double *fwd, int64_t n, int64_t chunk0,
-                                                  int64_t total, double *lds, double *x, unsigned &bad)
+__device__ __forceinline__ Affine filt_thread_map(const DevCfg &c, const FiltCoef &f, const double *fwd, const FiltGeom &g,
+                                                  int64_t chunk0, double *lds, double *x, unsigned &bad)
 {
-    // All loads of the thread are issued before the first use: indices are clamped / reflected with selects, the odd
-    // extension and the end of the sequence are applied to the loaded values afterwards (a branch per element would
-    // serialise sixteen memory round trips).
+    const int64_t lead = PASS == 0 ? g.lead : 0;
     double v[FILT_PER];
     double x_first = 0.0, x_last = 0.0;
     if (PASS == 0) {
         x_first = static_cast<double>(load_count<DT>(c, 0, bad));
-        x_last = static_cast<double>(load_count<DT>(c, n - 1, bad));
+        x_last = static_cast<double>(load_count<DT>(c, g.n - 1, bad));
     }
 #pragma unroll
     for (int k = 0; k < FILT_PER; ++k) {
         // the backward pass walks memory downwards: lane order is flipped there so that a wave still reads ascending addresses
         const int e = PASS == 0 ? k * FILT_NT + threadIdx.x : FILT_CHUNK - 1 - (k * FILT_NT + threadIdx.x);
-        const int64_t i = min(chunk0 + e, total - 1);
-        if (PASS == 1) v[k] = fwd[total - 1 - i];
+        const int64_t i = min(max(chunk0 + e - lead, static_cast<int64_t>(0)), g.total - 1);
+        if (PASS == 1) v[k] = fwd[g.padded - 1 - i];
         else {
             const int64_t j = i - FILT_PAD;
-            const int64_t idx = j < 0 ? -j : (j >= n ? 2 * (n - 1) - j : j);
+            const int64_t idx = j < 0 ? -j : (j >= g.n ? 2 * (g.n - 1) - j : j);
             v[k] = static_cast<double>(load_count<DT>(c, idx, bad));
         }
     }
 #pragma unroll
     for (int k = 0; k < FILT_PER; ++k) {
         const int e = PASS == 0 ? k * FILT_NT + threadIdx.x : FILT_CHUNK - 1 - (k * FILT_NT + threadIdx.x);
-        const int64_t i = chunk0 + e;
         double val = v[k];
         if (PASS == 0) {
-            const int64_t j = i - FILT_PAD;
-            val = (j < 0 ? 2.0 * x_first - val : (j >= n ? 2.0 * x_last - val : val)) * c.q;
+            const int64_t j = chunk0 + e - lead - FILT_PAD;
+            val = (j < 0 ? 2.0 * x_first - val : (j >= g.n ? 2.0 * x_last - val : val)) * c.q;
         }
-        lds[filt_slot(e)] = i < total ? val : 0.0;
+        lds[filt_slot(e)] = val;
     }
     __syncthreads();
     Affine m = {1.0, 0.0};
@@ -116,51 +112,49 @@ __device__ __forceinline__ Affine filt_thread_map(const DevCfg &c, const FiltCoe
 #pragma unroll
     for (int k = 0; k < FILT_PER; ++k) {
         x[k] = lds[filt_slot(e0 + k)];
-        if (chunk0 + e0 + k < total) { m.s = fma(f.alpha, m.s, f.beta * x[k]); m.a *= f.alpha; }
+        const int64_t i = chunk0 + e0 + k - lead;
+        if (i >= 0 && i < g.total) { m.s = fma(f.alpha, m.s, f.beta * x[k]); m.a *= f.alpha; }
     }
     return m;
 }
 
-template <int PASS, int DT>
-__global__ __launch_bounds__(FILT_NT) void filt_local_kernel(DevCfg c, FiltCoef f, const double *fwd, int64_t n, double2 *agg,
-                                                             unsigned *status)
+// Forward fold: agg[chunk] = map of the chunk.
+template <int DT>
+__global__ __launch_bounds__(FILT_NT) void filt_local_kernel(DevCfg c, FiltCoef f, FiltGeom g, double2 *agg, unsigned *status)
 {
     __shared__ Affine wsum[FILT_NT / 64];
     __shared__ double lds[FILT_LDS];
-    const int64_t total = n + 2 * FILT_PAD;
-    // (the backward pass takes its chunks in descending order: consecutive workgroups then walk memory upwards)
-    const int64_t chunk = PASS == 0 ? blockIdx.x : gridDim.x - 1 - blockIdx.x;
-    const int64_t chunk0 = chunk * FILT_CHUNK;
+    const int64_t chunk = blockIdx.x;
     unsigned bad = 0;
     double x[FILT_PER];
-    const Affine mine = filt_thread_map<PASS, DT>(c, f, fwd, n, chunk0, total, lds, x, bad);
+    const Affine mine = filt_thread_map<0, DT>(c, f, nullptr, g, chunk * FILT_CHUNK, lds, x, bad);
     Affine all;
     (void)filt_block_exscan(mine, all, wsum);
     if (threadIdx.x == 0) agg[chunk] = make_double2(all.a, all.s);
     if (bad) atomicOr(status, bad);
 }
 
-// zin[chunk] = state entering the chunk.  The entry state of the whole pass is zi * (first element).
+// zin[chunk] = state entering the chunk, chunks taken in pass order.  The entry state of the pass is zi * (its first
+// element): x_ext[0] = 2 x[0] - x[6] for the forward pass, the last forward output for the backward pass.
 template <int PASS, int DT>
-__global__ __launch_bounds__(1024) void filt_carry_kernel(DevCfg c, FiltCoef f, const double *fwd, int64_t n,
+__global__ __launch_bounds__(1024) void filt_carry_kernel(DevCfg c, FiltCoef f, const double *fwd, FiltGeom g,
                                                           const double2 *__restrict__ agg, int64_t n_chunks, double *__restrict__ zin)
 {
-    __shared__ Affine tsum[1024];
     unsigned bad = 0;
-    const double z0 = f.zi * filt_src<PASS, DT>(c, fwd, n, 0, bad);
+    const double first = PASS == 1 ? fwd[g.padded - 1]
+                                   : (2.0 * load_count<DT>(c, 0, bad) - static_cast<double>(load_count<DT>(c, FILT_PAD, bad))) * c.q;
+    const double z0 = f.zi * first;
     const int64_t per = (n_chunks + 1023) / 1024;
     const int64_t c0 = static_cast<int64_t>(threadIdx.x) * per, c1 = min(n_chunks, c0 + per);
     constexpr int B = 8;                               // maps loaded per trip (independent loads, one round trip)
     Affine m = {1.0, 0.0};
     for (int64_t k0 = c0; k0 < c1; k0 += B) {
-        double2 g[B];
+        double2 q[B];
 #pragma unroll
-        for (int i = 0; i < B; ++i) g[i] = agg[min(k0 + i, n_chunks - 1)];
+        for (int i = 0; i < B; ++i) q[i] = agg[min(k0 + i, n_chunks - 1)];
 #pragma unroll
-        for (int i = 0; i < B; ++i) if (k0 + i < c1) m = after({g[i].x, g[i].y}, m);
+        for (int i = 0; i < B; ++i) if (k0 + i < c1) m = after({q[i].x, q[i].y}, m);
     }
-    tsum[threadIdx.x] = m;
-    __syncthreads();
     // exclusive scan of the 1 024 thread maps: wave scans, then the 16 wave totals serially
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -183,54 +177,72 @@ __global__ __launch_bounds__(1024) void filt_carry_kernel(DevCfg c, FiltCoef f, 
     }
     double z = fma(m.a, z0, m.s);
     for (int64_t k0 = c0; k0 < c1; k0 += B) {
-        double2 g[B];
+        double2 q[B];
 #pragma unroll
-        for (int i = 0; i < B; ++i) g[i] = agg[min(k0 + i, n_chunks - 1)];
+        for (int i = 0; i < B; ++i) q[i] = agg[min(k0 + i, n_chunks - 1)];
 #pragma unroll
-        for (int i = 0; i < B; ++i) if (k0 + i < c1) { zin[k0 + i] = z; z = fma(g[i].x, z, g[i].y); }
+        for (int i = 0; i < B; ++i) if (k0 + i < c1) { zin[k0 + i] = z; z = fma(q[i].x, z, q[i].y); }
     }
 }
 
-// PASS 0 writes the forward output (n + 12 values); PASS 1 writes out[j], j = 0..n-1 (the extension is dropped and the
-// order restored).
+// Replays a chunk from its true entry state.
+//   PASS 0 writes the forward output to fwd_out[u] (chunk space, i.e. behind the lead-in) and folds the chunk's output,
+//          taken back to front, into agg_b[K-1-chunk]: the map of the backward pass's chunk that covers the same memory.
+//   PASS 1 writes out[j], j = 0..n-1 (the extension is dropped and the order restored); its chunks are taken in
+//          descending order so that consecutive workgroups walk memory upwards.
 template <int PASS, int DT>
-__global__ __launch_bounds__(FILT_NT) void filt_apply_kernel(DevCfg c, FiltCoef f, const double *fwd, int64_t n, const double *zin,
-                                                             double *out, unsigned *status)
+__global__ __launch_bounds__(FILT_NT) void filt_apply_kernel(DevCfg c, FiltCoef f, const double *fwd, FiltGeom g, const double *zin,
+                                                             double *out, double2 *agg_b, unsigned *status)
 {
     __shared__ Affine wsum[FILT_NT / 64];
     __shared__ double lds[FILT_LDS];
-    const int64_t total = n + 2 * FILT_PAD;
-    // (the backward pass takes its chunks in descending order: consecutive workgroups then walk memory upwards)
     const int64_t chunk = PASS == 0 ? blockIdx.x : gridDim.x - 1 - blockIdx.x;
     const int64_t chunk0 = chunk * FILT_CHUNK;
+    const int64_t lead = PASS == 0 ? g.lead : 0;
     unsigned bad = 0;
     double x[FILT_PER];
-    const Affine mine = filt_thread_map<PASS, DT>(c, f, fwd, n, chunk0, total, lds, x, bad);
+    const Affine mine = filt_thread_map<PASS, DT>(c, f, fwd, g, chunk0, lds, x, bad);
     Affine all;
     const Affine before = filt_block_exscan(mine, all, wsum);
     double z = fma(before.a, zin[chunk], before.s);
     const int e0 = threadIdx.x * FILT_PER;
 #pragma unroll
     for (int k = 0; k < FILT_PER; ++k) {
-        const double y = fma(f.b0, x[k], z);
-        z = fma(-f.a1, y, f.b1 * x[k]);
-        lds[filt_slot(e0 + k)] = y;                    // (each thread overwrites its own slots)
+        const int64_t i = chunk0 + e0 + k - lead;
+        if (i >= 0 && i < g.total) {                   // (identity elements leave the state alone)
+            const double y = fma(f.b0, x[k], z);
+            z = fma(-f.a1, y, f.b1 * x[k]);
+            lds[filt_slot(e0 + k)] = y;                // (each thread overwrites its own slots)
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < FILT_PER; ++k) {               // coalesced write-out (ascending addresses in both passes)
         const int e = PASS == 0 ? k * FILT_NT + threadIdx.x : FILT_CHUNK - 1 - (k * FILT_NT + threadIdx.x);
-        const int64_t i = chunk0 + e;
-        if (i < total) {
+        const int64_t i = chunk0 + e - lead;
+        if (i >= 0 && i < g.total) {
             const double y = lds[filt_slot(e)];
-            if (PASS == 0) out[i] = y;
+            if (PASS == 0) out[chunk0 + e] = y;
             else {
-                const int64_t j = total - 1 - i - FILT_PAD;   // position in the original order
-                if (j >= 0 && j < n) out[j] = y;
+                const int64_t j = g.total - 1 - i - FILT_PAD;    // position in the original order
+                if (j >= 0 && j < g.n) out[j] = y;
             }
         }
     }
-    if (PASS == 0 && bad) atomicOr(status, bad);
+    if (PASS == 0) {
+        // backward fold of this chunk: thread t takes the run of thread FILT_NT-1-t back to front
+        const int r0 = (FILT_NT - 1 - static_cast<int>(threadIdx.x)) * FILT_PER;
+        Affine mb = {1.0, 0.0};
+#pragma unroll
+        for (int k = FILT_PER - 1; k >= 0; --k) {
+            const int64_t i = chunk0 + r0 + k - lead;
+            if (i >= 0 && i < g.total) { mb.s = fma(f.alpha, mb.s, f.beta * lds[filt_slot(r0 + k)]); mb.a *= f.alpha; }
+        }
+        Affine allb;
+        (void)filt_block_exscan(mb, allb, wsum);
+        if (threadIdx.x == 0) agg_b[gridDim.x - 1 - chunk] = make_double2(allb.a, allb.s);
+        if (bad) atomicOr(status, bad);
+    }
 }
 
 }  // namespace ps
