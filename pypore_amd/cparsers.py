@@ -40,19 +40,32 @@ class FastStatSplit(object):
     def parse_batch(self, currents):
         """One device call for many independent events (one reference parse() per event)."""
         ctx = engine.context(self.device)
-        devs, q = [], self.quantum
-        for cur in currents:
-            t, q1 = engine.to_device_samples(cur, q, self.device)
-            if q is None:
-                q = q1
-            elif q1 != q and self.quantum is None:
-                q = min(q, q1)
-            devs.append(t)
         import torch
+
+        def upload(full_detect):
+            devs, q = [], self.quantum
+            for cur in currents:
+                t, q1 = engine.to_device_samples(cur, q, self.device, full_detect=full_detect)
+                if q is None:
+                    q = q1
+                elif q1 != q and self.quantum is None:
+                    q = min(q, q1)
+                devs.append(t)
+            return devs, q
+
+        devs, q = upload(False)
         lens = np.array([t.numel() for t in devs], dtype=np.int64)
         ev_off = np.concatenate(([0], np.cumsum(lens)))
         samples = devs[0] if len(devs) == 1 else torch.cat(devs)
-        bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
+        try:
+            bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
+        except ValueError:
+            if self.quantum is not None:
+                raise
+            # the grid was detected on a subset of the samples and the device found a sample off it: search all
+            # samples for the grid once (still ValueError if there is none)
+            devs, q = upload(True)
+            bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
         b = bounds.cpu().numpy()
         st = stats.cpu().numpy()
         out = []

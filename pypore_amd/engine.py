@@ -196,29 +196,46 @@ def context(device=None):
 
 
 # ---- host-side input normalisation -------------------------------------------------------------
-def detect_quantum(x, max_bits=24):
+def detect_quantum(x, max_bits=24, full=True):
     """Largest power of two q = 2**-k (0 <= k <= max_bits) such that every sample of the numpy
     array `x` is an integer multiple of q; ValueError if there is none (off-grid data).
     Real traces are int16 ADC counts times a scale (read_abf.py:202-210), so such a q exists
-    whenever the scale is a power of two; pass quantum= explicitly to skip this O(n) host pass."""
+    whenever the scale is a power of two; pass quantum= explicitly to skip this host pass.
+    The candidate is found on a strided subset (<= 65 536 samples) and then confirmed on the whole
+    array, so a large trace costs two passes instead of one per bit.  With full=False the confirmation
+    is left to the device, which checks every sample anyway (PS_ERR_OFF_GRID -> ValueError)."""
     x = np.asarray(x)
     if x.size == 0:
         return 1.0
-    for k in (5,) + tuple(i for i in range(0, max_bits + 1) if i != 5):
-        y = x * (2.0 ** k)
-        if np.all(y == np.rint(y)):
-            # shrink k while still integral so that counts stay small
-            while k > 0:
-                y2 = x * (2.0 ** (k - 1))
-                if not np.all(y2 == np.rint(y2)):
-                    break
-                k -= 1
-            return 2.0 ** -k
-    raise ValueError("samples are not on a power-of-two ADC grid; pass quantum= (pA per count)")
+
+    def integral(a, k):
+        y = a * (2.0 ** k)
+        return bool(np.all(y == np.rint(y)))
+
+    def smallest_k(a):
+        for k in (5,) + tuple(i for i in range(0, max_bits + 1) if i != 5):
+            if integral(a, k):
+                while k > 0 and integral(a, k - 1):        # coarsest grid that still holds
+                    k -= 1
+                return k
+        return None
+
+    sub = x[::max(1, x.size // 65536)]
+    k = smallest_k(sub)
+    if k is None:
+        raise ValueError("samples are not on a power-of-two ADC grid; pass quantum= (pA per count)")
+    if not full or sub.size == x.size or integral(x, k):
+        return 2.0 ** -k
+    k = smallest_k(x)                                      # the subset was too coarse a witness: full search
+    if k is None:
+        raise ValueError("samples are not on a power-of-two ADC grid; pass quantum= (pA per count)")
+    return 2.0 ** -k
 
 
-def to_device_samples(current, quantum=None, device=None):
-    """numpy float64/float32 (pA), numpy int16 (ADC counts) or torch tensor -> (CUDA tensor, quantum)."""
+def to_device_samples(current, quantum=None, device=None, full_detect=False):
+    """numpy float64/float32 (pA), numpy int16 (ADC counts) or torch tensor -> (CUDA tensor, quantum).
+    Without `quantum` the grid is detected on a subset of the samples (full_detect=True: on all of them); a
+    finer grid that only shows elsewhere makes the device call fail with ValueError (off grid)."""
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
     if isinstance(current, torch.Tensor):
         t = current
@@ -237,7 +254,7 @@ def to_device_samples(current, quantum=None, device=None):
     if a.dtype not in (np.float64, np.float32):
         raise ValueError("Buffer dtype mismatch, expected 'double' but got %s" % a.dtype)
     if quantum is None:
-        quantum = detect_quantum(a)
+        quantum = detect_quantum(a, full=full_detect)
     a32 = a.astype(np.float32)
     if a.dtype == np.float64 and not np.array_equal(a32.astype(np.float64), a):
         raise ValueError("samples are not exactly representable in float32; pass int16 counts or a coarser grid")

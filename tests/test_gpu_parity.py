@@ -408,3 +408,18 @@ def test_randomised_event_batches_fp32_int16_odd_offsets(seed, ctx):
                         np.testing.assert_allclose(got[1], seg.std(), rtol=1e-5, atol=1e-9)
     finally:
         ctx.set_option("mode", 0)
+
+
+def test_grid_detected_on_a_subset_is_confirmed_by_the_device(ctx):
+    """The drop-in parse() finds the ADC grid on a strided subset of a large array; a sample on a finer grid elsewhere
+    makes the device refuse (it checks every sample) and the host then searches all samples once."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    k = synth.random_dwell_counts(300000, 21, 1000, 20000)
+    x = k.astype(np.float64) * synth.QUANTUM
+    x[123457] += 2.0 ** -8                               # not in the strided subset (stride 4), finer than 2**-5
+    ref = oracle.parse(x, prior_segments_per_second=10.)
+    got = _bounds(SpeedyStatSplit(prior_segments_per_second=10.).parse(x))
+    np.testing.assert_array_equal(got, ref)
+    x[123457] += 1e-7                                    # on no power-of-two grid at all
+    with pytest.raises(ValueError):
+        SpeedyStatSplit(prior_segments_per_second=10.).parse(x)
