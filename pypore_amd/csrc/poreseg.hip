@@ -30,8 +30,10 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool owned = true;        // false: p points into another buffer (alias), nothing to free
     hipError_t reserve(size_t bytes)
     {
+        if (!owned) { p = nullptr; cap = 0; owned = true; }
         if (bytes <= cap) return hipSuccess;
         if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
         size_t want = std::max(bytes, cap + cap / 2);
@@ -39,7 +41,9 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    // Points this buffer into `blob` (one upload for several small arrays); a later reserve() allocates afresh.
+    void alias(void *ptr) { if (p && owned) (void)hipFree(p); p = ptr; cap = 0; owned = false; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -74,7 +78,7 @@ struct ps_ctx {
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
-    DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin;
+    DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
@@ -478,8 +482,6 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     const int64_t tscratch_bound = total_len / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
     const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
 
-    HIP_TRY(ctx, ctx->ev_len.reserve(evb));
-    HIP_TRY(ctx, ctx->spine_jobs.reserve(std::max<size_t>(1, nj) * sizeof(SpineJob)));
     HIP_TRY(ctx, ctx->spine_scratch.reserve(std::max<int64_t>(1, list_entries) * sizeof(int2)));
     HIP_TRY(ctx, ctx->spine_meta.reserve(std::max<size_t>(4, nj) * sizeof(int4)));
     HIP_TRY(ctx, ctx->bridges.reserve(std::max<size_t>(1, nj) * BR_MAX * sizeof(int2)));
@@ -494,45 +496,46 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int32_t)));
     HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int2)));
     HIP_TRY(ctx, ctx->first_item.reserve(evb));
-    HIP_TRY(ctx, ctx->ev_first_tile.reserve(evb));
-    HIP_TRY(ctx, ctx->ev_off.reserve(evb));
     HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
     HIP_TRY(ctx, ctx->asm_hdr.reserve(sizeof(AsmHeader)));
     HIP_TRY(ctx, ctx->h_hdr.reserve(sizeof(AsmHeader)));
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
 
-    // one upload blob: [jobs | ev_first_tile | ev_off]
-    const size_t jb = nj * sizeof(SpineJob);
-    HIP_TRY(ctx, ctx->h_up.reserve(jb + 4 * evb + 64));
+    // one upload: [jobs | ev_first_tile | ev_start | ev_len | ev_boff] -> one device blob the five arrays point into
+    const size_t jb = (nj * sizeof(SpineJob) + 15) & ~static_cast<size_t>(15);
+    std::vector<int64_t> boff(static_cast<size_t>(n_ev) + 1, 0);           // first block of every event (K0)
+    for (int e = 0; e < n_ev; ++e) boff[e + 1] = boff[e] + (ev_len[e] + 7) / 8;
+    const size_t up_bytes = jb + 4 * evb;
+    HIP_TRY(ctx, ctx->h_up.reserve(up_bytes + 64));
+    HIP_TRY(ctx, ctx->up_dev.reserve(up_bytes + 64));
     char *up = ctx->h_up.as<char>();
-    if (nj) std::memcpy(up, jobs.data(), jb);
+    if (nj) std::memcpy(up, jobs.data(), nj * sizeof(SpineJob));
     std::memcpy(up + jb, ev_first_tile.data(), evb);
     std::memcpy(up + jb + evb, ev_start, evb - sizeof(int64_t));
     std::memcpy(up + jb + 2 * evb, ev_len, evb - sizeof(int64_t));
-    if (nj) HIP_TRY(ctx, hipMemcpyAsync(ctx->spine_jobs.p, up, jb, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_first_tile.p, up + jb, evb, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_off.p, up + jb + evb, evb, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_len.p, up + jb + 2 * evb, evb, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(up + jb + 3 * evb, boff.data(), evb);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->up_dev.p, up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    char *dup = ctx->up_dev.as<char>();
+    ctx->spine_jobs.alias(dup);
+    ctx->ev_first_tile.alias(dup + jb);
+    ctx->ev_off.alias(dup + jb + evb);
+    ctx->ev_len.alias(dup + jb + 2 * evb);
+    ctx->ev_boff.alias(dup + jb + 3 * evb);
 
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     if (use_bs && nj) {
         // K0: chunk-prefixed block sums (one streaming pass), per-event centre m, totals + max|k| per 256 blocks
-        std::vector<int64_t> boff(static_cast<size_t>(n_ev) + 1, 0);
-        for (int e = 0; e < n_ev; ++e) boff[e + 1] = boff[e] + (ev_len[e] + 7) / 8;
         const int64_t nb_total = boff[n_ev];
         const unsigned k0_grid = static_cast<unsigned>((nb_total + 1 + BS_CHUNK - 1) / BS_CHUNK);   // (+1: the end boundary)
         HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int4)));
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
         HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(k0_grid + 1) * 2 * sizeof(int4)));
-        HIP_TRY(ctx, ctx->ev_boff.reserve(evb));
         if (d_stats) {                                 // per-block min/max for the statistics kernel (4 B per block)
             HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int)));
             cfg.blk_mm = ctx->blk_mm.as<int>();
         }
-        std::memcpy(up + jb + 3 * evb, boff.data(), evb);
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->ev_boff.p, up + jb + 3 * evb, evb, hipMemcpyHostToDevice, ctx->stream));
         if (f32) hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_F32>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end,
                                     ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),
@@ -664,7 +667,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
-                      &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin};
+                      &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
