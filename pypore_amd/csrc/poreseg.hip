@@ -77,6 +77,8 @@ struct ps_ctx {
     int rep_eval = 1, rep_stage = 1, rep_sum = 1;
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
+    double wide_quantum = 0;  // quantum of the last call K0 refused (counts too wide) ...
+    int wide_skip = 0;        // ... and the number of calls with that quantum that still start on the LDS-window path
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
@@ -584,7 +586,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
                        static_cast<int>(nj), ctx->spine_meta.as<int4>(), ctx->bmeta.as<int4>(),
                        ctx->ev_first_tile.as<int64_t>(), n_ev, ti, ti + njp, ti + 2 * njp, ti + 3 * njp,
                        ctx->sp_off.as<long long>(), ctx->first_item.as<int64_t>(), ctx->asm_hdr.as<AsmHeader>(),
-                       static_cast<long long>(max_items), use_lds);
+                       static_cast<long long>(max_items), use_lds, reinterpret_cast<const unsigned *>(&sm->status));
     HIP_TRY(ctx, hipGetLastError());
     // no host round trip here: the downstream kernels read the item count from the header on the device
     // (launches sized by the host-side upper bound), header and status are checked after the final sync
@@ -793,8 +795,11 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
         // block-sum scan: candidates must avoid the ragged ends of a window (min_width >= 8) and a window must fit
         // the single-wave sweep (W <= 90 000); otherwise the LDS-window kernels take the call
         bool use_bs = ctx->scan_bs && mw >= 8 && W <= 90000 && ctx->mode != MODE_EXACT;
+        if (use_bs && ctx->wide_skip > 0 && fmt->quantum == ctx->wide_quantum) { use_bs = false; --ctx->wide_skip; }
         rc = device_stitch_batch(ctx, cfg, use_bs, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
         if (rc == RC_WIDE) {                          // counts too wide for uint32 block sums: LDS-window scan instead
+            ctx->wide_quantum = fmt->quantum;         // (the next calls on this grid skip the attempt)
+            ctx->wide_skip = 16;
             for (double &m : ctx->ms) m = 0;
             for (int64_t &c : ctx->counters) c = 0;
             HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));

@@ -983,6 +983,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
+    if (c.bsum != nullptr && (*status & ST_WIDE_RANGE) != 0u) return;      // K0 refused the data: the host redoes the call
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
     // One workgroup per resident slot, striding over the tiles: with more tiles than slots (many short events)
@@ -1044,6 +1045,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
+    if (c.bsum != nullptr && (*status & ST_WIDE_RANGE) != 0u) return;      // K0 refused the data: the host redoes the call
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
     for (int g = blockIdx.x; g < n_jobs; g += gridDim.x) {
@@ -1208,6 +1210,11 @@ __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, cons
                                                          const int64_t *first_item, int32_t n_ev, int64_t *bounds_off)
 {
     constexpr int PER = 8;
+    if (hdr && hdr->fail) {                            // failed / refused stitch: first_item is not valid either
+        for (int e = threadIdx.x; e <= n_ev; e += 1024) bounds_off[e] = 0;
+        if (threadIdx.x == 0) pos[0] = 0;
+        return;
+    }
     const int64_t n_items = dev_count(hdr, n_items_host);
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
@@ -1303,8 +1310,14 @@ __device__ __forceinline__ void chunk_exscan2(long long v1, long long v2, long l
 __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
     int n_tiles, const int4 *meta, const int4 *bmeta, const int64_t *ev_first_tile, int n_ev,
     int *g_reach, int *g_jump_a, int *g_jump_b, int *entry_out, long long *sp_off_out,
-    int64_t *first_item, AsmHeader *hdr, long long max_items, int use_lds)
+    int64_t *first_item, AsmHeader *hdr, long long max_items, int use_lds, const unsigned *status)
 {
+    // K0 refused the data (counts too wide for the block sums): the scan kernels did nothing; mark the stitch failed so
+    // that everything downstream is a no-op and the host redoes the call with the LDS-window kernels.
+    if ((*status & ST_WIDE_RANGE) != 0u) {
+        if (threadIdx.x == 0) { hdr->n_items = 0; hdr->n_jobs = 0; hdr->tscratch = 0; hdr->fail = 1; hdr->pad = 0; }
+        return;
+    }
     extern __shared__ long long dyn_lds[];
     __shared__ long long wsum[32];
     __shared__ long long carry[2];
