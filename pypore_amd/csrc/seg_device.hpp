@@ -1204,12 +1204,12 @@ struct Item { int32_t job; int32_t anchor; };
 
 // single-workgroup exclusive scan of (tree count + 1) per item -> pos[n_items + 1]; then the per-event
 // offsets bounds_off[e] = pos[first_item[e]].
-// Eight items per thread and trip: their loads are issued together (a trip is one memory round trip).
+// Sixteen items per thread and trip: their loads are issued together (a trip is one memory round trip).
 __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, const int32_t *counts,
                                                          int64_t n_items_host, int64_t *pos, const AsmHeader *hdr,
                                                          const int64_t *first_item, int32_t n_ev, int64_t *bounds_off)
 {
-    constexpr int PER = 8;
+    constexpr int PER = 16;                            // 16 384 items per trip: one trip for the bench trace
     if (hdr && hdr->fail) {                            // failed / refused stitch: first_item is not valid either
         for (int e = threadIdx.x; e <= n_ev; e += 1024) bounds_off[e] = 0;
         if (threadIdx.x == 0) pos[0] = 0;
