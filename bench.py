@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--stats", action="store_true", help="also run the per-segment statistics kernel in the step")
+    ap.add_argument("--dwell", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="dwell range of the synthetic trace in samples (default: BASELINE's U[1000, 20000))")
     ap.add_argument("--workload", choices=["trace", "file"], default="trace",
                     help="trace: one SpeedyStatSplit.parse over the whole 1e8-sample fp32 trace (default); "
                          "file: BASELINE config 3 -- int16 .abf-shaped trace, lambda_event_parser(threshold=90) "
@@ -70,7 +72,7 @@ def main():
     params = _lib.split_params(**PARAMS)
     from pypore_amd import dist as pdist
     if args.workload == "trace":
-        d = synth.dwell_table(seed, n)
+        d = synth.dwell_table(seed, n, *args.dwell) if args.dwell else synth.dwell_table(seed, n)
         ends = np.cumsum(d)
         lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
         trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)

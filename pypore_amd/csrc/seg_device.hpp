@@ -30,8 +30,10 @@ namespace ps {
 
 constexpr int LDS_STACK = 128;   // DFS stack entries kept in LDS before spilling to HBM
 constexpr int MAX_WAVES = 16;
-constexpr int OBUF = 256;
-constexpr int BR_MAX = 32;        // bridge chain: anchors a seam may add before it must have joined
+constexpr int OBUF = 256;          // (>= BR_MAX: a bridge buffers its whole chain in LDS)
+constexpr int BR_MAX = 256;       // bridge chain: anchors a seam may add before it must have joined (densely stepped
+                                  // data: two chains pick the best of ~10 steps per window and can take dozens of
+                                  // anchors to meet; a seam that gives up sends the whole call to the host stitch)
 constexpr int LST_MAX = 256;
 constexpr int QMAX = 256;          // blocks of candidates queued for full evaluation per window
 constexpr int PBLK = 8;            // candidates per pruning block      // anchors of the downstream tile cached in LDS for membership tests        // buffered outputs per job (int2 anchors / 2x int boundaries)
@@ -87,7 +89,7 @@ struct QEnt { int j, jend, p1, r1; unsigned p2, r2; int cL, cR; };
 // keeps it small so that 16 workgroups fit a CU.
 template <int NT> struct SharedT {
     static constexpr int NWV = NT / 64;
-    static constexpr int OB = NT == 64 ? 64 : OBUF;          // buffered outputs
+    static constexpr int OB = NT == 64 ? BR_MAX : OBUF;      // buffered outputs (a bridge buffers its whole chain)
     static constexpr int QN = NT == 64 ? 304 : QMAX;         // queued blocks
     static constexpr int LN = NT == 64 ? 128 : LST_MAX;      // cached downstream anchors
     static constexpr int SN = NT == 64 ? 64 : LDS_STACK;     // DFS stack entries before spilling
