@@ -38,7 +38,7 @@ constexpr int LST_MAX = 256;
 constexpr int QMAX = 256;          // blocks of candidates queued for full evaluation per window
 constexpr int PBLK = 8;            // candidates per pruning block      // anchors of the downstream tile cached in LDS for membership tests        // buffered outputs per job (int2 anchors / 2x int boundaries)
 
-enum : int { KIND_NONE = 0, KIND_HIT = 1, KIND_EARLY = 2, KIND_LATE = 3 };
+enum : int { KIND_NONE = 0, KIND_HIT = 1, KIND_EARLY = 2, KIND_LATE = 3, KIND_STOP = 4 };   // STOP: gave up at stop_lim (spine tiles)
 enum : unsigned { ST_OFF_GRID = 1u, ST_OUT_OVERFLOW = 2u, ST_STACK_OVERFLOW = 4u, ST_VERIFY_MISMATCH = 8u };
 enum : int { MODE_FAST = 0, MODE_EXACT = 1, MODE_VERIFY = 2 };
 
@@ -915,11 +915,15 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 // parent frame, DESIGN.md "memoised left child").
 template <int NT, int DT, bool VALIDATE>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
-                          SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, int ev = 0)
+                          SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, int ev = 0,
+                          long long stop_lim = 0x7fffffffffffffffLL)
 {
     const long long lim = static_cast<long long>(end) - 2LL * c.mw;
     for (long long ps = static_cast<long long>(start) + static_cast<long long>(j0) * c.half; ps < lim;
          ps += c.half) {
+        // A speculative tile chain gives up once its windows start beyond stop_lim: in a long stretch without
+        // splits every tile would otherwise walk to the same distant anchor; the seam's bridge does that once.
+        if (ps >= stop_lim) { kind = KIND_STOP; return static_cast<int>((ps - start) / c.half); }   // (windows scanned so far)
         if (ps > static_cast<long long>(start) + c.maxw) {             // :189-191
             long long a = static_cast<long long>(start) + c.maxw, b = static_cast<long long>(end) - c.mw;
             kind = KIND_EARLY;
@@ -993,11 +997,14 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(
     for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
         const SpineJob job = jobs[jb];
         int2 *out = scratch + job.out_off;
-        int a = job.start, cnt = 0, ended = 0, flushed = 0;
+        int a = job.start, cnt = 0, ended = 0, flushed = 0, open_j = 0;
         for (;;) {
             int kind;
-            int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev);
+            // (device stitch only: the host stitch expects every list to reach its tile end)
+            int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev,
+                                             dense == nullptr ? static_cast<long long>(job.stop) + 2LL * c.W : 0x7fffffffffffffffLL);
             if (kind == KIND_NONE) { ended = 1; break; }
+            if (kind == KIND_STOP) { open_j = s; break; }   // open end: the list stops short of the tile end (not "ended")
             if (cnt - flushed == SharedT<NT>::OB) {    // rare: spill the LDS buffer to the private scratch
                 __syncthreads();
                 for (int i = threadIdx.x; i < SharedT<NT>::OB; i += NT)
@@ -1015,7 +1022,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(
         __syncthreads();
         if (dense == nullptr) {                        // device-stitch pipeline: the list stays in its own region
             for (int i = flushed + threadIdx.x; i < cnt; i += NT) out[i] = sh.obuf[i - flushed];
-            if (threadIdx.x == 0) meta[jb] = make_int4(cnt, ended, 0, 0);
+            if (threadIdx.x == 0) meta[jb] = make_int4(cnt, ended, open_j, 0);   // .z: windows already scanned after the last anchor
         } else {
             if (threadIdx.x == 0) {
                 unsigned long long pos = atomicAdd(dense_count, static_cast<unsigned long long>(cnt));
@@ -1054,11 +1061,19 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
         const SpineJob job = jobs[g];
         const int4 m = meta[g];
         const bool last_tile = (g - job.first_tile) == job.ntiles - 1;
-        if (last_tile || m.y != 0 || m.x == 0) {       // chain already ran to the end of the event
+        if (last_tile || m.y != 0) {                   // chain already ran to the end of the event
             if (threadIdx.x == 0) bmeta[g] = make_int4(0, -1, 0, BR_NONE);
             continue;
         }
-        int a = lists[job.out_off + m.x - 1].x;
+        // From the tile's last anchor.  A tile that gave up before its first anchor (open end) can only be entered at its
+        // start: certain for an event's first tile, which is bridged from there; otherwise only if a true anchor falls
+        // exactly on the tile start -- not worth a walk through the whole stretch by every such tile: it is marked failed,
+        // and the stitch falls back to the host should the true chain ever reach it.
+        if (m.x == 0 && g != job.first_tile) {
+            if (threadIdx.x == 0) bmeta[g] = make_int4(0, -1, 0, BR_FAIL);
+            continue;
+        }
+        int a = m.x > 0 ? lists[job.out_off + m.x - 1].x : job.start;
         int cnt = 0, st = BR_FAIL, jt = -1, ji = 0, cached = -1, ccnt = 0;
         for (int step = 0; step <= BR_MAX; ++step) {
             int u = a / job.tile_len;
@@ -1086,8 +1101,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
             if (found != -2 && u != g) { st = BR_JOINED; jt = u; ji = found; break; }
             if (step == BR_MAX) break;
             int kind;
-            // (the samples a bridge reads were validated by the downstream tiles' own spine scans)
-            const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev);
+            // (the samples a bridge reads were validated by the downstream tiles' own spine scans; the first call skips
+            // the windows the tile's own chain already scanned without a hit before it gave up)
+            const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, step == 0 ? m.z : 0, kind, sh, bad, wk, job.end, job.ev);
             if (kind == KIND_NONE) { st = BR_ENDED; break; }
             if (threadIdx.x == 0) sh.obuf[cnt] = make_int2(s, kind);
             ++cnt;
@@ -1422,7 +1438,8 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     } else {
         const int kb = k - (cnt - en);
         el = bridges[static_cast<long long>(g) * BR_MAX + kb];
-        pred = kb > 0 ? bridges[static_cast<long long>(g) * BR_MAX + kb - 1].x : lists[jb2.out_off + cnt - 1].x;
+        // (a tile that gave up before its first anchor is entered at its start: that is the predecessor then)
+        pred = kb > 0 ? bridges[static_cast<long long>(g) * BR_MAX + kb - 1].x : (cnt > 0 ? lists[jb2.out_off + cnt - 1].x : jb2.start);
     }
     const bool has = el.y == KIND_HIT || el.y == KIND_LATE;
     Item it;
