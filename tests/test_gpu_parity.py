@@ -423,3 +423,39 @@ def test_grid_detected_on_a_subset_is_confirmed_by_the_device(ctx):
     x[123457] += 1e-7                                    # on no power-of-two grid at all
     with pytest.raises(ValueError):
         SpeedyStatSplit(prior_segments_per_second=10.).parse(x)
+
+
+REGIMES = [
+    ((100, 400), {}), ((100000, 1000000), {}), ((1000, 20000), dict(window_width=1000)),
+    ((1000, 20000), dict(window_width=50000)), ((1000, 20000), dict(min_width=8, window_width=2000)),
+    ((1000, 20000), dict(min_width=1000)), ((1000, 20000), dict(max_width=30000)),
+    ((1000, 20000), dict(prior_segments_per_second=1000.)), ((20000, 400000), dict(max_width=100000)),
+    ((1000, 20000), dict(window_width=100000)),
+]
+
+
+@pytest.mark.parametrize("regime", REGIMES, ids=[("dwell%d-%d " % r[0]) + ",".join("%s=%s" % kv for kv in r[1].items()) for r in REGIMES])
+def test_dwell_and_parameter_regimes(regime, ctx):
+    """Small edition of tools/regime_parity.py: dense and sparse steps (open-ended tiles, long bridges, forced splits),
+    narrow and wide windows (incl. wider than the block-sum scan takes), several tilings, default and verify mode."""
+    import torch
+    from pypore_amd import _lib
+    (lo, hi), extra = regime
+    n = 1_500_000
+    d = synth.dwell_table(91, n, lo, hi)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    t = ctx.synth_trace(n, 91, np.cumsum(d), lv, dtype=torch.float32)
+    kw = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    kw.update(extra)
+    ref = oracle.parse(t.cpu().numpy().astype(np.float64), **kw)
+    try:
+        for tile in (0, 60000):
+            ctx.set_tiling(tile, 0)
+            for mode in (0, 2):
+                ctx.set_option("mode", mode)
+                b, _, _ = ctx.segment_batch(t, np.array([0, n], dtype=np.int64), _lib.split_params(**kw), synth.QUANTUM,
+                                            want_stats=False)
+                np.testing.assert_array_equal(b.cpu().numpy(), ref)
+    finally:
+        ctx.set_option("mode", 0)
+        ctx.set_tiling(0, 0)
