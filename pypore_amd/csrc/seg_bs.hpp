@@ -217,7 +217,7 @@ template <int DT>
 __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                               double thresh, SharedT<64> &sh, unsigned &bad, Work &wk)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;                 // (one wave; possibly one of several in its workgroup)
     const int n = pe - ps;
     const int g0 = (ps + 7) & ~7, g1 = pe & ~7;
     const int nblk = (g1 - g0) >> 3;
@@ -265,13 +265,13 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     // a(t) = E[t] + off[chunk(t)] : sums of [ps, g0 + 8t) about m  (off includes the head and -E[0])
     const int K1 = static_cast<int>(H1d) - e0.x;
     const double K2 = H2d - ent2(e0);
-    __syncthreads();                                  // previous user of sh.q (this wave) is done
+    ps_sync<64>();                                  // previous user of sh.q (this wave) is done
     {
         BsOff o;
         o.o1 = static_cast<int>(ci1 - cs1) + K1; o.pad = 0; o.o2 = (ci2 - cs2) + K2;
         coff[lane] = o;
     }
-    __syncthreads();
+    ps_sync<64>();
     const BsOff oN = coff[nch - 1];
     const int T1 = eN.x + oN.o1 + static_cast<int>(TL1d);
     const double T2 = ent2(eN) + oN.o2 + TL2d;                        // window totals about m
@@ -331,7 +331,7 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         int qcount = 0;
         auto drain = [&]() {
             // drain: interior candidates of the queued blocks
-            __syncthreads();
+            ps_sync<64>();
             PS_STAMP_AT(wk, 1);                    // boundary sweep
             for (int r = 0; r < qcount; r += 64) {
                 // (a) one queued block per lane: its 8 samples, as int16 offsets from m, go to LDS
@@ -346,7 +346,7 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
                     pk.z = (y[4] & 0xffff) | (y[5] << 16); pk.w = (y[6] & 0xffff) | (y[7] << 16);
                     ybuf[lane] = pk;
                 }
-                __syncthreads();
+                ps_sync<64>();
                 // (b) one (block, offset) pair per lane: candidate J - u, u = 1..7 (the block's last u samples removed)
                 for (int r0 = 0; r0 < nb * 7; r0 += 64) {
                     const int idx = r0 + lane;
@@ -372,7 +372,7 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
                     flag |= static_cast<unsigned>(inr && !ok);
                     if (phase) PS_COLLECT(gq >= Tc, gq, J, x1, x2)
                 }
-                __syncthreads();
+                ps_sync<64>();
             }
             qcount = 0;
             PS_STAMP_AT(wk, 2);                        // drain
@@ -476,7 +476,7 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     }
 #undef PS_COLLECT
     if (result == -2 && !anyflag && ccount <= BS_NC) {
-        __syncthreads();                              // contender stores visible to the other lanes
+        ps_sync<64>();                              // contender stores visible to the other lanes
         const double var_summed = static_cast<double>(n) *
             log(ref_var(T1d + dn * static_cast<double>(m),
                         T2 + 2.0 * static_cast<double>(m) * T1d + dn * static_cast<double>(m) * static_cast<double>(m), n, c.q, c.q2));

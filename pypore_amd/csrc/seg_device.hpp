@@ -224,6 +224,23 @@ __device__ __forceinline__ void wave_minmax(int &mn, int &mx)      // result in 
 }
 
 // ---- workgroup primitives -------------------------------------------------------------------
+// The NT = 64 instantiations of everything below serve ONE WAVE, which may be one of several in its workgroup (bridge
+// look-ahead): their thread index is the lane and their "barrier" is wave-local -- lanes of a wave run in lockstep, so
+// LDS traffic between them only has to be complete (s_waitcnt), not synchronised with other waves.
+template <int NT> __device__ __forceinline__ int ps_tid()
+{
+    return NT == 64 ? static_cast<int>(threadIdx.x & 63u) : static_cast<int>(threadIdx.x);
+}
+template <int NT> __device__ __forceinline__ void ps_sync()
+{
+    if constexpr (NT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 // Exclusive prefix over the workgroup of two fp64 values that are exact integers (so the
 // summation order does not matter); also returns the workgroup totals.  One barrier.
 template <int NT>
@@ -231,11 +248,11 @@ __device__ __forceinline__ void block_exscan2(double v1, double v2, double &e1, 
                                               double &t1, double &t2, SharedT<NT> &sh)
 {
     constexpr int NW = NT / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = ps_tid<NT>() >> 6;
     double i1 = v1, i2 = v2;
     wave_incl_scan2(i1, i2);
     if (lane == 63) { sh.wsum1[wave] = i1; sh.wsum2[wave] = i2; }
-    __syncthreads();
+    ps_sync<NT>();
     double b1 = 0, b2 = 0, s1 = 0, s2 = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -261,7 +278,7 @@ template <int NT>
 __device__ __forceinline__ int block_argmax(double g, int idx, SharedT<NT> &sh, double *gain_out)
 {
     constexpr int NW = NT / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = ps_tid<NT>() >> 6;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         double og = __shfl_down(g, d);
@@ -269,7 +286,7 @@ __device__ __forceinline__ int block_argmax(double g, int idx, SharedT<NT> &sh, 
         if (beats(og, oi, g, idx)) { g = og; idx = oi; }
     }
     if (lane == 0) { sh.wbest[wave] = g; sh.widx[wave] = idx; }
-    __syncthreads();
+    ps_sync<NT>();
     double bg = sh.wbest[0];
     int bi = sh.widx[0];
 #pragma unroll
@@ -290,10 +307,10 @@ __device__ int scan_exact(const DevCfg &c, const lds_t *ys, int64_t g0, int ps, 
                           double *best_gain_out)
 {
     const int ch = ((n + NT - 1) / NT) | 1;
-    const long long lo_ll = static_cast<long long>(threadIdx.x) * ch;
+    const long long lo_ll = static_cast<long long>(ps_tid<NT>()) * ch;
     const int lo = lo_ll < n ? static_cast<int>(lo_ll) : n;
     const int hi = (lo + ch < n) ? lo + ch : n;
-    __syncthreads();        // a screen that bailed out early may still be reading the scan slots
+    ps_sync<NT>();          // a screen that bailed out early may still be reading the scan slots
 
     double s1 = 0, s2 = 0;
     for (int j = lo; j < hi; ++j) {
