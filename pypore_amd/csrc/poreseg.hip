@@ -416,6 +416,17 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
 
 
 
+template <int DT> int launch_bridge_la(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
+{
+    const unsigned grid = std::min(nj, resident_slots(ctx, bridge_la_kernel<DT>, 64 * BR_LA, 0));
+    hipLaunchKernelGGL((bridge_la_kernel<DT>), dim3(grid), dim3(64 * BR_LA), 0, ctx->stream, cfg,
+                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
+                       ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
+                       &sm->work0, static_cast<int>(nj));
+    HIP_TRY(ctx, hipGetLastError());
+    return PS_OK;
+}
+
 template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
@@ -557,7 +568,10 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
         int lrc = f32 ? launch_spine<64, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16>(ctx, cfg, g, sm, true);
         if (lrc) return lrc;
         HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        // single-wave bridges first; the seams that run into a stretch without splits are finished by the look-ahead kernel
         lrc = f32 ? launch_bridge<64, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<64, PS_DTYPE_I16>(ctx, cfg, g, sm);
+        if (lrc) return lrc;
+        lrc = f32 ? launch_bridge_la<PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge_la<PS_DTYPE_I16>(ctx, cfg, g, sm);
         if (lrc) return lrc;
     } else if (nj) {
         const unsigned g = static_cast<unsigned>(nj);

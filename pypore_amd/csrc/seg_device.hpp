@@ -933,14 +933,14 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 template <int NT, int DT, bool VALIDATE>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
                           SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, int ev = 0,
-                          long long stop_lim = 0x7fffffffffffffffLL)
+                          long long stop_lim = 0x7fffffffffffffffLL, int budget = 0x7fffffff)
 {
     const long long lim = static_cast<long long>(end) - 2LL * c.mw;
     for (long long ps = static_cast<long long>(start) + static_cast<long long>(j0) * c.half; ps < lim;
          ps += c.half) {
         // A speculative tile chain gives up once its windows start beyond stop_lim: in a long stretch without
         // splits every tile would otherwise walk to the same distant anchor; the seam's bridge does that once.
-        if (ps >= stop_lim) { kind = KIND_STOP; return static_cast<int>((ps - start) / c.half); }   // (windows scanned so far)
+        if (ps >= stop_lim || budget-- == 0) { kind = KIND_STOP; return static_cast<int>((ps - start) / c.half); }   // (windows scanned so far)
         if (ps > static_cast<long long>(start) + c.maxw) {             // :189-191
             long long a = static_cast<long long>(start) + c.maxw, b = static_cast<long long>(end) - c.mw;
             kind = KIND_EARLY;
@@ -1062,7 +1062,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(
 // start): from there on the two chains are identical.  bmeta[g] = (count, join_tile, join_idx,
 // status); status 0 nothing to do, 1 joined (continue with list[join_tile][join_idx+1..]),
 // 2 the chain reached the end of the event, 3 gave up (host fallback).
-enum : int { BR_NONE = 0, BR_JOINED = 1, BR_ENDED = 2, BR_FAIL = 3 };
+enum : int { BR_NONE = 0, BR_JOINED = 1, BR_ENDED = 2, BR_FAIL = 3, BR_DEFER = 4 };
+constexpr int BR_PATIENCE = 3;     // windows without a hit a single-wave bridge scans in one find_split before it defers
+                                   // the seam to the look-ahead kernel (bmeta = (count, next window, -, BR_DEFER))
 
 template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
@@ -1120,8 +1122,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
             int kind;
             // (the samples a bridge reads were validated by the downstream tiles' own spine scans; the first call skips
             // the windows the tile's own chain already scanned without a hit before it gave up)
-            const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, step == 0 ? m.z : 0, kind, sh, bad, wk, job.end, job.ev);
+            const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, step == 0 ? m.z : 0, kind, sh, bad, wk, job.end, job.ev,
+                                                    0x7fffffffffffffffLL, (NT == 64 && c.bsum != nullptr) ? BR_PATIENCE : 0x7fffffff);
             if (kind == KIND_NONE) { st = BR_ENDED; break; }
+            if (kind == KIND_STOP) { st = BR_DEFER; jt = s; break; }     // a long stretch: the look-ahead kernel takes over at window s
             if (threadIdx.x == 0) sh.obuf[cnt] = make_int2(s, kind);
             ++cnt;
             a = s;
@@ -1132,6 +1136,121 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
         __syncthreads();                               // obuf / lst are reused by the next tile
     }
     flush(bad, wk, status, work, 1);
+}
+
+// ---- phase 1b with look-ahead (block-sum scan) ---------------------------------------------------
+// A seam's chain is sequential, but between two anchors it is predictable: windows at a + j*W/2 until one hits.  LA
+// waves scan LA consecutive windows of the chain at once; the first decisive outcome in window order is the chain's
+// (a later window's result is simply dropped), so a stretch without splits is walked LA windows per step.  The
+// bridge kernel is the place for it: few seams need more than a window or two, so the machine is nearly idle while
+// the longest seam sets the kernel's duration.  Semantics: find_split (cparsers.pyx:186-201) window by window.
+constexpr int BR_LA = 4;
+template <int DT>
+__global__ __launch_bounds__(64 * BR_LA, 2) void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+                                                                  const int4 *meta, int2 *bridges, int4 *bmeta,
+                                                                  unsigned *status, unsigned long long *work, int n_jobs)
+{
+    __shared__ SharedT<64> shw[BR_LA];                 // one scratch per wave
+    __shared__ int lst[LST_MAX];                       // downstream anchor positions (shared by the waves)
+    __shared__ int2 obuf[BR_MAX];
+    __shared__ int2 res[BR_LA];                        // per wave: (outcome, value)
+    if ((*status & ST_WIDE_RANGE) != 0u) return;       // K0 refused the data: the host redoes the call
+    const int wave = threadIdx.x >> 6;
+    SharedT<64> &sh = shw[wave];
+    unsigned bad = 0;
+    Work wk = PS_WORK_INIT;
+    enum : int { O_CONT = 0, O_HIT = 1, O_EARLY = 2, O_LATE = 3, O_NONE = 4 };
+    for (int g = blockIdx.x; g < n_jobs; g += gridDim.x) {
+        const int4 bm = bmeta[g];
+        if (bm.w != BR_DEFER) continue;                // only the seams the single-wave bridge kernel deferred
+        const SpineJob job = jobs[g];
+        const int4 m = meta[g];
+        int cnt = bm.x;                                // anchors the seam already has; the chain resumes behind the last one
+        for (int i = threadIdx.x; i < cnt; i += 64 * BR_LA) obuf[i] = bridges[static_cast<int64_t>(g) * BR_MAX + i];
+        __syncthreads();
+        int a = cnt > 0 ? obuf[cnt - 1].x : (m.x > 0 ? lists[job.out_off + m.x - 1].x : job.start);
+        int st = BR_FAIL, jt = -1, ji = 0, cached = -1, ccnt = 0;
+        long long jres = bm.y;                         // window of the current find_split to resume at
+        for (int step = cnt; step <= BR_MAX; ++step) {
+            int u = a / job.tile_len;
+            if (u > job.ntiles - 1) u = job.ntiles - 1;
+            u += job.first_tile;
+            const SpineJob uj = jobs[u];
+            if (u != cached) {                         // cache the downstream list's positions in LDS
+                ccnt = meta[u].x;
+                __syncthreads();
+                for (int i = threadIdx.x; i < ccnt && i < LST_MAX; i += 64 * BR_LA) lst[i] = lists[uj.out_off + i].x;
+                __syncthreads();
+                cached = u;
+            }
+            int found = -2;                            // -1: a is the tile start, >=0: index in its list
+            if (a == uj.start) found = -1;
+            else {
+                int lo = 0, hi = ccnt - 1;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int v = mid < LST_MAX ? lst[mid] : lists[uj.out_off + mid].x;
+                    if (v == a) { found = mid; break; }
+                    if (v < a) lo = mid + 1; else hi = mid - 1;
+                }
+            }
+            if (found != -2 && u != g) { st = BR_JOINED; jt = u; ji = found; break; }
+            if (step == BR_MAX) break;
+            // find_split(a, job.end) with look-ahead
+            const long long start = a, end = job.end;
+            const long long lim = end - 2LL * c.mw;
+            int kind = KIND_NONE, s = -1;
+            const long long jfirst = jres;
+            jres = 0;
+            for (long long j = jfirst;; j += BR_LA) {
+                const long long ps = start + (j + wave) * c.half;
+                int oc = O_CONT, val = -1;
+                if (ps >= lim) {                                               // the loop is over: :199-201
+                    if (end - start <= c.maxw) oc = O_NONE;
+                    else { oc = O_LATE; const long long x = start + c.maxw, y = end - c.mw; val = static_cast<int>(x < y ? x : y); }
+                } else if (ps > start + c.maxw) {                              // :189-191
+                    oc = O_EARLY; const long long x = start + c.maxw, y = end - c.mw; val = static_cast<int>(x < y ? x : y);
+                } else {
+                    long long pe = ps + c.W;
+                    if (pe > end) pe = end;
+                    if (pe - ps > 2LL * c.mw) {
+                        if ((threadIdx.x & 63) == 0) { wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1; }
+                        val = scan_window_bs<DT>(c, job.ev, job.base, static_cast<int>(ps), static_cast<int>(pe),
+                                                 static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
+                        if (val >= 0) oc = O_HIT;
+                    }
+                }
+                if ((threadIdx.x & 63) == 0) res[wave] = make_int2(oc, val);
+                __syncthreads();
+                int first = -1;
+#pragma unroll
+                for (int w = BR_LA - 1; w >= 0; --w) if (res[w].x != O_CONT) first = w;
+                const int2 r = res[first < 0 ? 0 : first];
+                __syncthreads();
+                if (first >= 0) {
+                    kind = r.x == O_HIT ? KIND_HIT : r.x == O_EARLY ? KIND_EARLY : r.x == O_LATE ? KIND_LATE : KIND_NONE;
+                    s = r.y;
+                    break;
+                }
+            }
+            if (kind == KIND_NONE) { st = BR_ENDED; break; }
+            if (threadIdx.x == 0) obuf[cnt] = make_int2(s, kind);
+            ++cnt;
+            a = s;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 64 * BR_LA) bridges[static_cast<int64_t>(g) * BR_MAX + i] = obuf[i];
+        if (threadIdx.x == 0) bmeta[g] = make_int4(cnt, jt, ji, st);
+        __syncthreads();                               // obuf / lst are reused by the next tile
+    }
+    // counters: every wave counted its own scans
+    if (bad) atomicOr(status, bad);
+    if ((threadIdx.x & 63) == 0 && wk.windows) {
+        atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
+        atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
+        if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
+        if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
+    }
 }
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
@@ -1394,7 +1513,7 @@ __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
         if (!reach[g]) continue;
         const int4 b = bmeta[g];
         if (b.w == BR_JOINED) entry[b.y] = b.z + 1;
-        if (b.w == BR_FAIL) fail_s = 1;
+        if (b.w == BR_FAIL || b.w == BR_DEFER) fail_s = 1;
     }
     __syncthreads();
     // D. contribution of every tile and its offset in the true spine
