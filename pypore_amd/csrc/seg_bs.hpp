@@ -381,9 +381,8 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         int Jr = g0 + 8 * lane, gtr = gbl + lane;
         float nlf = static_cast<float>(Jr - ps);
         double nld = static_cast<double>(Jr - ps);
-        auto do_row = [&](bool first_row, const int4 &cur) {
+        auto do_row = [&](bool first_row, const int4 &cur, const BsOff &off) {
             const int J = Jr, nl = J - ps;
-            const BsOff off = coff[min(gtr >> 8, nch - 1)];
             const int a1 = cur.x + off.o1;
             const double a2 = ent2(cur) + off.o2;
             // screened gain of the boundary (bs_eval, with the running nl and the right side from the totals)
@@ -436,18 +435,23 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         int4 ga[BS_G], gb[BS_G];
 #pragma unroll
         for (int i = 0; i < BS_G; ++i) ga[i] = i == 0 ? row0 : bsw[min(i * BS_STRIDE + lane, nblk)];
+        BsOff offs[BS_G];                              // the group's chunk offsets: one LDS round trip per group, not per row
         for (int r0 = 0; r0 < rows; r0 += 2 * BS_G) {
             if (qcount > BS_QN - 64 * BS_G) drain();
 #pragma unroll
+            for (int i = 0; i < BS_G; ++i) offs[i] = coff[min((gtr + i * BS_STRIDE) >> 8, nch - 1)];
+#pragma unroll
             for (int i = 0; i < BS_G; ++i) gb[i] = bsw[min((r0 + BS_G + i) * BS_STRIDE + lane, nblk)];
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) do_row(r0 + i == 0, ga[i]);     // (rows past the end are inert)
+            for (int i = 0; i < BS_G; ++i) do_row(r0 + i == 0, ga[i], offs[i]);     // (rows past the end are inert)
             if (r0 + BS_G >= rows) break;
             if (qcount > BS_QN - 64 * BS_G) drain();
 #pragma unroll
+            for (int i = 0; i < BS_G; ++i) offs[i] = coff[min((gtr + i * BS_STRIDE) >> 8, nch - 1)];
+#pragma unroll
             for (int i = 0; i < BS_G; ++i) ga[i] = bsw[min((r0 + 2 * BS_G + i) * BS_STRIDE + lane, nblk)];
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) do_row(false, gb[i]);
+            for (int i = 0; i < BS_G; ++i) do_row(false, gb[i], offs[i]);
         }
         drain();
         if (phase == 1) break;
