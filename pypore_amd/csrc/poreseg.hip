@@ -116,7 +116,8 @@ int fail(ps_ctx *ctx, int code, const char *fmt, ...)
     } while (0)
 
 // status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..3] work, [4] dense count
-struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9]; };
+// (hdr: the stitch header lives behind the counters so that one copy brings both back)
+struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9]; AsmHeader hdr; };
 
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
              double min_gain, DevCfg *c)
@@ -353,7 +354,6 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     HIP_TRY(ctx, ctx->h_meta.reserve(evb));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
-    if (d_hdr) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr.p, d_hdr, sizeof(AsmHeader), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(h_bounds_off, ctx->h_meta.p, evb);
     const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
@@ -361,7 +361,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     rc = check_status(ctx, static_cast<unsigned>(hs.status));
     if (rc) return rc;
     if (d_hdr) {
-        const AsmHeader hd = *ctx->h_hdr.as<AsmHeader>();
+        const AsmHeader hd = hs.hdr;
         if (hdr_out) *hdr_out = hd;
         if (hd.fail) return RC_FALLBACK;
     }
@@ -510,8 +510,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int2)));
     HIP_TRY(ctx, ctx->first_item.reserve(evb));
     HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
-    HIP_TRY(ctx, ctx->asm_hdr.reserve(sizeof(AsmHeader)));
-    HIP_TRY(ctx, ctx->h_hdr.reserve(sizeof(AsmHeader)));
+    ctx->asm_hdr.alias(&ctx->small.as<SmallLayout>()->hdr);
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
 
     // one upload: [jobs | ev_first_tile | ev_start | ev_len | ev_boff] -> one device blob the five arrays point into
