@@ -57,7 +57,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    use_dist = args.gpus > 1 or world > 1 or os.environ.get("PORESEG_BENCH_DIST") == "1"   # env: exercise the
+    if use_dist:                                         # N > 1 code path on one GPU (torchrun --nproc-per-node 1)
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -80,8 +81,7 @@ def main():
 
         def step():
             b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats)
-            if world > 1:
-                pdist.gather_varlen(b)                   # the final boundary-index gather (RCCL)
+            gather(b)
             return b, o, st
     else:
         ends, lv, _ = synth.file_trace_table(n, seed)
@@ -91,19 +91,35 @@ def main():
         def step():
             st_, ln_, b, o, stt = pipeline.segment_file_trace(trace, synth.QUANTUM, params, threshold=90.0,
                                                               want_stats=args.stats)
-            if world > 1:
-                pdist.gather_varlen(b)
+            gather(b)
             return b, o, stt
     torch.cuda.synchronize()
 
+    # the final boundary-index gather (RCCL): one fixed-shape all_gather per batch, enqueued without a
+    # host sync; the previous batch's gathered boundaries are consumed while this one is in flight
+    bg, pending, gathered = None, [], [None]
+
+    def gather(b, drain=False):
+        if not use_dist:
+            return
+        if bg is not None and b is not None:
+            pending.append(bg.submit(b))
+        while pending and (drain or len(pending) > 1):
+            gathered[0] = bg.result(pending.pop(0))
+
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist:                                         # slot size of the gather: twice the largest count seen
+        b0, _, _ = step()
+        most = max(int(t.numel()) for t in pdist.gather_varlen(b0))
+        bg = pdist.BoundaryGather(1 << int(np.ceil(np.log2(2 * most + 2))), b0.device, b0.dtype)
     for _ in range(args.warmup):
         step()
+    gather(None, drain=True)
     kern = dict(blocksum_ms=0.0, spine_ms=0.0, bridge_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, total_ms=0.0)
     barrier()
     t0 = time.perf_counter()
@@ -112,16 +128,15 @@ def main():
         tm = ctx.timings()                               # HIP-event timings on the library's stream
         for k in kern:
             kern[k] += tm[k]
+    gather(None, drain=True)                             # the last batch's gather is inside the timed region
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        cnt = torch.tensor([bounds.numel()], dtype=torch.int64, device="cuda")
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)                       # the only collective: boundary counts
-        n_bounds = [int(c.item()) for c in allc]
+        n_bounds = [int(t.numel()) for t in gathered[0]]          # the last step's gathered boundaries, all ranks
+        assert torch.equal(gathered[0][rank], bounds), "boundary gather returned something else for this rank"
     else:
         n_bounds = [int(bounds.numel())]
     for k in kern:
@@ -194,7 +209,7 @@ def main():
                                              "(gcc -O2), single thread" % m,
                                    "prefix_boundaries_equal": bool(np.array_equal(ref[:k], got[:k]))}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

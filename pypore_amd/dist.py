@@ -1,9 +1,10 @@
 """Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm, "gloo"
 on CPU for tests).  The path shards embarrassingly -- events / files are independent units
 (Experiment.parse iterates files, then events: DataTypes.py:968-984) -- so there is NO data-path
-collective; the only exchange is the final gather of boundary indices:
-one all_gather of the per-rank counts, then one padded all_gather of the int32 payload
-(tens of KB: latency-bound, a single step over the xGMI links).
+collective; the only exchange is the final gather of boundary indices, tens of KB
+and latency-bound: BoundaryGather does it as one fixed-shape all_gather per batch, enqueued without
+a host sync and overlapped with the next batch; gather_varlen (counts, then padded payload) is the
+general two-collective form.
 """
 import numpy as np
 import torch
@@ -38,6 +39,49 @@ def gather_varlen(local, group=None):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
     return [o[:c] for o, c in zip(out, counts)]
+
+
+class BoundaryGather:
+    """The boundary gather as ONE fixed-shape collective per batch and no host synchronisation on the
+    submitting side: every rank contributes a slot of `capacity` elements, element 0 = its count,
+    the payload behind it.  submit() enqueues the all_gather asynchronously (RCCL's own stream, so the
+    next batch's kernels overlap it); result() waits, reads the counts and slices.  A contribution that
+    does not fit is seen by EVERY rank in the gathered counts, so all ranks fall back to gather_varlen
+    for that batch together (no extra agreement round).  `depth` batches may be in flight."""
+
+    def __init__(self, capacity, device, dtype=torch.int32, group=None, depth=2):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.cap = int(capacity)
+        self.slots = [dict(send=torch.zeros(self.cap, dtype=dtype, device=device),
+                           recv=torch.zeros(self.world * self.cap, dtype=dtype, device=device),
+                           work=None, local=None) for _ in range(depth)]
+        self.k = 0
+
+    def submit(self, local):
+        """Enqueues the gather of `local` (1-D, the gather's dtype/device); returns a ticket."""
+        s = self.slots[self.k % len(self.slots)]
+        assert s["work"] is None, "BoundaryGather: result() of an earlier batch is outstanding"
+        n = local.numel()
+        s["send"][:1].fill_(n)
+        if n < self.cap:
+            s["send"][1:1 + n].copy_(local)
+        s["local"] = local
+        s["work"] = dist.all_gather_into_tensor(s["recv"], s["send"], group=self.group, async_op=True)
+        self.k += 1
+        return self.k - 1
+
+    def result(self, ticket):
+        """Per-rank tensors of batch `ticket` (views into the slot: consume before `depth` more submits)."""
+        s = self.slots[ticket % len(self.slots)]
+        s["work"].wait()
+        s["work"] = None
+        rows = s["recv"].view(self.world, self.cap)
+        counts = [int(c) for c in rows[:, 0].cpu().tolist()]
+        local, s["local"] = s["local"], None
+        if max(counts) >= self.cap:
+            return gather_varlen(local, self.group)
+        return [rows[r, 1:1 + c] for r, c in enumerate(counts)]
 
 
 def segment_units_sharded(unit_lengths, segment_fn, device=None, group=None):

@@ -44,6 +44,16 @@ def _worker(rank, world, port, q):
         t = torch.arange(3 * rank, dtype=torch.int32)
         g = pdist.gather_varlen(t)
         ok = ok and [x.numel() for x in g] == [3 * r for r in range(world)]
+        # the single-collective gather: two batches in flight, then one that overflows its slot
+        bg = pdist.BoundaryGather(8, torch.device("cpu"), torch.int32, depth=2)
+        t0 = bg.submit(torch.arange(2 + rank, dtype=torch.int32) + 10 * rank)
+        t1 = bg.submit(torch.zeros(0, dtype=torch.int32))
+        r0, r1 = bg.result(t0), bg.result(t1)
+        ok = ok and all(np.array_equal(r0[r].numpy(), np.arange(2 + r) + 10 * r) for r in range(world))
+        ok = ok and all(x.numel() == 0 for x in r1)
+        t2 = bg.submit(torch.arange(5 + 20 * rank, dtype=torch.int32))        # rank 1: 25 > 7 payload slots
+        r2 = bg.result(t2)
+        ok = ok and all(np.array_equal(r2[r].numpy(), np.arange(5 + 20 * r)) for r in range(world))
         q.put((rank, bool(ok), [len(b) for b in out]))
     finally:
         dist.destroy_process_group()
