@@ -48,6 +48,9 @@ def lib():
         L.so_lambda_events.restype = ctypes.c_long
         L.so_bessel1_filtfilt.argtypes = [dp, ctypes.c_long, ctypes.c_double, ctypes.c_double, dp]
         L.so_bessel1_filtfilt.restype = ctypes.c_int
+        L.so_align.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp, dp, dp, ctypes.c_int,
+                               dp, ctypes.POINTER(ctypes.c_uint)]
+        L.so_align.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -147,3 +150,29 @@ def bessel_filtfilt(x, cutoff=2000.0, second=1.0e5):
         raise ValueError("The length of the input vector x must be greater than padlen, which is 6." if x.size <= 6
                          else "cutoff must lie strictly between 0 and the Nyquist frequency")
     return out
+
+
+ALIGN_ERRORS = {1: ValueError, 2: IndexError, 3: ZeroDivisionError, 4: IndexError}
+
+
+def align_raw(model_means, model_stds, model_durs, skip_penalty, backslip_penalty, seq_means, seq_stds, seq_durs):
+    """cSegmentAligner(model..., penalties).align(seq...) (calignment.pyx:20-100) -> (rc, score[s-1, m-1], path uint32)."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (model_means, model_stds, model_durs,
+                                                              seq_means, seq_stds, seq_durs)]
+    m, s = a[0].size, a[3].size
+    path = np.zeros(max(s, 1), dtype=np.uint32)
+    score = ctypes.c_double(0.0)
+    rc = lib().so_align(_dptr(a[0]), _dptr(a[1]), _dptr(a[2]), m, float(skip_penalty), float(backslip_penalty),
+                        _dptr(a[3]), _dptr(a[4]), _dptr(a[5]), s, ctypes.byref(score),
+                        path.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)))
+    return rc, score.value, path[:s]
+
+
+def align(model_means, model_stds, model_durs, skip_penalty, backslip_penalty, seq_means, seq_stds, seq_durs):
+    """What the reference returns: (score[s-1, m-1] / np.sum(seq_durs), float64 array of model indices); raises the
+    exception class the compiled reference raises (rc 4 = undefined there, IndexError here)."""
+    rc, score, path = align_raw(model_means, model_stds, model_durs, skip_penalty, backslip_penalty,
+                                seq_means, seq_stds, seq_durs)
+    if rc:
+        raise ALIGN_ERRORS[rc]("cSegmentAligner.align: reference raises here (code %d)" % rc)
+    return score / np.sum(np.asarray(seq_durs, dtype=np.float64)), path.astype(np.float64)

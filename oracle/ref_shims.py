@@ -55,6 +55,14 @@ def load_cparsers():
     return cparsers
 
 
+def load_calignment():
+    """The compiled, unmodified reference calignment (cSegmentAligner)."""
+    if ORACLE_DIR not in sys.path:
+        sys.path.insert(0, ORACLE_DIR)
+    import calignment
+    return calignment
+
+
 def load_reference_parsers():
     """The reference's own parsers.py (lambda_event_parser, SpeedyStatSplit wrapper) under Py3."""
     cparsers = load_cparsers()

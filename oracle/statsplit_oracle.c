@@ -294,3 +294,103 @@ int so_bessel1_filtfilt(const double *x, long n, double cutoff, double second, d
     free(ext);
     return 0;
 }
+
+/* ==== calignment.pyx:20-100  cSegmentAligner =========================
+ * TEST INFRASTRUCTURE like the rest of this file.  Pinned against the compiled, unmodified
+ * reference by tests/golden/make_golden_align.py -> tests/golden/golden_align.npz.
+ *
+ * Semi-local alignment of a sequence of segments (mean, std, duration) to a model of
+ * segments: score[i][j] = best score of aligning seq[0..i] with seq[i] on model[j]; moves
+ * into (i, j): stay (i-1, j), step (i-1, j-1), skip forward over model segments (running
+ * maximum from the left, skip_penalty x skipped duration), slip back (running maximum
+ * from the right, backslip_penalty x duration).
+ *
+ * Return codes follow what the compiled reference does on the same input:
+ *    0  ok
+ *    1  ValueError   (s == 0: the reference cannot create an empty (0, m) array)
+ *    2  IndexError   (an index left [0, m): m == 1 with s > 1; the traceback reaching j == 0
+ *                     before the first segment -- `score[i-1, j-1]` with an unsigned j; a skip to
+ *                     before the model start)
+ *    3  ZeroDivisionError (seq_std * model_std == 0)
+ *    4  no final score above -1: double_argmax (calignment.pyx:11-18) starts from -1 and
+ *       returns an UNINITIALISED int then -- undefined in the reference, reported here
+ * out_score = score[s-1][m-1]  (the reference divides it by numpy's sum of the durations; callers do
+ * that in numpy so that the pairwise summation order is numpy's). out_path: s entries (uint32: the
+ * reference keeps j unsigned, a final skip below 0 shows as 4294967295).                          */
+#define SO_NEGINF (-99999999.0)
+static double so_dmax(double a, double b) { return a >= b ? a : b; }    /* :8 */
+
+int so_align(const double *mm, const double *ms, const double *md, int m,
+             double skip_pen, double back_pen,
+             const double *sm, const double *ss, const double *sd, int s,
+             double *out_score, unsigned *out_path)
+{
+    if (s <= 0) return 1;
+    if (m <= 0) return 1;
+    size_t cells = (size_t)s * (size_t)m;
+    double *match = malloc(cells * sizeof(double)), *score = malloc(cells * sizeof(double));
+    double *skip = malloc(cells * sizeof(double)), *back = malloc(cells * sizeof(double));
+    double *cdur = malloc((size_t)m * sizeof(double));
+    int rc = 0;
+#define AT(a, i, j) a[(size_t)(i) * (size_t)m + (size_t)(j)]
+    { double run = 0.0;                                     /* :30 np.cumsum: sequential */
+      for (int j = 0; j < m; ++j) { run = j ? run + md[j] : md[j]; cdur[j] = run; } }
+    for (int i = 0; i < s && !rc; ++i)                      /* :47-49 */
+        for (int j = 0; j < m; ++j) {
+            double d = sm[i] - mm[j], den = ss[i] * ms[j];
+            if (den == 0.0) { rc = 3; break; }
+            AT(match, i, j) = -(d * d) / den;
+        }
+    if (rc) goto done;
+    for (int j = 0; j < m; ++j)                             /* :51-52 */
+        AT(score, 0, j) = AT(match, 0, j) * sd[0] - skip_pen * (cdur[j] - md[j]);
+    if (s > 1 && m < 2) { rc = 2; goto done; }              /* :59-62 index 1 / m-2 of a 1-wide model */
+    for (int i = 1; i < s; ++i) {
+        AT(skip, i, 0) = SO_NEGINF;                         /* :55-57 */
+        for (int j = 1; j < m; ++j)
+            AT(skip, i, j) = so_dmax(AT(skip, i, j - 1), AT(score, i - 1, j - 1)) - md[j] * skip_pen;
+        AT(back, i, m - 1) = SO_NEGINF;                     /* :58-61 (row j = 0 has the same form) */
+        for (int j = m - 2; j >= 0; --j)
+            AT(back, i, j) = so_dmax(AT(back, i, j + 1), AT(score, i - 1, j + 1)) - md[j + 1] * back_pen;
+        for (int j = 0; j < m; ++j) {                       /* :63-69 */
+            double p = AT(score, i - 1, j);
+            if (j > 0) {
+                if (AT(score, i - 1, j - 1) > p) p = AT(score, i - 1, j - 1);   /* Python max(): first of equals */
+                if (AT(skip, i, j - 1) > p) p = AT(skip, i, j - 1);
+            }
+            if (j < m - 1) p = so_dmax(p, AT(back, i, j));
+            AT(score, i, j) = p + AT(match, i, j) * sd[i];
+        }
+    }
+    {
+        unsigned j = 0, mu = (unsigned)m;
+        double best = -1.0; int found = 0;                  /* :11-18 */
+        for (int q = 0; q < m; ++q)
+            if (AT(score, s - 1, q) > best) { best = AT(score, s - 1, q); j = (unsigned)q; found = 1; }
+        if (!found) { rc = 4; goto done; }
+        for (int i = s - 1; i >= 1; --i) {                  /* :73-97 */
+            out_path[i] = j;
+            if (j >= mu || j == 0) { rc = 2; goto done; }   /* score[i, j] / score[i-1, j-1] out of bounds */
+            double prev = AT(score, i, j) - AT(match, i, j) * sd[i];
+            double tol = 1e-6 * fabs(prev);
+            if (fabs(prev - AT(score, i - 1, j - 1)) <= tol) { j -= 1; continue; }
+            if (fabs(prev - AT(score, i - 1, j)) <= tol) continue;
+            if (j < mu - 1) {
+                unsigned k = j; double t = prev;
+                while (k < mu - 1 && fabs(t - AT(back, i, k)) <= tol) { k += 1; t += md[k] * back_pen; }
+                if (k > j) { j = k; continue; }
+            }
+            if (j > 0) {
+                unsigned k = j; double t = prev;
+                while (k >= 1 && fabs(t - AT(skip, i, k - 1)) <= tol) { k -= 1; t += md[k] * skip_pen; }
+                if (k < j) { j = k - 1u; continue; }
+            }
+        }
+        out_path[0] = j;
+        *out_score = AT(score, s - 1, m - 1);
+    }
+done:
+#undef AT
+    free(match); free(score); free(skip); free(back); free(cdur);
+    return rc;
+}
