@@ -176,6 +176,29 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
 int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int32_t order,
                      double cutoff, double sampling_freq, double *d_out);
 
+/* Replaces cSegmentAligner(model_means, model_stds, model_durs, skip_penalty, backslip_penalty).align(seq_means,
+ * seq_stds, seq_durs) (calignment.pyx:20-100; called from SegmentAligner.align, alignment.py:33-46) for a BATCH of
+ * sequences against one model: sequence q is entries [h_seq_off[q], h_seq_off[q+1]) of the three device arrays
+ * (per-segment mean, std, duration -- e.g. the statistics ps_segment_batch produced).  Model arrays are host
+ * pointers (m doubles each, 1 <= m <= 1024).  Outputs (device): d_scores[q] = score[s-1][m-1] -- the reference
+ * returns it divided by numpy.sum(seq_durs), which the caller does in numpy to keep numpy's summation order --,
+ * d_paths = the model index of every sequence segment (uint32 like the reference's unsigned j; same layout as the
+ * inputs), d_status[q] = what the compiled reference does on that sequence:
+ *   PS_ALIGN_OK; PS_ALIGN_VALUE_ERROR (empty sequence); PS_ALIGN_INDEX_ERROR (one-segment model with s > 1, or the
+ *   traceback reaching model index 0 before the first sequence segment: `score[i-1, j-1]`, calignment.pyx:76);
+ *   PS_ALIGN_ZERO_DIVISION (seq_std * model_std == 0, :49); PS_ALIGN_UNDEFINED (no final score above -1:
+ *   double_argmax, :11-18, returns an uninitialised int there).  Scores and paths are bit-exact with the reference:
+ *   the kernel keeps its operation order (sequential running maxima, fp64, no FMA contraction). */
+#define PS_ALIGN_OK             0
+#define PS_ALIGN_VALUE_ERROR    1
+#define PS_ALIGN_INDEX_ERROR    2
+#define PS_ALIGN_ZERO_DIVISION  3
+#define PS_ALIGN_UNDEFINED      4
+int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_model_stds, const double *h_model_durs,
+                   int32_t m, double skip_penalty, double backslip_penalty, const double *d_seq_means,
+                   const double *d_seq_stds, const double *d_seq_durs, const int64_t *h_seq_off, int32_t n_seq,
+                   double *d_scores, uint32_t *d_paths, int32_t *d_status);
+
 /* Timing of the most recent ps_segment_batch, measured with HIP events on the context's
  * stream: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[3] whole
  * call (host wall clock), ms[4] stitch (assemble kernels, or the host stitch), ms[5] bridge kernel,

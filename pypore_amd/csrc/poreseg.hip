@@ -22,6 +22,7 @@
 
 #include "poreseg.h"
 #include "seg_device.hpp"
+#include "seg_align.hpp"
 
 using namespace ps;
 
@@ -81,6 +82,7 @@ struct ps_ctx {
     int wide_skip = 0;        // ... and the number of calls with that quantum that still start on the LDS-window path
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
+    DevBuf align_in, align_scratch;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
@@ -682,7 +684,8 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
-                      &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev};
+                      &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
+                      &ctx->align_in, &ctx->align_scratch};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1213,6 +1216,72 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
+}
+
+int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_model_stds, const double *h_model_durs,
+                   int32_t m, double skip_penalty, double backslip_penalty, const double *d_seq_means,
+                   const double *d_seq_stds, const double *d_seq_durs, const int64_t *h_seq_off, int32_t n_seq,
+                   double *d_scores, uint32_t *d_paths, int32_t *d_status)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!h_model_means || !h_model_stds || !h_model_durs || !h_seq_off) return fail(ctx, PS_ERR_ARG, "null pointer");
+    if (m < 1 || m > ALIGN_M_MAX) return fail(ctx, PS_ERR_ARG, "model of %d segments: the device aligner takes 1..%d", m, ALIGN_M_MAX);
+    if (n_seq < 0) return fail(ctx, PS_ERR_ARG, "negative sequence count");
+    if (n_seq == 0) return PS_OK;
+    if (!d_scores || !d_paths || !d_status) return fail(ctx, PS_ERR_ARG, "null output pointer");
+    int64_t s_max = 0;
+    for (int32_t q = 0; q < n_seq; ++q) {
+        const int64_t len = h_seq_off[q + 1] - h_seq_off[q];
+        if (len < 0 || h_seq_off[q] < 0) return fail(ctx, PS_ERR_ARG, "sequence offsets must be non-negative and ascending");
+        if (len > INT32_MAX / 2) return fail(ctx, PS_ERR_ARG, "sequence %d too long", q);
+        s_max = std::max(s_max, len);
+    }
+    if (h_seq_off[n_seq] > 0 && (!d_seq_means || !d_seq_stds || !d_seq_durs)) return fail(ctx, PS_ERR_ARG, "null sequence pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // one upload: model rows (mean, std, dur*skip, dur*backslip, first-row penalty, dur), then the offsets
+    const size_t model_bytes = static_cast<size_t>(6) * m * sizeof(double);
+    const size_t off_bytes = (static_cast<size_t>(n_seq) + 1) * sizeof(int64_t);
+    HIP_TRY(ctx, ctx->h_up.reserve(model_bytes + off_bytes));
+    HIP_TRY(ctx, ctx->align_in.reserve(model_bytes + off_bytes));
+    {
+        double *h = ctx->h_up.as<double>();
+        double run = 0.0;                                   // np.cumsum(model_dur): sequential (calignment.pyx:30)
+        for (int j = 0; j < m; ++j) {
+            run = j ? run + h_model_durs[j] : h_model_durs[j];
+            h[j] = h_model_means[j];
+            h[m + j] = h_model_stds[j];
+            h[2 * m + j] = h_model_durs[j] * skip_penalty;              // :57
+            h[3 * m + j] = h_model_durs[j] * backslip_penalty;          // :61-62
+            h[4 * m + j] = skip_penalty * (run - h_model_durs[j]);      // :52
+            h[5 * m + j] = h_model_durs[j];
+        }
+        std::memcpy(h + 6 * m, h_seq_off, off_bytes);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->align_in.p, ctx->h_up.p, model_bytes + off_bytes, hipMemcpyHostToDevice, ctx->stream));
+    AlignModel M;
+    const double *dm = ctx->align_in.as<double>();
+    M.mean = dm; M.std = dm + m; M.dsp = dm + 2 * m; M.dbp = dm + 3 * m; M.pen0 = dm + 4 * m; M.dur = dm + 5 * m;
+    M.m = m; M.skip_pen = skip_penalty; M.back_pen = backslip_penalty;
+    const long long *d_off = reinterpret_cast<const long long *>(dm + 6 * m);
+    // scratch: score, skip_score and backslip_score of one sequence per resident workgroup
+    // traceback block: as many rows as fit in ~48 KB of LDS next to the 9 working rows; 12 KB when the batch is
+    // large enough to want many resident workgroups per CU instead
+    const size_t blk_budget = n_seq > 512 ? (12u << 10) : (48u << 10);
+    const int B = static_cast<int>(std::max<size_t>(1, std::min<size_t>(ALIGN_B_MAX, blk_budget / (3u * m * sizeof(double)))));
+    const size_t lds = align_lds_doubles(m, B) * sizeof(double);
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)));
+    const unsigned long long per_wg = 3ull * static_cast<unsigned long long>(std::max<int64_t>(s_max, 1)) * m;   // doubles
+    const unsigned long long budget = 2ull << 30;          // bytes of scratch at most (unless one sequence needs more)
+    if (per_wg * sizeof(double) > (32ull << 30)) return fail(ctx, PS_ERR_ARG, "a %lld x %d alignment needs more than 32 GiB of scratch", (long long)s_max, m);
+    unsigned grid = std::min<unsigned>(static_cast<unsigned>(n_seq), resident_slots(ctx, align_kernel, ALIGN_NT, lds));
+    grid = static_cast<unsigned>(std::max<unsigned long long>(1, std::min<unsigned long long>(grid, budget / (per_wg * sizeof(double)))));
+    HIP_TRY(ctx, ctx->align_scratch.reserve(static_cast<size_t>(grid) * per_wg * sizeof(double)));
+    hipLaunchKernelGGL(align_kernel, dim3(grid), dim3(ALIGN_NT), lds, ctx->stream, M, d_seq_means, d_seq_stds, d_seq_durs,
+                       d_off, n_seq, ctx->align_scratch.as<double>(), static_cast<long long>(per_wg), B, d_scores, d_paths, d_status);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PS_OK;
 }
 
 }  // extern "C"

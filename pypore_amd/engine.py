@@ -170,6 +170,33 @@ class Context(object):
                                            ctypes.c_void_p(out.data_ptr())), self.handle)
         return out[:samples.numel()]
 
+    def align_batch(self, model_means, model_stds, model_durs, skip_penalty, backslip_penalty,
+                    seq_means, seq_stds, seq_durs, seq_off):
+        """ps_align_batch: cSegmentAligner.align (calignment.pyx:20-100) for a batch of sequences.  Model arrays: host
+        (numpy); sequence arrays: float64 CUDA tensors, sequence q = [seq_off[q], seq_off[q+1]).  Returns CUDA tensors
+        (scores float64 [n_seq] = score[s-1][m-1], paths uint32-as-int64 view avoided: int32 bits of the reference's
+        unsigned j [total], status int32 [n_seq])."""
+        mm, ms, md = (np.ascontiguousarray(a, dtype=np.float64) for a in (model_means, model_stds, model_durs))
+        assert mm.size == ms.size == md.size
+        off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        n_seq = off.size - 1
+        for t in (seq_means, seq_stds, seq_durs):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64 and t.numel() >= int(off[-1])
+        dev = seq_means.device
+        scores = torch.zeros(max(n_seq, 1), dtype=torch.float64, device=dev)
+        paths = torch.zeros(max(int(off[-1]), 1), dtype=torch.int32, device=dev)
+        status = torch.zeros(max(n_seq, 1), dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        dp = ctypes.POINTER(ctypes.c_double)
+        _lib.check(self.L.ps_align_batch(self.handle, mm.ctypes.data_as(dp), ms.ctypes.data_as(dp), md.ctypes.data_as(dp),
+                                         mm.size, float(skip_penalty), float(backslip_penalty),
+                                         ctypes.c_void_p(seq_means.data_ptr()), ctypes.c_void_p(seq_stds.data_ptr()),
+                                         ctypes.c_void_p(seq_durs.data_ptr()),
+                                         off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_seq,
+                                         ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(paths.data_ptr()),
+                                         ctypes.c_void_p(status.data_ptr())), self.handle)
+        return scores[:n_seq], paths[:int(off[-1])], status[:n_seq]
+
     def synth_trace(self, n, seed, seg_end, level_counts, dtype=torch.float32):
         """Synthetic step trace generated directly in HBM (csrc synth_kernel == pypore_amd.synth)."""
         out = torch.empty(n, dtype=dtype, device="cuda:%d" % self.device)
