@@ -91,8 +91,10 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * scans only, 2 verify (screen and exact must agree); "scan_bs" 1 (default) block-sum scan with
  * single-wave workgroups behind the block-prefix kernel, 0 LDS-window scan; "prune" 0 switches the
  * block pruning of the LDS-window scan off; "stitch_host" 1 forces the host-stitch pipeline (halo
- * tiles + seam repairs, otherwise only the fallback); "spine_nt" 256/512/1024, "tree_nt" 256/512
- * workgroup sizes of the LDS-window kernels.  Unknown names return PS_ERR_ARG. */
+ * tiles + seam repairs, otherwise only the fallback); "tree_mw" 1 (default) subtree jobs of the block-sum
+ * scan run on 8-wave workgroups whose waves share the workgroup's job list, 0 single-wave workgroups;
+ * "spine_nt" 256/512/1024, "tree_nt" 256/512 workgroup sizes of the LDS-window kernels.  Unknown names
+ * return PS_ERR_ARG. */
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);
 /* Blocks until all work submitted on the context's stream has finished. */
 int ps_synchronize(ps_ctx *ctx);

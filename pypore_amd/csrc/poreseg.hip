@@ -80,6 +80,7 @@ struct ps_ctx {
     int prune = 1;
     double wide_quantum = 0;  // quantum of the last call K0 refused (counts too wide) ...
     int wide_skip = 0;        // ... and the number of calls with that quantum that still start on the LDS-window path
+    int tree_mw = 1;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
@@ -202,6 +203,23 @@ template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsign
     return PS_OK;
 }
 
+// block-sum scan, TREE_W waves per workgroup sharing the workgroup's job list (tree_mw_kernel)
+template <int DT> int launch_tree_mw(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, size_t n_jobs,
+                                     const AsmHeader *d_hdr)
+{
+    const unsigned want = (nj + TREE_W - 1) / TREE_W;
+    const size_t lds = sizeof(SharedT<64>) * TREE_W;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_mw_kernel<DT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const unsigned grid = std::max(1u, std::min(want, resident_slots(ctx, tree_mw_kernel<DT>, 64 * TREE_W, lds)));
+    hipLaunchKernelGGL((tree_mw_kernel<DT>), dim3(grid), dim3(64 * TREE_W), lds, ctx->stream, cfg,
+                       ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
+                       ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
+                       static_cast<long long>(n_jobs), d_hdr);
+    HIP_TRY(ctx, hipGetLastError());
+    return PS_OK;
+}
+
 struct Anchor { int32_t pos, kind; };
 
 struct TileList {
@@ -317,7 +335,9 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (n_tj) {
         const unsigned g = static_cast<unsigned>(std::min<size_t>(n_tj, 0x7fffffff));
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
-        int lrc = cfg.bsum != nullptr
+        int lrc = cfg.bsum != nullptr && ctx->tree_mw
+                      ? (f32 ? launch_tree_mw<PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree_mw<PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
+                  : cfg.bsum != nullptr
                       ? (f32 ? launch_tree<64, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<64, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
                   : ctx->tree_nt == 512
                       ? (f32 ? launch_tree<512, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<512, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
@@ -667,6 +687,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
@@ -711,6 +732,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
+    else if (n == "tree_mw") ctx->tree_mw = value != 0;
     else if (n == "spine_nt" && (value == 256 || value == 512 || value == 1024)) ctx->spine_nt = static_cast<int>(value);
     else if (n == "tree_nt" && (value == 256 || value == 512)) ctx->tree_nt = static_cast<int>(value);
     else return fail(ctx, PS_ERR_ARG, "unknown option or value: %s", name);

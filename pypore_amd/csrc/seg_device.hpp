@@ -995,6 +995,18 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
     }
 }
 
+// the same for one wave of a multi-wave workgroup (every wave keeps its own counters)
+__device__ __forceinline__ void flush_wave(unsigned bad, const Work &wk, unsigned *status, unsigned long long *work)
+{
+    if (bad) atomicOr(status, bad);
+    if ((threadIdx.x & 63u) == 0 && wk.windows) {
+        atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
+        atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
+        if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
+        if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
+    }
+}
+
 // ---- phase 1: spine of rec(start, end), left subtrees skipped ------------------------------------
 // out (private scratch, int2 = (anchor, kind)); meta[job] = (count, ended, dense position).
 // After the chain stops, the workgroup reserves `count` slots in the dense list with one
@@ -1254,6 +1266,69 @@ __global__ __launch_bounds__(64 * BR_LA, 2) void bridge_la_kernel(DevCfg c, cons
 }
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
+// One job, by the NT threads that share `sh` (a workgroup, or one wave of a multi-wave workgroup when NT == 64).
+template <int NT, int DT>
+__device__ __forceinline__ void tree_job(const DevCfg &c, int *ys, const TreeJob &job, long long ji, int32_t *scratch,
+                                         int2 *spill, int32_t *counts, SharedT<NT> &sh, unsigned &bad, Work &wk)
+{
+    const int tid = ps_tid<NT>();
+    int32_t *out = scratch + job.out_off;
+    int2 *sp_glob = spill + job.out_off;
+    int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0, flushed = 0;
+    int *obuf = reinterpret_cast<int *>(sh.obuf);
+    constexpr int OB = 2 * SharedT<NT>::OB;
+    auto emit = [&](int v) {
+        if (cnt - flushed == OB) {                     // rare: spill the LDS buffer to the private scratch
+            ps_sync<NT>();
+            for (int i = tid; i < OB; i += NT)
+                if (flushed + i < job.out_cap) out[flushed + i] = obuf[i];
+            flushed += OB;
+            ps_sync<NT>();
+        }
+        if (cnt >= job.out_cap) bad |= ST_OUT_OVERFLOW;
+        if (tid == 0) obuf[cnt - flushed] = v;
+        ++cnt;
+    };
+    for (;;) {
+        int kind;
+        int s = find_split<NT, DT, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
+        if (kind == KIND_NONE) {
+            if (sp == 0) break;
+            --sp;
+            if (tid == 0) sh.pop = sp < SharedT<NT>::SN ? sh.stack[sp] : sp_glob[sp - SharedT<NT>::SN];
+            ps_sync<NT>();
+            const int2 top = sh.pop;
+            ps_sync<NT>();
+            emit(top.x);
+            start = top.x; end = top.y; j0 = 0;
+            continue;
+        }
+        if (kind == KIND_EARLY) {                     // [split] + rec(split, end)
+            emit(s);
+            start = s; j0 = 0;
+            continue;
+        }
+        // HIT / LATE: rec(start, s) first, then emit s and continue with rec(s, end)
+        if (sp < SharedT<NT>::SN) {
+            if (tid == 0) sh.stack[sp] = make_int2(s, end);
+        } else if (sp - SharedT<NT>::SN < job.out_cap) {
+            if (tid == 0) sp_glob[sp - SharedT<NT>::SN] = make_int2(s, end);
+        } else {
+            bad |= ST_STACK_OVERFLOW;
+            break;
+        }
+        ++sp;
+        ps_sync<NT>();
+        j0 = left_child_j0(start, s, c.W, c.half);
+        end = s;
+    }
+    if (cnt > job.out_cap) cnt = job.out_cap;
+    ps_sync<NT>();
+    for (int i = flushed + tid; i < cnt; i += NT) out[i] = obuf[i - flushed];
+    if (tid == 0) counts[ji] = cnt;
+    ps_sync<NT>();                                     // obuf / stack are reused by the next job
+}
+
 template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
@@ -1267,65 +1342,45 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(D
     // One workgroup per resident slot, striding over the jobs (a workgroup per job costs more in launches than the
     // one or two scans of a typical job: 0.28 ms against 0.17 ms for the 9 231 jobs of the bench trace).
     for (long long ji = blockIdx.x; ji < n_jobs; ji += gridDim.x) {
-    const TreeJob job = jobs[ji];
-    if (job.out_cap == 0) continue;                    // spine anchor without a left subtree (device stitch)
-    int32_t *out = scratch + job.out_off;
-    int2 *sp_glob = spill + job.out_off;
-    int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0, flushed = 0;
-    int *obuf = reinterpret_cast<int *>(sh.obuf);
-    constexpr int OB = 2 * SharedT<NT>::OB;
-    auto emit = [&](int v) {
-        if (cnt - flushed == OB) {                     // rare: spill the LDS buffer to the private scratch
-            __syncthreads();
-            for (int i = threadIdx.x; i < OB; i += NT)
-                if (flushed + i < job.out_cap) out[flushed + i] = obuf[i];
-            flushed += OB;
-            __syncthreads();
-        }
-        if (cnt >= job.out_cap) bad |= ST_OUT_OVERFLOW;
-        if (threadIdx.x == 0) obuf[cnt - flushed] = v;
-        ++cnt;
-    };
-    for (;;) {
-        int kind;
-        int s = find_split<NT, DT, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
-        if (kind == KIND_NONE) {
-            if (sp == 0) break;
-            --sp;
-            if (threadIdx.x == 0) sh.pop = sp < SharedT<NT>::SN ? sh.stack[sp] : sp_glob[sp - SharedT<NT>::SN];
-            __syncthreads();
-            const int2 top = sh.pop;
-            __syncthreads();
-            emit(top.x);
-            start = top.x; end = top.y; j0 = 0;
-            continue;
-        }
-        if (kind == KIND_EARLY) {                     // [split] + rec(split, end)
-            emit(s);
-            start = s; j0 = 0;
-            continue;
-        }
-        // HIT / LATE: rec(start, s) first, then emit s and continue with rec(s, end)
-        if (sp < SharedT<NT>::SN) {
-            if (threadIdx.x == 0) sh.stack[sp] = make_int2(s, end);
-        } else if (sp - SharedT<NT>::SN < job.out_cap) {
-            if (threadIdx.x == 0) sp_glob[sp - SharedT<NT>::SN] = make_int2(s, end);
-        } else {
-            bad |= ST_STACK_OVERFLOW;
-            break;
-        }
-        ++sp;
-        __syncthreads();
-        j0 = left_child_j0(start, s, c.W, c.half);
-        end = s;
-    }
-    if (cnt > job.out_cap) cnt = job.out_cap;
-    __syncthreads();
-    for (int i = flushed + threadIdx.x; i < cnt; i += NT) out[i] = obuf[i - flushed];
-    if (threadIdx.x == 0) counts[ji] = cnt;
-    __syncthreads();                                   // obuf / stack are reused by the next job
+        const TreeJob job = jobs[ji];
+        if (job.out_cap == 0) continue;                // spine anchor without a left subtree (device stitch)
+        tree_job<NT, DT>(c, ys, job, ji, scratch, spill, counts, sh, bad, wk);
     }
     flush(bad, wk, status, work, 2);
+}
+
+// Block-sum scan, TREE_W waves per workgroup: every wave runs single-wave jobs on its own, and the waves of a
+// workgroup share the workgroup's strided list of jobs through a counter in LDS -- a wave that got short jobs takes
+// more of them (bench trace: 0.165 -> 0.146 ms; 4 waves: 0.150).  A counter in HBM for all workgroups costs more than
+// it balances: the returning atomic sits in front of the scan's loads in the wave's in-order memory counter.
+#ifndef PS_TREE_W
+#define PS_TREE_W 8           // a whole CU at two waves per SIMD
+#endif
+constexpr int TREE_W = PS_TREE_W;
+template <int DT>
+__global__ __launch_bounds__(64 * TREE_W, 2) void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+                                                  int2 *spill, int32_t *counts, unsigned *status,
+                                                  unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr)
+{
+    extern __shared__ int ys[];                        // TREE_W x SharedT<64> (beyond the static 64 KB for 8 waves)
+    __shared__ int next_k;
+    const int wave = threadIdx.x >> 6;
+    SharedT<64> &sh = reinterpret_cast<SharedT<64> *>(ys)[wave];
+    const long long n_jobs = dev_count(hdr, n_jobs_host);
+    unsigned bad = 0;
+    Work wk = PS_WORK_INIT;
+    if (threadIdx.x == 0) next_k = TREE_W;             // the first TREE_W jobs of the list are the waves' own
+    __syncthreads();
+    for (long long k = wave;;) {
+        const long long ji = blockIdx.x + k * gridDim.x;
+        if (ji >= n_jobs) break;
+        const TreeJob job = jobs[ji];
+        if (job.out_cap != 0) tree_job<64, DT>(c, nullptr, job, ji, scratch, spill, counts, sh, bad, wk);
+        int kk = 0;
+        if (ps_tid<64>() == 0) kk = atomicAdd(&next_k, 1);
+        k = __builtin_amdgcn_readfirstlane(kk);
+    }
+    flush_wave(bad, wk, status, work);
 }
 
 // ---- single scans for the API-completeness entry points -----------------------------------------

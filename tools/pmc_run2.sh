@@ -18,7 +18,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in files:
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'spine' not in k and 'tree_k' not in k and 'bridge' not in k: continue
+        if 'spine' not in k and 'tree_' not in k and 'bridge' not in k: continue
         k = k.split('(')[0]
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1

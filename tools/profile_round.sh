@@ -13,4 +13,4 @@ python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 bash tools/pmc_run.sh ${TAG}_pmc > /dev/null 2>&1
 head -20 gpurun_out/${TAG}_kernel_stats.csv
 cat gpurun_out/${TAG}_bench.json
-grep -E "^(fetch|write) " gpurun_out/${TAG}_pmc_summary.txt | grep -E "blocksum|spine|bridge|tree_k"
+grep -E "^(fetch|write) " gpurun_out/${TAG}_pmc_summary.txt | grep -E "blocksum|spine|bridge|tree_"
