@@ -91,7 +91,7 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * scans only, 2 verify (screen and exact must agree); "scan_bs" 1 (default) block-sum scan with
  * single-wave workgroups behind the block-prefix kernel, 0 LDS-window scan; "prune" 0 switches the
  * block pruning of the LDS-window scan off; "stitch_host" 1 forces the host-stitch pipeline (halo
- * tiles + seam repairs, otherwise only the fallback); "tree_mw" 1 (default) subtree jobs of the block-sum
+ * tiles + seam repairs, otherwise only the fallback); "timing" 0/1/2 (see ps_get_timings); "tree_mw" 1 (default) subtree jobs of the block-sum
  * scan run on 8-wave workgroups whose waves share the workgroup's job list, 0 single-wave workgroups;
  * "spine_nt" 256/512/1024, "tree_nt" 256/512 workgroup sizes of the LDS-window kernels.  Unknown names
  * return PS_ERR_ARG. */
@@ -201,10 +201,13 @@ int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_mod
                    const double *d_seq_stds, const double *d_seq_durs, const int64_t *h_seq_off, int32_t n_seq,
                    double *d_scores, uint32_t *d_paths, int32_t *d_status);
 
-/* Timing of the most recent ps_segment_batch, measured with HIP events on the context's
- * stream: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[3] whole
- * call (host wall clock), ms[4] stitch (assemble kernels, or the host stitch), ms[5] bridge kernel,
- * ms[6] block-prefix kernel (K0; 0 for the LDS-window scan).  counters[0] window scans, [1] candidate
+/* Timing of the most recent ps_segment_batch, measured with HIP events on the context's stream.
+ * ms[7] = the call's device work from the first upload to the last result copy (option "timing" >= 1, the
+ * default); ms[3] = whole call on the host's wall clock.  With option "timing" = 2 an event is also recorded
+ * between the phases: ms[0] spine kernel, ms[1] tree kernel, ms[2] gather+stats kernels, ms[4] stitch (assemble
+ * kernels, or the host stitch), ms[5] bridge kernels, ms[6] block-prefix kernel (K0; 0 for the LDS-window scan)
+ * -- every such event keeps the next kernel from starting back to back (about 6 us of idle GPU each), so the
+ * breakdown is a diagnostic and off by default.  counters[0] window scans, [1] candidate
  * positions covered, [2] tiles, [3] tree jobs, [4] seam repairs, [5] windows decided in fp64 (among
  * contenders or by a whole-window scan), [6] of which whole-window scans. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);

@@ -91,7 +91,9 @@ struct ps_ctx {
     DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
         tree_counts, items, item_pos, first_item, ev_off, bounds_off, small;
     HostBuf h_meta, h_dense, h_small, h_up;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};   // [0..7] phase marks (timing level 2), [8] start and [9] end of the call's device work (level 1)
+    int timing = 1;           // 0: no events, 1: start/end of the sequence, 2: an event between the phases as well (each costs
+                              // ~6 us of idle GPU: the next kernel does not start back to back)
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -259,7 +261,7 @@ int run_spines(ps_ctx *ctx, const DevCfg &cfg, const std::vector<SpineJob> &jobs
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     HIP_TRY(ctx, hipMemcpyAsync(ctx->spine_jobs.p, ctx->h_up.p, nj * sizeof(SpineJob), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(&sm->dense, 0, sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     {
         const unsigned g = static_cast<unsigned>(nj);
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
@@ -270,7 +272,7 @@ int run_spines(ps_ctx *ctx, const DevCfg &cfg, const std::vector<SpineJob> &jobs
                       : (f32 ? launch_spine<1024, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_spine<1024, PS_DTYPE_I16>(ctx, cfg, g, sm));
         if (lrc) return lrc;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, ctx->h_meta.reserve(nj * sizeof(int4)));
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->spine_meta.p, nj * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
@@ -286,7 +288,7 @@ int run_spines(ps_ctx *ctx, const DevCfg &cfg, const std::vector<SpineJob> &jobs
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->ms[0] += ms;
+    if (ctx->timing >= 2 && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->ms[0] += ms;
     const int4 *meta = ctx->h_meta.as<int4>();
     const int2 *dense = ctx->h_dense.as<int2>();
     for (size_t j = 0; j < nj; ++j) {
@@ -331,7 +333,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     int rc;
     const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
     SmallLayout *sm = ctx->small.as<SmallLayout>();
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_tj) {
         const unsigned g = static_cast<unsigned>(std::min<size_t>(n_tj, 0x7fffffff));
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
@@ -344,7 +346,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
                       : (f32 ? launch_tree<256, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<256, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr));
         if (lrc) return lrc;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
                        ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>(), d_hdr,
                        ctx->first_item.as<int64_t>(), n_ev, ctx->bounds_off.as<int64_t>());
@@ -371,12 +373,17 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
                                ctx->ev_len.as<int64_t>(), n_ev, d_bounds, ctx->bounds_off.as<int64_t>(), d_stats, scap,
                                reinterpret_cast<unsigned *>(&sm->status), d_hdr);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+        if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     }
     HIP_TRY(ctx, ctx->h_meta.reserve(evb));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[9], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        float seq = 0;                                 // the call's device work, upload to result copies, by HIP events
+        if (ctx->timing >= 1 && hipEventElapsedTime(&seq, ctx->ev[8], ctx->ev[9]) == hipSuccess) ctx->ms[7] = seq;
+    }
     std::memcpy(h_bounds_off, ctx->h_meta.p, evb);
     const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
     if (wide_check && (static_cast<unsigned>(hs.status) & ST_WIDE_RANGE)) return RC_WIDE;    // counts too wide for the block sums
@@ -426,12 +433,12 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         }
     }
     if (!stats_from_digest) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+        if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->ms[1] = ms;
-    if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->ms[2] = ms;
+    if (ctx->timing >= 2 && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->ms[1] = ms;
+    if (ctx->timing >= 2 && hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->ms[2] = ms;
     ctx->ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return PS_OK;
 }
@@ -558,7 +565,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
 
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     if (use_bs && nj) {
         // K0: chunk-prefixed block sums (one streaming pass), per-event centre m, totals + max|k| per 256 blocks
         const int64_t nb_total = boff[n_ev];
@@ -583,12 +590,12 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
         cfg.ev_info = ctx->ev_info.as<int4>();
         cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (nj && use_bs) {
         const unsigned g = static_cast<unsigned>(nj);
         int lrc = f32 ? launch_spine<64, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16>(ctx, cfg, g, sm, true);
         if (lrc) return lrc;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // single-wave bridges first; the seams that run into a stretch without splits are finished by the look-ahead kernel
         lrc = f32 ? launch_bridge<64, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<64, PS_DTYPE_I16>(ctx, cfg, g, sm);
         if (lrc) return lrc;
@@ -602,13 +609,13 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
                       ? (f32 ? launch_spine<512, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<512, PS_DTYPE_I16>(ctx, cfg, g, sm, true))
                       : (f32 ? launch_spine<1024, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<1024, PS_DTYPE_I16>(ctx, cfg, g, sm, true));
         if (lrc) return lrc;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         lrc = ctx->spine_nt == 256
                   ? (f32 ? launch_bridge<256, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<256, PS_DTYPE_I16>(ctx, cfg, g, sm))
                   : (f32 ? launch_bridge<512, PS_DTYPE_F32>(ctx, cfg, g, sm) : launch_bridge<512, PS_DTYPE_I16>(ctx, cfg, g, sm));
         if (lrc) return lrc;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     int *ti = ctx->tile_i32.as<int>();
     const size_t njp = std::max<size_t>(1, nj);
     // per-tile arrays of the stitch live in LDS when they fit: (nj+1) int64 + 4*nj int32
@@ -635,16 +642,16 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
                            ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     AsmHeader hd = {};
     int rc = finish_batch(ctx, cfg, static_cast<size_t>(max_items), max_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin,
                           d_hdr, &hd, use_bs);
     ctx->counters[3] = hd.n_items;
     float ms = 0;
-    if (nj && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[0]) == hipSuccess) ctx->ms[6] = ms;       // blocksum_kernel (K0)
-    if (nj && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[6]) == hipSuccess) ctx->ms[0] = ms;       // spine_kernel
-    if (nj && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[1]) == hipSuccess) ctx->ms[5] = ms;       // bridge_kernel
-    if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]) == hipSuccess) ctx->ms[4] = ms;     // device stitch incl. header sync
+    if (ctx->timing >= 2 && nj && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[0]) == hipSuccess) ctx->ms[6] = ms;       // blocksum_kernel (K0)
+    if (ctx->timing >= 2 && nj && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[6]) == hipSuccess) ctx->ms[0] = ms;       // spine_kernel
+    if (ctx->timing >= 2 && nj && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[1]) == hipSuccess) ctx->ms[5] = ms;       // bridge_kernel
+    if (ctx->timing >= 2 && hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]) == hipSuccess) ctx->ms[4] = ms;     // device stitch incl. header sync
     return rc;
 }
 }  // namespace
@@ -687,6 +694,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
@@ -732,6 +740,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
+    else if (n == "timing") ctx->timing = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(2, value)));
     else if (n == "tree_mw") ctx->tree_mw = value != 0;
     else if (n == "spine_nt" && (value == 256 || value == 512 || value == 1024)) ctx->spine_nt = static_cast<int>(value);
     else if (n == "tree_nt" && (value == 256 || value == 512)) ctx->tree_nt = static_cast<int>(value);
@@ -827,6 +836,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (double &m : ctx->ms) m = 0;
     for (int64_t &c : ctx->counters) c = 0;
+    if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
 
     if (!ctx->stitch_host) {

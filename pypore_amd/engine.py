@@ -46,7 +46,7 @@ class Context(object):
         ms = (ctypes.c_double * 8)()
         cnt = (ctypes.c_int64 * 8)()
         _lib.check(self.L.ps_get_timings(self.handle, ms, 8, cnt, 8))
-        return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4], bridge_ms=ms[5], blocksum_ms=ms[6],
+        return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4], bridge_ms=ms[5], blocksum_ms=ms[6], seq_ms=ms[7],
                     windows=cnt[0], candidates=cnt[1], tiles=cnt[2], tree_jobs=cnt[3], repairs=cnt[4],
                     exact_rescans=cnt[5], full_exact_scans=cnt[6])
 
