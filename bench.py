@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--samples", type=int, default=100_000_000)
     ap.add_argument("--cpu-samples", type=int, default=20_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-detail", action="store_true", help="skip the separate per-kernel timing pass (kernel_ms stays 0)")
     ap.add_argument("--stats", action="store_true", help="also run the per-segment statistics kernel in the step")
     ap.add_argument("--dwell", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="dwell range of the synthetic trace in samples (default: BASELINE's U[1000, 20000))")
@@ -139,7 +140,7 @@ def main():
     # Per-kernel breakdown: a separate, untimed pass with an event between the phases (each such event keeps the next
     # kernel from starting back to back, ~6 us of idle GPU, so the timed region above runs without them).
     ctx.set_option("timing", 2)
-    for _ in range(args.steps):
+    for _ in range(0 if args.no_detail else args.steps):
         step()
         tm = ctx.timings()
         for k in kern:

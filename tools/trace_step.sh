@@ -3,7 +3,7 @@
 ROOT=$PWD
 export TMPDIR=/tmp
 cd /tmp && rm -rf /tmp/ktrace
-rocprofv3 --kernel-trace -d /tmp/ktrace -o out --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu "$@" > /tmp/ktrace.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/ktrace -o out --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-detail "$@" > /tmp/ktrace.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/ktrace/**/*kernel_trace.csv', recursive=True)[0]
