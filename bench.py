@@ -80,33 +80,40 @@ def main():
         trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
         ev_off = np.array([0, n], dtype=np.int64)
 
-        def step():
-            b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats)
-            gather(b)
+        def step(k=None):
+            # k: index of a timed batch when the job gathers its boundaries at the end (N > 1): they are written straight
+            # into row k of the send buffer
+            b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats,
+                                          out=acc[k] if k is not None and acc is not None else None)
+            if k is not None and acc is not None:
+                acc_counts[k] = b.numel()
             return b, o, st
     else:
         ends, lv, _ = synth.file_trace_table(n, seed)
         trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.int16)     # what read_abf's data section holds
         from pypore_amd import pipeline
 
-        def step():
+        def step(k=None):
             st_, ln_, b, o, stt = pipeline.segment_file_trace(trace, synth.QUANTUM, params, threshold=90.0,
                                                               want_stats=args.stats)
-            gather(b)
+            if k is not None and acc is not None:
+                acc[k, :b.numel()].copy_(b)
+                acc_counts[k] = b.numel()
             return b, o, stt
     torch.cuda.synchronize()
 
-    # the final boundary-index gather (RCCL): one fixed-shape all_gather per batch, enqueued without a
-    # host sync; the previous batch's gathered boundaries are consumed while this one is in flight
-    bg, pending, gathered = None, [], [None]
+    # The final boundary-index gather (RCCL), as in Experiment.parse (results are collected after all files are
+    # parsed): every rank writes the boundaries of its K batches into a [K, slot] send buffer and ONE all_gather (plus
+    # one of the K counts) runs at the end of the job, inside the timed region.  (dist.BoundaryGather is the per-batch
+    # form, one asynchronous collective per batch; it costs ~65 us of host time per batch.)
+    acc, acc_counts, recv, recv_counts = None, None, None, None
 
-    def gather(b, drain=False):
+    def final_gather():
         if not use_dist:
             return
-        if bg is not None and b is not None:
-            pending.append(bg.submit(b))
-        while pending and (drain or len(pending) > 1):
-            gathered[0] = bg.result(pending.pop(0))
+        cnt = torch.from_numpy(acc_counts).to(acc.device)
+        dist.all_gather_into_tensor(recv_counts, cnt)
+        dist.all_gather_into_tensor(recv, acc.view(-1))
 
     def barrier():
         torch.cuda.synchronize()
@@ -117,7 +124,11 @@ def main():
     if use_dist:                                         # slot size of the gather: twice the largest count seen
         b0, _, _ = step()
         most = max(int(t.numel()) for t in pdist.gather_varlen(b0))
-        bg = pdist.BoundaryGather(1 << int(np.ceil(np.log2(2 * most + 2))), b0.device, b0.dtype)
+        slot = 1 << int(np.ceil(np.log2(2 * most + 8)))
+        acc = torch.zeros((args.steps, slot), dtype=torch.int32, device=b0.device)
+        acc_counts = np.zeros(args.steps, dtype=np.int64)
+        recv = torch.zeros(world * args.steps * slot, dtype=torch.int32, device=b0.device)
+        recv_counts = torch.zeros(world * args.steps, dtype=torch.int64, device=b0.device)
     # A fresh process starts cold (GPU clocks, pinned staging buffers, the allocator's pools): settle for a fixed
     # 0.2 s before the W warmup steps so that a small W does not leak start-up effects into the K timed steps.
     t_settle = time.perf_counter()
@@ -125,15 +136,14 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
-    gather(None, drain=True)
     kern = dict(blocksum_ms=0.0, spine_ms=0.0, bridge_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, seq_ms=0.0)
     seq_ms = 0.0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bounds, boff, _ = step()
+    for k in range(args.steps):
+        bounds, boff, _ = step(k)
         seq_ms += ctx.timings()["seq_ms"]                # HIP events on the library's stream: first upload .. last result copy
-    gather(None, drain=True)                             # the last batch's gather is inside the timed region
+    final_gather()                                       # the job's boundary gather is inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     seq_ms /= args.steps
@@ -145,14 +155,15 @@ def main():
         tm = ctx.timings()
         for k in kern:
             kern[k] += tm[k]
-    gather(None, drain=True)
     ctx.set_option("timing", 1)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        n_bounds = [int(t.numel()) for t in gathered[0]]          # the last step's gathered boundaries, all ranks
-        assert torch.equal(gathered[0][rank], bounds), "boundary gather returned something else for this rank"
+        all_counts = recv_counts.view(world, args.steps).cpu().numpy()
+        n_bounds = [int(c) for c in all_counts[:, -1]]            # the last batch's boundaries, all ranks
+        mine = recv.view(world, args.steps, -1)[rank, args.steps - 1, :n_bounds[rank]]
+        assert torch.equal(mine, bounds), "boundary gather returned something else for this rank"
     else:
         n_bounds = [int(bounds.numel())]
     for k in kern:

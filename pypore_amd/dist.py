@@ -44,10 +44,15 @@ def gather_varlen(local, group=None):
 class BoundaryGather:
     """The boundary gather as ONE fixed-shape collective per batch and no host synchronisation on the
     submitting side: every rank contributes a slot of `capacity` elements, element 0 = its count,
-    the payload behind it.  submit() enqueues the all_gather asynchronously (RCCL's own stream, so the
-    next batch's kernels overlap it); result() waits, reads the counts and slices.  A contribution that
+    the payload from element HEADER on.  submit() enqueues the all_gather asynchronously (RCCL's own stream, so
+    the next batch's kernels overlap it); result() waits, reads the counts and slices.  A contribution that
     does not fit is seen by EVERY rank in the gathered counts, so all ranks fall back to gather_varlen
-    for that batch together (no extra agreement round).  `depth` batches may be in flight."""
+    for that batch together (no extra agreement round).  `depth` batches may be in flight.
+
+    No copy when the boundaries already sit HEADER elements into a buffer of at least `capacity` elements
+    (engine.segment_batch(..., lead=BoundaryGather.HEADER)): the count goes into the buffer's first element and the
+    buffer's head is sent as it is (whatever lies behind the count's worth of payload is ignored by the receiver)."""
+    HEADER = 4          # elements before the payload (16 bytes: the payload keeps its alignment)
 
     def __init__(self, capacity, device, dtype=torch.int32, group=None, depth=2):
         self.group = group
@@ -63,25 +68,37 @@ class BoundaryGather:
         s = self.slots[self.k % len(self.slots)]
         assert s["work"] is None, "BoundaryGather: result() of an earlier batch is outstanding"
         n = local.numel()
-        s["send"][:1].fill_(n)
-        if n < self.cap:
-            s["send"][1:1 + n].copy_(local)
+        base = local._base
+        if (base is not None and base.dim() == 1 and local.storage_offset() == self.HEADER and base.numel() >= self.cap
+                and base.dtype == s["send"].dtype):
+            send = base[:self.cap]                       # in place: header + payload are already laid out
+            send[:1].fill_(n)
+        else:
+            send = s["send"]
+            send[:1].fill_(n)
+            if n <= self.cap - self.HEADER:
+                send[self.HEADER:self.HEADER + n].copy_(local)
         s["local"] = local
-        s["work"] = dist.all_gather_into_tensor(s["recv"], s["send"], group=self.group, async_op=True)
+        s["work"] = dist.all_gather_into_tensor(s["recv"], send, group=self.group, async_op=True)
         self.k += 1
         return self.k - 1
 
-    def result(self, ticket):
-        """Per-rank tensors of batch `ticket` (views into the slot: consume before `depth` more submits)."""
+    def result(self, ticket, host=True):
+        """Per-rank tensors of batch `ticket` (views into the slot: consume before `depth` more submits).
+        host=False: only waits for the collective (no host sync) and returns the gathered rows [world, capacity] on
+        the device, count in column 0 -- for consumers that stay on the device; an overflowing contribution then
+        shows as a count above capacity - HEADER."""
         s = self.slots[ticket % len(self.slots)]
         s["work"].wait()
         s["work"] = None
         rows = s["recv"].view(self.world, self.cap)
-        counts = [int(c) for c in rows[:, 0].cpu().tolist()]
         local, s["local"] = s["local"], None
-        if max(counts) >= self.cap:
+        if not host:
+            return rows
+        counts = [int(c) for c in rows[:, 0].cpu().tolist()]
+        if max(counts) > self.cap - self.HEADER:
             return gather_varlen(local, self.group)
-        return [rows[r, 1:1 + c] for r, c in enumerate(counts)]
+        return [rows[r, self.HEADER:self.HEADER + c] for r, c in enumerate(counts)]
 
 
 def segment_units_sharded(unit_lengths, segment_fn, device=None, group=None):

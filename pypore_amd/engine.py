@@ -52,10 +52,12 @@ class Context(object):
 
     # ---- the hot path ---------------------------------------------------------------------------
     def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None,
-                      want_spine=False):
+                      want_spine=False, lead=0, out=None):
         """ps_segment_batch on device-resident `samples` (torch float32 or int16 CUDA tensor).
         Returns (bounds int32 CUDA tensor [total], bounds_off int64 numpy [n_ev+1],
-        stats float64 CUDA tensor [total+n_ev, 4] or None)."""
+        stats float64 CUDA tensor [total+n_ev, 4] or None).  lead > 0: the boundaries are a view that starts `lead`
+        elements into their buffer (dist.BoundaryGather puts its header there and sends the buffer as it is).
+        out: int32 CUDA tensor to receive the boundaries (its size is the capacity; ValueError if they do not fit)."""
         assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
         if samples.dtype == torch.float32:
             dtype = _lib.PS_DTYPE_F32
@@ -72,7 +74,11 @@ class Context(object):
             if cap < 0:
                 raise ValueError("min_width must be >= 1")
         dev = samples.device
-        bounds = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        if out is not None:
+            assert out.is_cuda and out.is_contiguous() and out.dtype == torch.int32 and out.dim() == 1
+            bounds, cap = out, int(out.numel())
+        else:
+            bounds = torch.empty(max(cap, 1) + lead, dtype=torch.int32, device=dev)[lead:]
         stats = torch.empty((max(cap, 1) + n_ev, 4), dtype=torch.float64, device=dev) if want_stats else None
         boff = np.zeros(n_ev + 1, dtype=np.int64)
         torch.cuda.current_stream(dev).synchronize()      # inputs produced on torch's stream are ready

@@ -54,6 +54,15 @@ def _worker(rank, world, port, q):
         t2 = bg.submit(torch.arange(5 + 20 * rank, dtype=torch.int32))        # rank 1: 25 > 7 payload slots
         r2 = bg.result(t2)
         ok = ok and all(np.array_equal(r2[r].numpy(), np.arange(5 + 20 * r)) for r in range(world))
+        # in place: the payload already sits HEADER elements into a buffer of at least one slot
+        buf = torch.full((64,), -7, dtype=torch.int32)
+        view = buf[pdist.BoundaryGather.HEADER:][:3 - rank]
+        view.copy_(torch.arange(3 - rank, dtype=torch.int32) + 100 * rank)
+        r3 = bg.result(bg.submit(view))
+        ok = ok and all(np.array_equal(r3[r].numpy(), np.arange(3 - r) + 100 * r) for r in range(world))
+        ok = ok and int(buf[0]) == 3 - rank                                    # the count went into the buffer's head
+        rows = bg.result(bg.submit(view), host=False)                          # device-side consumer: rows, count in column 0
+        ok = ok and rows.shape == (world, 8) and [int(c) for c in rows[:, 0]] == [3 - r for r in range(world)]
         q.put((rank, bool(ok), [len(b) for b in out]))
     finally:
         dist.destroy_process_group()
