@@ -79,12 +79,13 @@ def main():
         lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
         trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
         ev_off = np.array([0, n], dtype=np.int64)
+        out1 = torch.empty(n // PARAMS["min_width"] + 1, dtype=torch.int32, device=trace.device)   # reused result buffer
 
         def step(k=None):
             # k: index of a timed batch when the job gathers its boundaries at the end (N > 1): they are written straight
             # into row k of the send buffer
             b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats,
-                                          out=acc[k] if k is not None and acc is not None else None)
+                                          out=acc[k] if k is not None and acc is not None else out1)
             if k is not None and acc is not None:
                 acc_counts[k] = b.numel()
             return b, o, st
