@@ -81,6 +81,7 @@ struct ps_ctx {
     double wide_quantum = 0;  // quantum of the last call K0 refused (counts too wide) ...
     int wide_skip = 0;        // ... and the number of calls with that quantum that still start on the LDS-window path
     int tree_mw = 1;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list
+    int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
@@ -555,7 +556,19 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     std::memcpy(up + jb + evb, ev_start, evb - sizeof(int64_t));
     std::memcpy(up + jb + 2 * evb, ev_len, evb - sizeof(int64_t));
     std::memcpy(up + jb + 3 * evb, boff.data(), evb);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->up_dev.p, up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->upload_by_kernel) {
+        void *up_devptr = nullptr;                     // the pinned blob as the device sees it
+        HIP_TRY(ctx, hipHostGetDevicePointer(&up_devptr, up, 0));
+        const long long n16 = static_cast<long long>((up_bytes + 15) / 16);
+        const unsigned ug = static_cast<unsigned>(std::max<long long>(1, std::min<long long>((n16 + 255) / 256, 1024)));
+        hipLaunchKernelGGL(upload_kernel, dim3(ug), dim3(256), 0, ctx->stream, static_cast<const int4 *>(up_devptr),
+                           ctx->up_dev.as<int4>(), n16, ctx->small.as<unsigned long long>(),
+                           static_cast<int>(sizeof(SmallLayout) / sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipGetLastError());
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->up_dev.p, up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     char *dup = ctx->up_dev.as<char>();
     ctx->spine_jobs.alias(dup);
     ctx->ev_first_tile.alias(dup + jb);
@@ -694,6 +707,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
@@ -740,6 +754,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
+    else if (n == "upload_by_kernel") ctx->upload_by_kernel = value != 0;
     else if (n == "timing") ctx->timing = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(2, value)));
     else if (n == "tree_mw") ctx->tree_mw = value != 0;
     else if (n == "spine_nt" && (value == 256 || value == 512 || value == 1024)) ctx->spine_nt = static_cast<int>(value);
@@ -837,7 +852,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
     for (double &m : ctx->ms) m = 0;
     for (int64_t &c : ctx->counters) c = 0;
     if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    if (ctx->stitch_host) HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));   // (the device-stitch path clears it with its upload)
 
     if (!ctx->stitch_host) {
         // block-sum scan: candidates must avoid the ragged ends of a window (min_width >= 8) and a window must fit

@@ -1007,6 +1007,18 @@ __device__ __forceinline__ void flush_wave(unsigned bad, const Work &wk, unsigne
     }
 }
 
+// The call's small host tables (tile jobs, event offsets) come to the device by a KERNEL that reads the pinned host
+// blob over PCIe and also clears the status/counter block: a hipMemcpyAsync goes through the SDMA engine, and the hand-over
+// between the engines costs ~35 us before the first kernel of the call can start (memset 2 us + 18 us gap + copy 9 us +
+// 8 us gap in the trace); this kernel runs back to back with its neighbours.
+__global__ __launch_bounds__(256) void upload_kernel(const int4 *src, int4 *dst, long long n16, unsigned long long *zero,
+                                                     int zero_words)
+{
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n16; i += gridDim.x * 256LL) dst[i] = src[i];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_words; i += 256) zero[i] = 0;
+}
+
 // ---- phase 1: spine of rec(start, end), left subtrees skipped ------------------------------------
 // out (private scratch, int2 = (anchor, kind)); meta[job] = (count, ended, dense position).
 // After the chain stops, the workgroup reserves `count` slots in the dense list with one
