@@ -143,7 +143,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         bounds, boff, _ = step(k)
-        seq_ms += ctx.timings()["seq_ms"]                # HIP events on the library's stream: first upload .. last result copy
+        seq_ms += ctx.seq_ms()                           # HIP events on the library's stream: first upload .. last result copy
     final_gather()                                       # the job's boundary gather is inside the timed region
     barrier()
     dt = time.perf_counter() - t0

@@ -42,6 +42,14 @@ class Context(object):
     def set_option(self, name, value):
         _lib.check(self.L.ps_set_option(self.handle, name.encode(), int(value)), self.handle)
 
+    def seq_ms(self):
+        """Device time of the most recent segment call (HIP events, first upload .. last result copy), in ms: the
+        light accessor for timed loops (timings() builds a dict of everything)."""
+        if not hasattr(self, "_tm"):
+            self._tm = ((ctypes.c_double * 8)(), (ctypes.c_int64 * 8)())
+        self.L.ps_get_timings(self.handle, self._tm[0], 8, self._tm[1], 8)
+        return self._tm[0][7]
+
     def timings(self):
         ms = (ctypes.c_double * 8)()
         cnt = (ctypes.c_int64 * 8)()
