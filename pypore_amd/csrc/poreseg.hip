@@ -123,6 +123,8 @@ int fail(ps_ctx *ctx, int code, const char *fmt, ...)
 
 // status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..3] work, [4] dense count
 // (hdr: the stitch header lives behind the counters so that one copy brings both back)
+// (SMALL_TAIL bytes behind it hold the per-event offsets of small batches, so that one copy brings everything back)
+constexpr size_t SMALL_TAIL = 64 * 1024;
 struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9]; AsmHeader hdr; };
 
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
@@ -376,16 +378,22 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     }
-    HIP_TRY(ctx, ctx->h_meta.reserve(evb));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    const bool one_copy = ctx->bounds_off.p == ctx->small.as<char>() + sizeof(SmallLayout);
+    if (one_copy) {
+        HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout) + evb));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout) + evb, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        HIP_TRY(ctx, ctx->h_meta.reserve(evb));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[9], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     {
         float seq = 0;                                 // the call's device work, upload to result copies, by HIP events
         if (ctx->timing >= 1 && hipEventElapsedTime(&seq, ctx->ev[8], ctx->ev[9]) == hipSuccess) ctx->ms[7] = seq;
     }
-    std::memcpy(h_bounds_off, ctx->h_meta.p, evb);
+    std::memcpy(h_bounds_off, one_copy ? ctx->h_small.as<char>() + sizeof(SmallLayout) : ctx->h_meta.as<char>(), evb);
     const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
     if (wide_check && (static_cast<unsigned>(hs.status) & ST_WIDE_RANGE)) return RC_WIDE;    // counts too wide for the block sums
     rc = check_status(ctx, static_cast<unsigned>(hs.status));
@@ -539,7 +547,8 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int32_t)));
     HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int2)));
     HIP_TRY(ctx, ctx->first_item.reserve(evb));
-    HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
+    if (evb <= SMALL_TAIL) ctx->bounds_off.alias(ctx->small.as<char>() + sizeof(SmallLayout));   // comes back with the status block
+    else HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
     ctx->asm_hdr.alias(&ctx->small.as<SmallLayout>()->hdr);
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
 
@@ -697,7 +706,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
-    if (ctx->small.reserve(sizeof(SmallLayout)) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
+    if (ctx->small.reserve(sizeof(SmallLayout) + SMALL_TAIL) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     ctx->lds_max_samples = (LDS_BYTES_MAX - 1024 * 8 - 256) / (static_cast<int>(sizeof(lds_t)) + 1);   // samples + block sums
     if (const char *e = std::getenv("PORESEG_MODE")) ctx->mode = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_SPINE_NT")) ctx->spine_nt = std::atoi(e);
