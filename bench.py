@@ -28,8 +28,8 @@ HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 BYTES_PER_SAMPLE = 4       # one fp32 read per input sample
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (r01_bs_pmc_summary.txt):
 # FETCH_SIZE (KiB) x2 per the gfx950 correction + WRITE_SIZE (KiB), fp32 trace workload, default build.
-PMC_TRAFFIC = {"blocksum_ms": (2 * 195355 + 196838) * 1024, "spine_ms": (2 * 186308 + 310) * 1024,
-               "bridge_ms": (2 * (3937 + 155) + 86) * 1024, "tree_ms": (2 * 87874 + 1426) * 1024}
+PMC_TRAFFIC = {"blocksum_ms": (2 * 195356 + 196838) * 1024, "spine_ms": (2 * 186039 + 310) * 1024,
+               "bridge_ms": (2 * (3940 + 155) + 86) * 1024, "tree_ms": (2 * 87959 + 1428) * 1024}
 PMC_TRAFFIC_BYTES = sum(PMC_TRAFFIC.values())
 
 
