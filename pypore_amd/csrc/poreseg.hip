@@ -82,6 +82,7 @@ struct ps_ctx {
     int wide_skip = 0;        // ... and the number of calls with that quantum that still start on the LDS-window path
     int tree_mw = 1;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
+    int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
@@ -716,6 +717,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_FILTER_FUSED")) ctx->filter_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
@@ -763,6 +765,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
+    else if (n == "filter_fused") ctx->filter_fused = value != 0;
     else if (n == "upload_by_kernel") ctx->upload_by_kernel = value != 0;
     else if (n == "timing") ctx->timing = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(2, value)));
     else if (n == "tree_mw") ctx->tree_mw = value != 0;
@@ -1246,6 +1249,26 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     f.zi = (f.b1 - f.a1 * f.b0) / (1.0 + f.a1);        // lfilter_zi: steady state of the delay for a unit step input
     FiltGeom g;
     g.n = n; g.total = n + 2 * FILT_PAD;
+    // Fast filters (the state forgets within a halo of <= 1024 samples): both directions in one kernel over tiles
+    // with halos.  alpha^H <= 2^-60.
+    if (ctx->filter_fused && f.alpha > 0.0 && f.alpha < 1.0) {
+        const double h_req = std::ceil(60.0 * std::log(2.0) / -std::log(f.alpha));
+        const int H = h_req <= 1024.0 ? std::max(64, (static_cast<int>(h_req) + 63) / 64 * 64) : 0;   // a multiple of 64, at most 1024
+        if (H) {
+            g.lead = 0; g.padded = g.total;
+            const int T = FILT_CHUNK - 2 * H;
+            const dim3 fgrid(static_cast<unsigned>((g.total + T - 1) / T));
+            HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+            unsigned *fst = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->status);
+            if (cfg.dtype == PS_DTYPE_F32) hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_F32>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
+            else                           hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_I16>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
+        }
+    }
     const int64_t n_chunks = (g.total + FILT_CHUNK - 1) / FILT_CHUNK;
     g.padded = n_chunks * FILT_CHUNK;                  // the intermediate is stored behind a lead-in (seg_filter.hpp)
     g.lead = g.padded - g.total;

@@ -110,3 +110,29 @@ def test_filter_rejects_bad_arguments():
         ctx.filter_bessel(dev, 1.0, order=3)
     with pytest.raises(ValueError):
         ctx.filter_bessel(dev, 1.0, cutoff=60000., sampling_freq=1e5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cutoff,n", [(2000., 3_000_001), (2000., 7), (2000., 3072 * 2 + 5), (700., 500_000), (5000., 100_000),
+                                      (20000., 100_000), (10000., 4096 - 12), (1200., 2_000_000), (600., 50_000)])
+def test_fused_filter_equals_three_pass_scan(cutoff, n):
+    """Fast filters run both directions in one kernel over tiles with halos (the state forgets within the halo to
+    2^-60); the result must agree with the exact three-pass scan to rounding, for every halo size the host can pick
+    (at 100 kHz: 960 for 700 Hz, 576 for 1.2 kHz, 384 for 2 kHz, 192 for 5 kHz, 64 above; 600 Hz is too slow and takes
+    the exact scan either way), tiles at the ends of the sequence and inputs shorter than a tile."""
+    import torch
+    from pypore_amd import engine
+    ctx = engine.context(0)
+    k = synth.random_dwell_counts(n, 17, 2, 4) if n < 100 else synth.random_dwell_counts(n, 17, 300, 5000)
+    dev = torch.from_numpy(k.astype(np.int16)).cuda()
+    try:
+        ctx.set_option("filter_fused", 0)
+        exact = ctx.filter_bessel(dev, synth.QUANTUM, cutoff=cutoff, sampling_freq=1e5).cpu().numpy()
+        ctx.set_option("filter_fused", 1)
+        fused = ctx.filter_bessel(dev, synth.QUANTUM, cutoff=cutoff, sampling_freq=1e5).cpu().numpy()
+    finally:
+        ctx.set_option("filter_fused", 1)
+    scale = np.max(np.abs(exact))
+    assert np.max(np.abs(fused - exact)) <= 2e-14 * scale
+    ref = oracle.bessel_filtfilt(k * synth.QUANTUM, cutoff, 1e5)
+    assert np.max(np.abs(fused - ref)) <= 1e-10 * np.max(np.abs(ref))
