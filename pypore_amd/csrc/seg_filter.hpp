@@ -254,8 +254,11 @@ __global__ __launch_bounds__(FILT_NT) void filt_apply_kernel(DevCfg c, FiltCoef 
 // contains the end), and writes the T elements in the middle: 4 096 / T x 4 B in, 8 B out per sample instead of the
 // 32 B of the three-pass scan, no intermediate in HBM, no carry kernels.  The host picks H from the pole (H <= 1024,
 // i.e. poles up to 0.96: cutoffs from ~0.6 kHz at 100 kHz sampling); slower filters take the exact scan above.
+#ifndef PS_FILT_OCC
+#define PS_FILT_OCC 2          // workgroups per CU the fused kernel is compiled for
+#endif
 template <int DT>
-__global__ __launch_bounds__(FILT_NT) void filt_fused_kernel(DevCfg c, FiltCoef f, FiltGeom g, int H, double *out, unsigned *status)
+__global__ __launch_bounds__(FILT_NT, PS_FILT_OCC) void filt_fused_kernel(DevCfg c, FiltCoef f, FiltGeom g, int H, double *out, unsigned *status)
 {
     __shared__ Affine wsum[FILT_NT / 64];
     __shared__ double lds[FILT_LDS];
