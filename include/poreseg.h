@@ -91,7 +91,10 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * scans only, 2 verify (screen and exact must agree); "scan_bs" 1 (default) block-sum scan with
  * single-wave workgroups behind the block-prefix kernel, 0 LDS-window scan; "prune" 0 switches the
  * block pruning of the LDS-window scan off; "stitch_host" 1 forces the host-stitch pipeline (halo
- * tiles + seam repairs, otherwise only the fallback); "timing" 0/1/2 (see ps_get_timings); "tree_mw" 1 (default) subtree jobs of the block-sum
+ * tiles + seam repairs, otherwise only the fallback); "timing" 0/1/2 (see ps_get_timings); "upload_by_kernel" 1
+ * (default) the call's host tables are fetched by a kernel reading the pinned blob, 0 hipMemcpyAsync; "filter_fused" 1
+ * (default) fast filters run both directions in one kernel over tiles with halos, 0 always the exact three-pass
+ * scan; "tree_mw" 1 (default) subtree jobs of the block-sum
  * scan run on 8-wave workgroups whose waves share the workgroup's job list, 0 single-wave workgroups;
  * "spine_nt" 256/512/1024, "tree_nt" 256/512 workgroup sizes of the LDS-window kernels.  Unknown names
  * return PS_ERR_ARG. */

@@ -566,9 +566,9 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     std::memcpy(up + jb + evb, ev_start, evb - sizeof(int64_t));
     std::memcpy(up + jb + 2 * evb, ev_len, evb - sizeof(int64_t));
     std::memcpy(up + jb + 3 * evb, boff.data(), evb);
-    if (ctx->upload_by_kernel) {
-        void *up_devptr = nullptr;                     // the pinned blob as the device sees it
-        HIP_TRY(ctx, hipHostGetDevicePointer(&up_devptr, up, 0));
+    void *up_devptr = nullptr;                         // the pinned blob as the device sees it (else: plain copy)
+    if (ctx->upload_by_kernel && hipHostGetDevicePointer(&up_devptr, up, 0) != hipSuccess) { up_devptr = nullptr; (void)hipGetLastError(); }
+    if (up_devptr) {
         const long long n16 = static_cast<long long>((up_bytes + 15) / 16);
         const unsigned ug = static_cast<unsigned>(std::max<long long>(1, std::min<long long>((n16 + 255) / 256, 1024)));
         hipLaunchKernelGGL(upload_kernel, dim3(ug), dim3(256), 0, ctx->stream, static_cast<const int4 *>(up_devptr),
