@@ -150,6 +150,7 @@ def main():
     seq_ms /= args.steps
     # Per-kernel breakdown: a separate, untimed pass with an event between the phases (each such event keeps the next
     # kernel from starting back to back, ~6 us of idle GPU, so the timed region above runs without them).
+    tm = ctx.timings()                                   # work counters of the last timed step
     ctx.set_option("timing", 2)
     for _ in range(0 if args.no_detail else args.steps):
         step()

@@ -42,6 +42,15 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // as reserve(), but a fresh allocation is cleared (buffers whose stale contents are compared with an epoch)
+    hipError_t reserve_zeroed(size_t bytes, hipStream_t st)
+    {
+        const void *before = p;
+        const size_t cap0 = cap;
+        hipError_t e = reserve(bytes);
+        if (e == hipSuccess && (p != before || cap != cap0) && p) e = hipMemsetAsync(p, 0, cap, st);
+        return e;
+    }
     // Points this buffer into `blob` (one upload for several small arrays); a later reserve() allocates afresh.
     void alias(void *ptr) { if (p && owned) (void)hipFree(p); p = ptr; cap = 0; owned = false; }
     void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
@@ -84,6 +93,20 @@ struct ps_ctx {
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
+    int spec_tree = 0;        // 1: waves of the spine kernel whose chains have ended run subtree jobs speculatively (spine_spec_kernel; measured slower: the scans are issue-bound)
+    int spec_flags = 1;       // spine_spec_kernel: 1 = chains at high priority, 2 = stop speculating when all chains have ended
+    int epoch = 0;            // call counter: tag of this call's queue entries and speculative records
+    DevBuf spec_queue, spec_qaux, spec_rec;
+    // host-side caches: occupancy per kernel, dynamic-LDS attribute last set, the tile tables of the last call
+    struct OccKey { const void *fn; int nt; size_t lds; unsigned slots; };
+    std::vector<OccKey> occ_cache;
+    std::vector<std::pair<const void *, int>> attr_cache;
+    struct TileCache {
+        bool valid = false;
+        int32_t n_ev = 0; int mw = 0, W = 0; int64_t L = 0; bool use_bs = false;
+        std::vector<int64_t> ev_start, ev_len;
+        size_t nj = 0, jb = 0, up_bytes = 0; int64_t list_entries = 0, total_len = 0, sample_end = 0, nb_total = 0, spec_total = 0;
+    } tile_cache;
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
@@ -126,7 +149,7 @@ int fail(ps_ctx *ctx, int code, const char *fmt, ...)
 // (hdr: the stitch header lives behind the counters so that one copy brings both back)
 // (SMALL_TAIL bytes behind it hold the per-event offsets of small batches, so that one copy brings everything back)
 constexpr size_t SMALL_TAIL = 64 * 1024;
-struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9]; AsmHeader hdr; };
+struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9], qctl, qhead; AsmHeader hdr; };
 
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
              double min_gain, DevCfg *c)
@@ -170,21 +193,40 @@ constexpr int LDS_BYTES_MAX = 160 * 1024 - static_cast<int>(sizeof(Shared)) - 51
 // workgroup per slot and stride over their jobs.
 template <typename K> unsigned resident_slots(ps_ctx *ctx, K kernel, int nt, size_t lds)
 {
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    for (const auto &k : ctx->occ_cache)
+        if (k.fn == fn && k.nt == nt && k.lds == lds) return k.slots;
     int per_cu = 0;
     if (ctx->n_cu <= 0) {
         hipDeviceProp_t prop;
         ctx->n_cu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), nt, lds) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, lds) != hipSuccess || per_cu <= 0)
         per_cu = 1;
-    return static_cast<unsigned>(per_cu) * static_cast<unsigned>(ctx->n_cu);
+    const unsigned slots = static_cast<unsigned>(per_cu) * static_cast<unsigned>(ctx->n_cu);
+    ctx->occ_cache.push_back({fn, nt, lds, slots});
+    return slots;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when the value changes (it is a driver call on every launch otherwise)
+hipError_t set_dyn_lds(ps_ctx *ctx, const void *fn, int lds)
+{
+    for (auto &a : ctx->attr_cache)
+        if (a.first == fn) {
+            if (a.second == lds) return hipSuccess;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) a.second = lds;
+            return e;
+        }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) ctx->attr_cache.push_back({fn, lds});
+    return e;
 }
 
 template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, bool list_mode = false)
 {
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(spine_kernel<NT, DT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(spine_kernel<NT, DT>), static_cast<int>(lds)));
     const unsigned grid = std::min(nj, resident_slots(ctx, spine_kernel<NT, DT>, NT, lds));
     hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(),
@@ -194,12 +236,25 @@ template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsig
     return PS_OK;
 }
 
+// block-sum scan: tile chains + speculative subtree jobs in the idle tail (spine_spec_kernel)
+template <int DT> int launch_spine_spec(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, int64_t qcap, int64_t spec_base)
+{
+    const unsigned grid = std::min(nj, resident_slots(ctx, spine_spec_kernel<DT>, 64, 0));
+    hipLaunchKernelGGL((spine_spec_kernel<DT>), dim3(grid), dim3(64), 0, ctx->stream, cfg, ctx->spine_jobs.as<SpineJob>(),
+                       ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(), ctx->spec_queue.as<unsigned long long>(),
+                       static_cast<long long>(qcap), &sm->qctl, &sm->qhead,
+                       ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(), static_cast<long long>(spec_base),
+                       ctx->spec_rec.as<SpecRec>(), ctx->epoch, ctx->spec_flags, reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
+                       static_cast<int>(nj));
+    HIP_TRY(ctx, hipGetLastError());
+    return PS_OK;
+}
+
 template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, size_t n_jobs,
                                           const AsmHeader *d_hdr)
 {
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_kernel<NT, DT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(tree_kernel<NT, DT>), static_cast<int>(lds)));
     const unsigned grid = std::min(nj, resident_slots(ctx, tree_kernel<NT, DT>, NT, lds));
     hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
@@ -215,8 +270,7 @@ template <int DT> int launch_tree_mw(ps_ctx *ctx, const DevCfg &cfg, unsigned nj
 {
     const unsigned want = (nj + TREE_W - 1) / TREE_W;
     const size_t lds = sizeof(SharedT<64>) * TREE_W;
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tree_mw_kernel<DT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(tree_mw_kernel<DT>), static_cast<int>(lds)));
     const unsigned grid = std::max(1u, std::min(want, resident_slots(ctx, tree_mw_kernel<DT>, 64 * TREE_W, lds)));
     hipLaunchKernelGGL((tree_mw_kernel<DT>), dim3(grid), dim3(64 * TREE_W), lds, ctx->stream, cfg,
                        ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
@@ -469,8 +523,7 @@ template <int DT> int launch_bridge_la(ps_ctx *ctx, const DevCfg &cfg, unsigned 
 template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bridge_kernel<NT, DT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(bridge_kernel<NT, DT>), static_cast<int>(lds)));
     const unsigned grid = std::min(nj, resident_slots(ctx, bridge_kernel<NT, DT>, NT, lds));
     hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
@@ -489,50 +542,84 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
                         std::chrono::steady_clock::time_point t_begin)
 {
     DevCfg cfg = cfg_in;
-    int64_t total_len = 0, sample_end = 0;
-    for (int e = 0; e < n_ev; ++e) { total_len += ev_len[e]; sample_end = std::max(sample_end, ev_start[e] + ev_len[e]); }
     int64_t L = ctx->tile_len;
-    if (L <= 0) L = use_bs ? std::max<int64_t>(4LL * W, (total_len + 2047) / 2048)
-                           : std::max<int64_t>(8LL * W, (total_len + 1023) / 1024);
-    L = (L + 7) & ~7LL;
-    L = std::min<int64_t>(L, 0x7fffffff);
-    std::vector<SpineJob> jobs;
-    std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
-    int64_t list_entries = 0, vb_run = 0;
-    for (int e = 0; e < n_ev; ++e) {
-        ev_first_tile[e] = static_cast<int64_t>(jobs.size());
-        const int64_t len = ev_len[e];
-        if (len == 0) continue;
-        const int64_t vbase = vb_run;
-        vb_run += len;
-        // tiles of one event share one length: the event is cut evenly (a 50k event with L = 40k: 2 x 25k)
-        const int64_t nt0 = (len + L - 1) / L;
-        const int64_t Le = std::min<int64_t>(((len + nt0 - 1) / nt0 + 7) & ~7LL, 0x7fffffff);
-        const int64_t nt = (len + Le - 1) / Le;
-        if (static_cast<int64_t>(jobs.size()) + nt > 0x7ffffff0) return RC_FALLBACK;
-        for (int64_t t = 0; t < nt; ++t) {
-            SpineJob j;
-            j.base = ev_start[e];
-            j.start = static_cast<int32_t>(t * Le);
-            j.end = static_cast<int32_t>(len);
-            j.stop = static_cast<int32_t>(t == nt - 1 ? len : (t + 1) * Le);
-            j.out_cap = static_cast<int32_t>(std::min<int64_t>((j.stop - j.start) / mw + 4, 0x7fffffff));
-            j.out_off = list_entries;
-            j.first_tile = static_cast<int32_t>(ev_first_tile[e]);
-            j.ntiles = static_cast<int32_t>(nt);
-            j.tile_len = static_cast<int32_t>(Le);
-            j.ev = e;
-            j.vbase = vbase;
-            list_entries += j.out_cap;
-            jobs.push_back(j);
+    // The tile tables depend only on the event layout and the parameters: a call that repeats the previous one's
+    // (the bench loop; a file segmented with several parameter sets) reuses the tables that are still on the device.
+    ps_ctx::TileCache &tc = ctx->tile_cache;
+    const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
+    bool reuse = tc.valid && tc.n_ev == n_ev && tc.mw == mw && tc.W == W && tc.L == L && tc.use_bs == use_bs &&
+                 std::equal(ev_start, ev_start + n_ev, tc.ev_start.begin()) && std::equal(ev_len, ev_len + n_ev, tc.ev_len.begin());
+    if (!reuse) {
+        tc.valid = false;
+        int64_t total_len = 0, sample_end = 0;
+        for (int e = 0; e < n_ev; ++e) { total_len += ev_len[e]; sample_end = std::max(sample_end, ev_start[e] + ev_len[e]); }
+        int64_t Lt = L;
+        if (Lt <= 0) Lt = use_bs ? std::max<int64_t>(4LL * W, (total_len + 2047) / 2048)
+                                 : std::max<int64_t>(8LL * W, (total_len + 1023) / 1024);
+        Lt = (Lt + 7) & ~7LL;
+        Lt = std::min<int64_t>(Lt, 0x7fffffff);
+        std::vector<SpineJob> jobs;
+        std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
+        int64_t list_entries = 0, vb_run = 0, spec_total = 0;
+        for (int e = 0; e < n_ev; ++e) {
+            ev_first_tile[e] = static_cast<int64_t>(jobs.size());
+            const int64_t len = ev_len[e];
+            if (len == 0) continue;
+            const int64_t vbase = vb_run;
+            vb_run += len;
+            // tiles of one event share one length: the event is cut evenly (a 50k event with L = 40k: 2 x 25k)
+            const int64_t nt0 = (len + Lt - 1) / Lt;
+            const int64_t Le = std::min<int64_t>(((len + nt0 - 1) / nt0 + 7) & ~7LL, 0x7fffffff);
+            const int64_t nt = (len + Le - 1) / Le;
+            if (static_cast<int64_t>(jobs.size()) + nt > 0x7ffffff0) return RC_FALLBACK;
+            for (int64_t t = 0; t < nt; ++t) {
+                SpineJob j;
+                j.base = ev_start[e];
+                j.start = static_cast<int32_t>(t * Le);
+                j.end = static_cast<int32_t>(len);
+                j.stop = static_cast<int32_t>(t == nt - 1 ? len : (t + 1) * Le);
+                j.out_cap = static_cast<int32_t>(std::min<int64_t>((j.stop - j.start) / mw + 4, 0x7fffffff));
+                j.out_off = list_entries;
+                j.first_tile = static_cast<int32_t>(ev_first_tile[e]);
+                j.ntiles = static_cast<int32_t>(nt);
+                j.tile_len = static_cast<int32_t>(Le);
+                j.ev = e;
+                j.vbase = vbase;
+                // speculative subtree outputs of the tile's own pairs: a chain ends before stop + 3 W (its windows start
+                // before stop + 2 W), region of pair i at (pred - start)/mw + i
+                j.spec_off = spec_total;
+                spec_total += 2 * ((std::min<int64_t>(len, static_cast<int64_t>(j.stop) + 3LL * W) - j.start) / mw + 2) + 4;
+                list_entries += j.out_cap;
+                jobs.push_back(j);
+            }
         }
+        ev_first_tile[n_ev] = static_cast<int64_t>(jobs.size());
+        const size_t nj = jobs.size();
+        // one upload: [jobs | ev_first_tile | ev_start | ev_len | ev_boff] -> one device blob the five arrays point into
+        const size_t jb = (nj * sizeof(SpineJob) + 15) & ~static_cast<size_t>(15);
+        std::vector<int64_t> boff(static_cast<size_t>(n_ev) + 1, 0);           // first block of every event (K0)
+        for (int e = 0; e < n_ev; ++e) boff[e + 1] = boff[e] + (ev_len[e] + 7) / 8;
+        const size_t up_bytes = jb + 4 * evb;
+        HIP_TRY(ctx, ctx->h_up.reserve(up_bytes + 64));
+        HIP_TRY(ctx, ctx->up_dev.reserve(up_bytes + 64));
+        char *up = ctx->h_up.as<char>();
+        if (nj) std::memcpy(up, jobs.data(), nj * sizeof(SpineJob));
+        std::memcpy(up + jb, ev_first_tile.data(), evb);
+        std::memcpy(up + jb + evb, ev_start, evb - sizeof(int64_t));
+        std::memcpy(up + jb + 2 * evb, ev_len, evb - sizeof(int64_t));
+        std::memcpy(up + jb + 3 * evb, boff.data(), evb);
+        tc.n_ev = n_ev; tc.mw = mw; tc.W = W; tc.L = L; tc.use_bs = use_bs;
+        tc.ev_start.assign(ev_start, ev_start + n_ev); tc.ev_len.assign(ev_len, ev_len + n_ev);
+        tc.nj = nj; tc.jb = jb; tc.up_bytes = up_bytes; tc.list_entries = list_entries; tc.total_len = total_len;
+        tc.sample_end = sample_end; tc.nb_total = boff[n_ev]; tc.spec_total = spec_total;
     }
-    ev_first_tile[n_ev] = static_cast<int64_t>(jobs.size());
-    const size_t nj = jobs.size();
+    const size_t nj = tc.nj, jb = tc.jb, up_bytes = tc.up_bytes;
+    const int64_t list_entries = tc.list_entries, total_len = tc.total_len, sample_end = tc.sample_end;
+    const bool spec = use_bs && ctx->spec_tree && nj > 0;
+    const int64_t spec_total = spec ? tc.spec_total : 0;
     ctx->counters[2] = static_cast<int64_t>(nj);
     const int64_t max_items = list_entries + static_cast<int64_t>(nj) * BR_MAX;
     const int64_t tscratch_bound = total_len / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
-    const size_t evb = (static_cast<size_t>(n_ev) + 1) * sizeof(int64_t);
 
     HIP_TRY(ctx, ctx->spine_scratch.reserve(std::max<int64_t>(1, list_entries) * sizeof(int2)));
     HIP_TRY(ctx, ctx->spine_meta.reserve(std::max<size_t>(4, nj) * sizeof(int4)));
@@ -545,39 +632,42 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<int64_t>(1, max_items) * sizeof(int32_t)));
     HIP_TRY(ctx, ctx->items.reserve(std::max<int64_t>(1, max_items) * sizeof(Item)));
     HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(max_items) + 1) * sizeof(int64_t)));
-    HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int32_t)));
-    HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int2)));
+    // (the speculative subtree outputs of the spine kernel live behind the regular regions of the same two buffers)
+    HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound + spec_total) * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound + spec_total) * sizeof(int2)));
     HIP_TRY(ctx, ctx->first_item.reserve(evb));
     if (evb <= SMALL_TAIL) ctx->bounds_off.alias(ctx->small.as<char>() + sizeof(SmallLayout));   // comes back with the status block
     else HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
     ctx->asm_hdr.alias(&ctx->small.as<SmallLayout>()->hdr);
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    if (spec) {
+        // queue of speculative pairs and their records: tagged with the call's epoch, so nothing is cleared per call
+        if (++ctx->epoch == 0x7fffffff) {              // (wrap: clear the tags once every 2^31 calls)
+            ctx->epoch = 1;
+            if (ctx->spec_queue.p) HIP_TRY(ctx, hipMemsetAsync(ctx->spec_queue.p, 0, ctx->spec_queue.cap, ctx->stream));
+            if (ctx->spec_rec.p) HIP_TRY(ctx, hipMemsetAsync(ctx->spec_rec.p, 0, ctx->spec_rec.cap, ctx->stream));
+        }
+        HIP_TRY(ctx, ctx->spec_queue.reserve_zeroed(std::max<int64_t>(1, list_entries) * 4 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, ctx->spec_rec.reserve_zeroed(std::max<int64_t>(1, list_entries) * sizeof(SpecRec), ctx->stream));
+    }
 
-    // one upload: [jobs | ev_first_tile | ev_start | ev_len | ev_boff] -> one device blob the five arrays point into
-    const size_t jb = (nj * sizeof(SpineJob) + 15) & ~static_cast<size_t>(15);
-    std::vector<int64_t> boff(static_cast<size_t>(n_ev) + 1, 0);           // first block of every event (K0)
-    for (int e = 0; e < n_ev; ++e) boff[e + 1] = boff[e] + (ev_len[e] + 7) / 8;
-    const size_t up_bytes = jb + 4 * evb;
-    HIP_TRY(ctx, ctx->h_up.reserve(up_bytes + 64));
-    HIP_TRY(ctx, ctx->up_dev.reserve(up_bytes + 64));
-    char *up = ctx->h_up.as<char>();
-    if (nj) std::memcpy(up, jobs.data(), nj * sizeof(SpineJob));
-    std::memcpy(up + jb, ev_first_tile.data(), evb);
-    std::memcpy(up + jb + evb, ev_start, evb - sizeof(int64_t));
-    std::memcpy(up + jb + 2 * evb, ev_len, evb - sizeof(int64_t));
-    std::memcpy(up + jb + 3 * evb, boff.data(), evb);
-    void *up_devptr = nullptr;                         // the pinned blob as the device sees it (else: plain copy)
-    if (ctx->upload_by_kernel && hipHostGetDevicePointer(&up_devptr, up, 0) != hipSuccess) { up_devptr = nullptr; (void)hipGetLastError(); }
-    if (up_devptr) {
-        const long long n16 = static_cast<long long>((up_bytes + 15) / 16);
-        const unsigned ug = static_cast<unsigned>(std::max<long long>(1, std::min<long long>((n16 + 255) / 256, 1024)));
-        hipLaunchKernelGGL(upload_kernel, dim3(ug), dim3(256), 0, ctx->stream, static_cast<const int4 *>(up_devptr),
-                           ctx->up_dev.as<int4>(), n16, ctx->small.as<unsigned long long>(),
-                           static_cast<int>(sizeof(SmallLayout) / sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipGetLastError());
-    } else {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->up_dev.p, up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const char *up = ctx->h_up.as<char>();
+        void *up_devptr = nullptr;                     // the pinned blob as the device sees it (else: plain copy)
+        if (ctx->upload_by_kernel && hipHostGetDevicePointer(&up_devptr, const_cast<char *>(up), 0) != hipSuccess) { up_devptr = nullptr; (void)hipGetLastError(); }
+        if (up_devptr) {
+            // (tables still on the device from the previous call: the kernel only clears the status block)
+            const long long n16 = reuse ? 0 : static_cast<long long>((up_bytes + 15) / 16);
+            const unsigned ug = static_cast<unsigned>(std::max<long long>(1, std::min<long long>((n16 + 255) / 256, 1024)));
+            hipLaunchKernelGGL(upload_kernel, dim3(ug), dim3(256), 0, ctx->stream, static_cast<const int4 *>(up_devptr),
+                               ctx->up_dev.as<int4>(), n16, ctx->small.as<unsigned long long>(),
+                               static_cast<int>(sizeof(SmallLayout) / sizeof(unsigned long long)));
+            HIP_TRY(ctx, hipGetLastError());
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+            if (!reuse) HIP_TRY(ctx, hipMemcpyAsync(ctx->up_dev.p, up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        tc.valid = true;
     }
     char *dup = ctx->up_dev.as<char>();
     ctx->spine_jobs.alias(dup);
@@ -591,7 +681,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     if (use_bs && nj) {
         // K0: chunk-prefixed block sums (one streaming pass), per-event centre m, totals + max|k| per 256 blocks
-        const int64_t nb_total = boff[n_ev];
+        const int64_t nb_total = tc.nb_total;
         const unsigned k0_grid = static_cast<unsigned>((nb_total + 1 + BS_CHUNK - 1) / BS_CHUNK);   // (+1: the end boundary)
         HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int4)));
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
@@ -616,7 +706,9 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (nj && use_bs) {
         const unsigned g = static_cast<unsigned>(nj);
-        int lrc = f32 ? launch_spine<64, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16>(ctx, cfg, g, sm, true);
+        int lrc = spec ? (f32 ? launch_spine_spec<PS_DTYPE_F32>(ctx, cfg, g, sm, list_entries, tscratch_bound)
+                              : launch_spine_spec<PS_DTYPE_I16>(ctx, cfg, g, sm, list_entries, tscratch_bound))
+                       : (f32 ? launch_spine<64, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16>(ctx, cfg, g, sm, true));
         if (lrc) return lrc;
         if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // single-wave bridges first; the seams that run into a stretch without splits are finished by the look-ahead kernel
@@ -645,8 +737,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     const size_t tile_lds = (nj + 1) * sizeof(long long) + 4 * nj * sizeof(int);
     const int use_lds = tile_lds <= 150 * 1024;
     if (use_lds)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(assemble_tiles_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds)));
+        HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(assemble_tiles_kernel), static_cast<int>(tile_lds)));
     hipLaunchKernelGGL(assemble_tiles_kernel, dim3(1), dim3(1024), use_lds ? tile_lds : 0, ctx->stream,
                        static_cast<int>(nj), ctx->spine_meta.as<int4>(), ctx->bmeta.as<int4>(),
                        ctx->ev_first_tile.as<int64_t>(), n_ev, ti, ti + njp, ti + 2 * njp, ti + 3 * njp,
@@ -662,7 +753,8 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
                            ctx->stream, ctx->spine_jobs.as<SpineJob>(), static_cast<int>(nj), ctx->spine_meta.as<int4>(),
                            ctx->spine_scratch.as<int2>(), ctx->bridges.as<int2>(), ti + 3 * njp,
                            ctx->sp_off.as<long long>(), 0LL, mw, W, ctx->tree_jobs.as<TreeJob>(),
-                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr);
+                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr,
+                           spec ? ctx->spec_rec.as<SpecRec>() : nullptr, ctx->epoch, static_cast<long long>(tscratch_bound));
         HIP_TRY(ctx, hipGetLastError());
     }
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
@@ -717,6 +809,8 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_SPEC_TREE")) ctx->spec_tree = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_SPEC_FLAGS")) ctx->spec_flags = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_FILTER_FUSED")) ctx->filter_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
@@ -739,7 +833,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
                       &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
-                      &ctx->align_in, &ctx->align_scratch};
+                      &ctx->align_in, &ctx->align_scratch, &ctx->spec_queue, &ctx->spec_qaux, &ctx->spec_rec};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -765,6 +859,8 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
+    else if (n == "spec_tree") ctx->spec_tree = value != 0;
+    else if (n == "spec_flags") ctx->spec_flags = static_cast<int>(value);
     else if (n == "filter_fused") ctx->filter_fused = value != 0;
     else if (n == "upload_by_kernel") ctx->upload_by_kernel = value != 0;
     else if (n == "timing") ctx->timing = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(2, value)));
@@ -1070,14 +1166,12 @@ static int single_scan(ps_ctx *ctx, const void *d_samples, const ps_sample_forma
     {
         const size_t lds = lds_bytes_for(cfg.lds_cap, 1024);
         if (cfg.dtype == PS_DTYPE_F32) {
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(single_scan_kernel<1024, PS_DTYPE_F32>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(single_scan_kernel<1024, PS_DTYPE_F32>), static_cast<int>(lds)));
             hipLaunchKernelGGL((single_scan_kernel<1024, PS_DTYPE_F32>), dim3(1), dim3(1024), lds, ctx->stream, cfg,
                                static_cast<int>(n), mode, d_scores, d_gain, d_idx,
                                reinterpret_cast<unsigned *>(&sm->status), &sm->work0);
         } else {
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(single_scan_kernel<1024, PS_DTYPE_I16>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(single_scan_kernel<1024, PS_DTYPE_I16>), static_cast<int>(lds)));
             hipLaunchKernelGGL((single_scan_kernel<1024, PS_DTYPE_I16>), dim3(1), dim3(1024), lds, ctx->stream, cfg,
                                static_cast<int>(n), mode, d_scores, d_gain, d_idx,
                                reinterpret_cast<unsigned *>(&sm->status), &sm->work0);

@@ -28,24 +28,51 @@ __device__ __forceinline__ unsigned long long u64_of(unsigned lo, unsigned hi) {
 // chunk_tot[2*chunk+1] = (max |k|, max |k-m|, -, -).
 // (the second moments are exact integers below 2^53 carried in fp64: the scan forms n*S2 - S1^2 there)
 // A chunk may straddle events (different m): only differences inside one event are ever formed.
+// Per-sample work is kept to the minimum the digest needs (the kernel is bound by vector-instruction issue as much
+// as by HBM: the first version spent 39 VALU instructions per sample): fp32 samples are checked for integrality in
+// float (x/q, v_rndne_f32, the difference OR-ed into one word), counts pass through min3 / max3 / add3 and one 24-bit
+// multiply-add each; the range checks (|k - m| < BS_WIDE, |k| < 2^23) are taken once per block from the block's
+// min and max.  A workgroup that lies inside one event (the common case) reads the event's tables with scalar loads.
+__device__ __forceinline__ int wave_incl_scan_i32(int x)
+{
+#define PS_STEP(CTRL, RM) { x += dpp_mov<CTRL, RM>(0, x); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+__device__ __forceinline__ double wave_incl_scan_f64(double x)
+{
+#define PS_STEP(CTRL, RM) { x += dpp_movd<CTRL, RM>(x); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+__device__ __forceinline__ int wave_max_i32(int x)            // result in lane 63
+{
+#define PS_STEP(CTRL, RM) { x = max(x, dpp_mov<CTRL, RM>(static_cast<int>(0x80000000), x)); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len,
                                                        const int64_t *ev_boff, int n_ev, int64_t n_samples, int4 *bs,
                                                        int4 *ev_info, int4 *chunk_tot, unsigned *status)
 {
-    __shared__ double w1[4], w2[4];
-    __shared__ int smax[4], symax[4];
-    const long long gb = blockIdx.x * 256LL + threadIdx.x;
+    __shared__ double w2[4];
+    __shared__ int w1[4], smax[4], symax[4];
+    const long long wg0 = blockIdx.x * 256LL;
+    const long long gb = wg0 + threadIdx.x;
     const long long nb_total = ev_boff[n_ev];
     unsigned bad = 0;
-    int mabs = 0, ymax = 0;
+    int mabs = 0, yabs = 0;                        // max |k| over the block's samples, max |k - m|
     int s1 = 0;
     unsigned s2 = 0;
-    int bmin = 0x7fff, bmax = -0x8000;
-    // event of the workgroup's first block (uniform search), then a short walk per thread
+    // event of the workgroup's first block (uniform search)
     int e_first = 0;
     {
-        const long long gfirst = min(blockIdx.x * 256LL, nb_total - 1);
+        const long long gfirst = min(wg0, nb_total - 1);
         int lo = 0, hi = n_ev - 1;                 // event e: ev_boff[e] <= gb < ev_boff[e+1]
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -53,35 +80,61 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
         }
         e_first = lo;
     }
+    const bool one_event = wg0 + 255 < ev_boff[e_first + 1];     // the whole workgroup lies in event e_first (uniform)
     if (gb < nb_total) {
         int e = e_first;
-        while (ev_boff[e + 1] <= gb) ++e;           // (empty events are stepped over)
-        const long long b = gb - ev_boff[e];
-        const int64_t len = ev_len[e], base = ev_start[e];
+        int64_t len, base;
+        long long b;
+        if (one_event) {                           // uniform indices: scalar loads
+            len = ev_len[e_first]; base = ev_start[e_first]; b = gb - ev_boff[e_first];
+        } else {
+            while (ev_boff[e + 1] <= gb) ++e;      // (empty events are stepped over)
+            len = ev_len[e]; base = ev_start[e]; b = gb - ev_boff[e];
+        }
         const int64_t i0 = 8 * b;
         const int m = load_count<DT>(c, base, bad);
-        int k[8];
+        int y[8];
         const int cnt = static_cast<int>(len - i0 < 8 ? len - i0 : 8);
         constexpr int ES = static_cast<int>(sizeof(typename Raw<DT>::type));
         const char *p = static_cast<const char *>(c.samples) + (base + i0) * ES;
+        int ymin, ymax;                            // over the block's real samples
+#define PS_MM8 { ymin = min(min(min(y[0], y[1]), min(y[2], y[3])), min(min(y[4], y[5]), min(y[6], y[7])));     \
+                 ymax = max(max(max(y[0], y[1]), max(y[2], y[3])), max(max(y[4], y[5]), max(y[6], y[7]))); }
         if (cnt == 8 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
             constexpr int NV = 8 * ES / 16;
             int4 raw[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) raw[v] = reinterpret_cast<const int4 *>(p)[v];
             if (DT == PS_DTYPE_F32) {
+                const f2 iq = {c.inv_q, c.inv_q};
+                const float mf = static_cast<float>(m);                    // |m| < 2^23: exact
+                const f2 mf2 = {mf, mf};
+                unsigned nz = 0;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    const float f[4] = {__int_as_float(raw[v].x), __int_as_float(raw[v].y), __int_as_float(raw[v].z),
-                                        __int_as_float(raw[v].w)};
+#pragma clang fp contract(off)                                              // (x/q rounded first, as in to_count)
+                    const int w[4] = {raw[v].x, raw[v].y, raw[v].z, raw[v].w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) k[v * 4 + q] = to_count<DT>(c, f[q], bad);
+                    for (int h = 0; h < 2; ++h) {
+                        const f2 x = {__int_as_float(w[2 * h]), __int_as_float(w[2 * h + 1])};
+                        const f2 t = x * iq;
+                        const f2 r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+                        const f2 d = t - r;                                 // +0 exactly when t is an integer; NaN for inf/NaN
+                        nz |= __float_as_uint(d.x) | __float_as_uint(d.y);
+                        const f2 yf = r - mf2;                              // exact while |r| < 2^24 (else: saturates below -> wide)
+                        y[v * 4 + 2 * h] = static_cast<int>(yf.x);
+                        y[v * 4 + 2 * h + 1] = static_cast<int>(yf.y);
+                    }
                 }
+                if (nz) bad |= ST_OFF_GRID;
+                PS_MM8
             } else {
                 const int w[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w};
+                const int om = c.off_counts - m;
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    k[q] = ((q & 1) ? (w[q >> 1] >> 16) : static_cast<int>(static_cast<short>(w[q >> 1] & 0xffff))) + c.off_counts;
+                    y[q] = ((q & 1) ? (w[q >> 1] >> 16) : static_cast<int>(static_cast<short>(w[q >> 1] & 0xffff))) + om;
+                PS_MM8
             }
         } else if (DT == PS_DTYPE_I16 && cnt == 8 && base + i0 >= 1 && base + i0 + 10 <= n_samples) {
             // int16 block that is not 16-byte aligned (events cut out of a file trace start anywhere):
@@ -92,47 +145,56 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
 #pragma unroll
             for (int q = 0; q < 5; ++q) v[q] = q4[q];            // (v[4] is inside the array: one more sample follows)
             const bool odd = (a & 2u) != 0;
+            const int om = c.off_counts - m;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int w = odd ? static_cast<int>((static_cast<unsigned>(v[q]) >> 16) | (static_cast<unsigned>(v[q + 1]) << 16)) : v[q];
-                k[2 * q] = static_cast<int>(static_cast<short>(w & 0xffff)) + c.off_counts;
-                k[2 * q + 1] = (w >> 16) + c.off_counts;
+                y[2 * q] = static_cast<int>(static_cast<short>(w & 0xffff)) + om;
+                y[2 * q + 1] = (w >> 16) + om;
             }
+            PS_MM8
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) k[q] = q < cnt ? load_count<DT>(c, base + i0 + q, bad) : m;
+            for (int q = 0; q < 8; ++q) y[q] = q < cnt ? load_count<DT>(c, base + i0 + q, bad) - m : 0;   // padding = m: y = 0
+            ymin = ymax = y[0];                    // (cnt >= 1: block b exists only if it holds a sample)
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+                if (q < cnt) { ymin = min(ymin, y[q]); ymax = max(ymax, y[q]); }
         }
+#undef PS_MM8
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int y = k[q] - m;                  // padding samples of a short last block are = m: y = 0
-            if (y >= BS_WIDE || y <= -BS_WIDE) bad |= ST_WIDE_RANGE;
-            s1 += y;
-            s2 += static_cast<unsigned>(y * y);
-            if (q < cnt) { mabs = max(mabs, k[q] < 0 ? -k[q] : k[q]); bmin = min(bmin, y); bmax = max(bmax, y); }
-            ymax = max(ymax, y < 0 ? -y : y);
+            s1 += y[q];
+            s2 += static_cast<unsigned>(__mul24(y[q], y[q]));              // |y| < BS_WIDE < 2^23, else the call is redone
         }
-        if (c.blk_mm) c.blk_mm[gb] = (bmin & 0xffff) | (bmax << 16);     // (|y| < BS_WIDE fits int16; otherwise the call is redone)
+        if (ymax >= BS_WIDE || ymin <= -BS_WIDE) bad |= ST_WIDE_RANGE;
+        const int ka = m + ymin, kb = m + ymax;
+        mabs = max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb);
+        yabs = max(-ymin, ymax);
+        if (DT == PS_DTYPE_F32 && mabs >= 8388608) bad |= ST_OFF_GRID;     // |count| >= 2^23
+        if (c.blk_mm) c.blk_mm[gb] = (ymin & 0xffff) | (ymax << 16);      // (|y| < BS_WIDE fits int16; otherwise the call is redone)
         if (b == 0) ev_info[e] = make_int4(m, 0, static_cast<int>(ev_boff[e] & 0xffffffffLL), static_cast<int>(ev_boff[e] >> 32));
     }
-    // exclusive prefix over the workgroup (exact integers in fp64)
-    double i1 = static_cast<double>(s1), i2 = static_cast<double>(s2);
-    wave_incl_scan2(i1, i2);
-    int mn = 0, mn2 = 0;
-    wave_minmax(mn, mabs);                           // (mn unused) max over the wave lands in lane 63
-    wave_minmax(mn2, ymax);
+    // exclusive prefix over the workgroup: first moments in int32 (256 * 8 * BS_WIDE < 2^31), second moments as exact
+    // integers in fp64
+    const int i1 = wave_incl_scan_i32(s1);
+    const double i2 = wave_incl_scan_f64(static_cast<double>(s2));
+    mabs = wave_max_i32(mabs);
+    yabs = wave_max_i32(yabs);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) { w1[wave] = i1; w2[wave] = i2; smax[wave] = mabs; symax[wave] = ymax; }
+    if (lane == 63) { w1[wave] = i1; w2[wave] = i2; smax[wave] = mabs; symax[wave] = yabs; }
     __syncthreads();
-    double o1 = 0.0, o2 = 0.0;
+    int o1 = 0;
+    double o2 = 0.0;
     for (int w = 0; w < wave; ++w) { o1 += w1[w]; o2 += w2[w]; }
     if (gb <= nb_total) {
-        const int e1 = static_cast<int>(o1 + i1) - s1;
+        const int e1 = o1 + i1 - s1;
         const double e2 = (o2 + i2) - static_cast<double>(s2);
         bs[gb] = make_int4(e1, 0, __double2loint(e2), __double2hiint(e2));
     }
     if (threadIdx.x == 255) {
         const double t2 = o2 + i2;
-        chunk_tot[2 * blockIdx.x] = make_int4(static_cast<int>(o1 + i1), 0, __double2loint(t2), __double2hiint(t2));
+        chunk_tot[2 * blockIdx.x] = make_int4(o1 + i1, 0, __double2loint(t2), __double2hiint(t2));
         chunk_tot[2 * blockIdx.x + 1] = make_int4(max(max(smax[0], smax[1]), max(smax[2], smax[3])),
                                                   max(max(symax[0], symax[1]), max(symax[2], symax[3])), 0, 0);
     }

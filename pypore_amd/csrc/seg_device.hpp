@@ -71,6 +71,7 @@ struct SpineJob {           // speculative spine of one tile: rec(start, end) wi
     int32_t tile_len;       // tile t of the event starts at t * tile_len
     int32_t ev;             // event index
     int64_t vbase;          // sum of the lengths of the preceding events (layout of the tree output regions)
+    int64_t spec_off;       // start of the tile's region in the speculative subtree output area
 };
 
 struct TreeJob {            // full in-order traversal of rec(start, end), first window index j0
@@ -930,7 +931,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 // ---- the window loop of _recursive_split: cparsers.pyx:186-201 ---------------------------------
 // Windows j < j0 are known to hold no split (they were scanned with identical bounds by the
 // parent frame, DESIGN.md "memoised left child").
-template <int NT, int DT, bool VALIDATE>
+template <int NT, int DT, bool VALIDATE, bool BSONLY = false>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
                           SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, int ev = 0,
                           long long stop_lim = 0x7fffffffffffffffLL, int budget = 0x7fffffff)
@@ -949,11 +950,19 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
         long long pe = ps + c.W;
         if (pe > end) pe = end;                                         // :193
         int s = -1;
-        if (pe - ps > 2LL * c.mw)                                       // :164
-            s = scan_window<NT, DT, VALIDATE>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
-                                static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
-                                c.min_gain, nullptr, sh, bad, wk, nullptr,
-                                static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim), ev);
+        if (pe - ps > 2LL * c.mw) {                                     // :164
+            if constexpr (BSONLY) {
+                static_assert(NT == 64, "block-sum scan: one wave per window");
+                if ((threadIdx.x & 63u) == 0) { wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1; }
+                s = scan_window_bs<DT>(c, ev, base, static_cast<int>(ps), static_cast<int>(pe), static_cast<int>(ps) + c.mw,
+                                       static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
+            } else {
+                s = scan_window<NT, DT, VALIDATE>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
+                                    static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
+                                    c.min_gain, nullptr, sh, bad, wk, nullptr,
+                                    static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim), ev);
+            }
+        }
         if (s >= 0) { kind = KIND_HIT; return s; }                      // :195-196
     }
     if (static_cast<long long>(end) - start <= c.maxw) { kind = KIND_NONE; return -1; }   // :199-200
@@ -1279,9 +1288,9 @@ __global__ __launch_bounds__(64 * BR_LA, 2) void bridge_la_kernel(DevCfg c, cons
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
 // One job, by the NT threads that share `sh` (a workgroup, or one wave of a multi-wave workgroup when NT == 64).
-template <int NT, int DT>
-__device__ __forceinline__ void tree_job(const DevCfg &c, int *ys, const TreeJob &job, long long ji, int32_t *scratch,
-                                         int2 *spill, int32_t *counts, SharedT<NT> &sh, unsigned &bad, Work &wk)
+template <int NT, int DT, bool BSONLY = false>
+__device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob &job, long long ji, int32_t *scratch,
+                                        int2 *spill, int32_t *counts, SharedT<NT> &sh, unsigned &bad, Work &wk)
 {
     const int tid = ps_tid<NT>();
     int32_t *out = scratch + job.out_off;
@@ -1303,7 +1312,7 @@ __device__ __forceinline__ void tree_job(const DevCfg &c, int *ys, const TreeJob
     };
     for (;;) {
         int kind;
-        int s = find_split<NT, DT, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
+        int s = find_split<NT, DT, false, BSONLY>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
         if (kind == KIND_NONE) {
             if (sp == 0) break;
             --sp;
@@ -1337,8 +1346,167 @@ __device__ __forceinline__ void tree_job(const DevCfg &c, int *ys, const TreeJob
     if (cnt > job.out_cap) cnt = job.out_cap;
     ps_sync<NT>();
     for (int i = flushed + tid; i < cnt; i += NT) out[i] = obuf[i - flushed];
-    if (tid == 0) counts[ji] = cnt;
+    if (tid == 0 && counts) counts[ji] = cnt;
     ps_sync<NT>();                                     // obuf / stack are reused by the next job
+    return cnt;
+}
+
+// ---- phase 1 + speculative phase 3 in one kernel (block-sum scan) ---------------------------------------------
+// The tile chains of the spine kernel differ in length (3 .. 15 windows for the bench trace), so 40 % of the wave
+// slots sit empty while the longest chain finishes, and the subtree kernel repeats the pattern.  Here a wave that has
+// finished its chains turns to subtree jobs: every chain publishes the pairs (a_{i-1}, a_i) of ITS OWN list in a queue
+// in HBM as soon as it ends, and idle waves draw from the queue -- rec(a_{i-1}, a_i) depends on nothing but its range,
+// and about four pairs in five turn out to lie on the true spine (the others, upstream of the point where the true
+// chain enters the tile, are wasted work in slots that were idle anyway).  The stitch accepts a speculative result
+// when its record (pred, anchor, epoch) matches the true pair; everything else (bridge anchors, a tile's first
+// anchor) is left to the subtree kernel proper.
+//
+// Queue: entry t = four 64-bit words (epoch << 32 | value) for pred, anchor, tile and the anchor's list index.  Every
+// word is written with one agent-scope atomic store and carries the call's epoch, so an entry is complete exactly when
+// all four words show the epoch: no ordering between the stores is needed, hence NO release / acquire fences -- on this
+// part an agent-scope acquire is a `buffer_inv sc1`, which drops every line the XCD's L2 holds of the digest the scans
+// live on (the first version did that once per job and ran twice as long).  Stale entries of earlier calls never match.
+// Producers reserve a range with one atomic on `qctl` (low word: tail, high word: producers that have finished
+// publishing); consumers take tickets from `qhead` and wait for THEIR entry, or leave when every producer is done and
+// the ticket lies beyond the final tail.  All waves of the grid are resident (one workgroup per slot) and producers
+// never wait: no deadlock.
+struct SpecRec { int32_t pred, anchor, cnt, epoch; };   // per list slot: what a speculative subtree job computed
+
+__device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent_i32(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int DT>
+__global__ __launch_bounds__(64, PS_BS_MINW) void spine_spec_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch, int4 *meta,
+                                                                    unsigned long long *queue, long long qcap, unsigned long long *qctl,
+                                                                    unsigned long long *qhead, int32_t *tscratch, int2 *tspill,
+                                                                    long long spec_base, SpecRec *rec, int epoch, int flags,
+                                                                    unsigned *status, unsigned long long *work, int n_jobs)
+{
+    __shared__ SharedT<64> sh;
+    if ((*status & ST_WIDE_RANGE) != 0u) return;       // K0 refused the data: the host redoes the call
+    const int lane = threadIdx.x;
+    unsigned bad = 0;
+    Work wk = PS_WORK_INIT;
+    // flags: 1 = chains at high priority, 2 = stop drawing subtree jobs once every chain has ended (the rest goes to the
+    // subtree kernel, which balances better than a draining queue)
+    if (flags & 1) __builtin_amdgcn_s_setprio(3);      // chains are the critical path; subtree jobs take what is left
+    // ---- producer: the chains of this wave's tiles (spine_kernel, list mode) ----
+    for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
+        const SpineJob job = jobs[jb];
+        int2 *out = scratch + job.out_off;
+        int a = job.start, cnt = 0, ended = 0, flushed = 0, open_j = 0;
+        for (;;) {
+            int kind;
+            int s = find_split<64, DT, true, true>(c, nullptr, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev,
+                                                   static_cast<long long>(job.stop) + 2LL * c.W);
+            if (kind == KIND_NONE) { ended = 1; break; }
+            if (kind == KIND_STOP) { open_j = s; break; }
+            if (cnt - flushed == SharedT<64>::OB) {    // rare: spill the LDS buffer to the list
+                ps_sync<64>();
+                for (int i = lane; i < SharedT<64>::OB; i += 64)
+                    if (flushed + i < job.out_cap) out[flushed + i] = sh.obuf[i];
+                flushed += SharedT<64>::OB;
+                ps_sync<64>();
+            }
+            if (cnt >= job.out_cap) bad |= ST_OUT_OVERFLOW;
+            if (lane == 0) sh.obuf[cnt - flushed] = make_int2(s, kind);
+            ++cnt;
+            a = s;
+            if (a >= job.stop) break;
+        }
+        if (cnt > job.out_cap) cnt = job.out_cap;
+        ps_sync<64>();
+        for (int i = flushed + lane; i < cnt; i += 64) out[i] = sh.obuf[i - flushed];
+        if (lane == 0) meta[jb] = make_int4(cnt, ended, open_j, 0);
+        // publish the pairs with a left subtree: (tile start | a_{i-1}, a_i), i >= 1 -- and i = 0 for an event's first
+        // tile, whose start is a true anchor.  (Only the part of the list still in LDS: a list that was spilled is
+        // densely stepped data, whose pairs the subtree kernel takes.)
+        if (flushed == 0 && cnt > 0) {
+            const int i0 = jb == job.first_tile ? 0 : 1;
+            int np = 0;
+            for (int i = i0 + lane; i < cnt; i += 64) { const int k = sh.obuf[i].y; np += (k == KIND_HIT || k == KIND_LATE) ? 1 : 0; }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) np += __shfl_xor(np, d);
+            if (np > 0) {
+                unsigned long long pos = 0;
+                if (lane == 0) pos = atomicAdd(qctl, static_cast<unsigned long long>(np)) & 0xffffffffULL;
+                pos = __shfl(pos, 0);
+                int w = 0;                             // lane 0 writes the few entries (np is 3 .. 6)
+                if (lane == 0) {
+                    const unsigned long long tag = static_cast<unsigned long long>(static_cast<unsigned>(epoch)) << 32;
+                    for (int i = i0; i < cnt; ++i) {
+                        const int2 e = sh.obuf[i];
+                        if (e.y != KIND_HIT && e.y != KIND_LATE) continue;
+                        const long long qi = static_cast<long long>(pos) + w;
+                        if (qi < qcap) {
+                            unsigned long long *q = queue + 4 * qi;
+                            const unsigned pred = static_cast<unsigned>(i > 0 ? sh.obuf[i - 1].x : job.start);
+                            __hip_atomic_store(q + 0, tag | pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(q + 1, tag | static_cast<unsigned>(e.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(q + 2, tag | static_cast<unsigned>(jb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(q + 3, tag | static_cast<unsigned>(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        ++w;
+                    }
+                }
+            }
+        }
+        ps_sync<64>();                                 // obuf is reused by the next tile
+    }
+    if (lane == 0) atomicAdd(qctl, 1ULL << 32);        // this producer is done (its reservations precede this in the same word)
+    // ---- consumer: speculative subtree jobs from the queue ----
+    if (flags & 1) __builtin_amdgcn_s_setprio(0);
+    const unsigned nprod = gridDim.x;
+    for (;;) {
+        if ((flags & 2) && static_cast<unsigned>(ld_agent_u64(qctl) >> 32) == nprod) break;
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(qhead, 1ULL);
+        t = __shfl(t, 0);
+        int4 e = make_int4(0, 0, 0, 0);                // (pred, anchor, tile, list index)
+        bool have = false;
+        const unsigned uep = static_cast<unsigned>(epoch);
+        for (;;) {                                     // wait for entry t, or for the end of the queue
+            if (static_cast<long long>(t) < qcap) {
+                const unsigned long long *q = queue + 4 * t;
+                const unsigned long long w3 = ld_agent_u64(q + 3);
+                if (static_cast<unsigned>(w3 >> 32) == uep) {
+                    const unsigned long long w0 = ld_agent_u64(q + 0), w1 = ld_agent_u64(q + 1), w2 = ld_agent_u64(q + 2);
+                    if (static_cast<unsigned>(w0 >> 32) == uep && static_cast<unsigned>(w1 >> 32) == uep && static_cast<unsigned>(w2 >> 32) == uep) {
+                        e = make_int4(static_cast<int>(w0 & 0xffffffffULL), static_cast<int>(w1 & 0xffffffffULL),
+                                      static_cast<int>(w2 & 0xffffffffULL), static_cast<int>(w3 & 0xffffffffULL));
+                        have = true;
+                        break;
+                    }
+                }
+            }
+            const unsigned long long ctl = ld_agent_u64(qctl);
+            if (static_cast<unsigned>(ctl >> 32) == nprod && t >= (ctl & 0xffffffffULL)) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        if (!have) break;
+        const SpineJob job = jobs[e.z];
+        TreeJob tj;
+        tj.base = job.base; tj.start = e.x; tj.end = e.y;
+        tj.j0 = left_child_j0(e.x, e.y, c.W, c.half);
+        tj.out_cap = (e.y - e.x) / c.mw + 1;
+        // region of the pair inside the tile's speculative area: (pred - tile start)/min_width + list index is monotone
+        // and non-overlapping ((a+b)/m >= a/m + b/m)
+        const int li = e.w;
+        tj.out_off = spec_base + job.spec_off + (e.x - job.start) / c.mw + li;
+        tj.ev = job.ev; tj.pad_ = 0;
+        const int n = tree_job<64, DT, true>(c, nullptr, tj, 0, tscratch, tspill, nullptr, sh, bad, wk);
+        if (lane == 0) {
+            SpecRec r; r.pred = e.x; r.anchor = e.y; r.cnt = n; r.epoch = epoch;
+            rec[job.out_off + li] = r;
+        }
+    }
+    flush(bad, wk, status, work, 0);
 }
 
 template <int NT, int DT>
@@ -1620,7 +1788,8 @@ __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
 __global__ __launch_bounds__(256) void assemble_items_kernel(
     const SpineJob *jobs, int n_tiles, const int4 *meta, const int2 *lists, const int2 *bridges,
     const int *entry, const long long *sp_off, long long n_items_host, int mw, int W,
-    TreeJob *tjobs, Item *items, int32_t *counts, const AsmHeader *hdr)
+    TreeJob *tjobs, Item *items, int32_t *counts, const AsmHeader *hdr,
+    const SpecRec *spec_rec, int epoch, long long spec_base)
 {
     const long long n_items = dev_count(hdr, n_items_host);
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n_items; i += gridDim.x * 256LL) {
@@ -1635,9 +1804,11 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     const SpineJob jb2 = jobs[g];
     int2 el;
     int pred;
+    long long slot = -1;                               // list slot of the anchor (speculative subtree records)
     if (k < cnt - en) {
         el = lists[jb2.out_off + en + k];
         pred = (en + k) > 0 ? lists[jb2.out_off + en + k - 1].x : jb2.start;
+        slot = jb2.out_off + en + k;
     } else {
         const int kb = k - (cnt - en);
         el = bridges[static_cast<long long>(g) * BR_MAX + kb];
@@ -1657,8 +1828,18 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     tj.out_cap = has ? (el.x - pred) / mw + 1 : 0;       // 0 marks "no left subtree": the tree kernel skips it
     tj.out_off = (jb2.vbase + pred) / mw + i;
     tj.ev = jb2.ev; tj.pad_ = 0;
+    int done_cnt = 0;
+    if (has && spec_rec != nullptr && slot >= 0) {
+        // the subtree of exactly this pair was computed speculatively by the spine kernel in this call: take it
+        const SpecRec r = spec_rec[slot];
+        if (r.epoch == epoch && r.pred == pred && r.anchor == el.x) {
+            tj.out_cap = 0;
+            tj.out_off = spec_base + jb2.spec_off + (pred - jb2.start) / mw + (en + k);
+            done_cnt = r.cnt;
+        }
+    }
     tjobs[i] = tj;
-    counts[i] = 0;
+    counts[i] = done_cnt;
     }
 }
 
