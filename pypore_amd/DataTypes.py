@@ -1,186 +1,176 @@
-"""File / Event containers: the call contract of DataTypes.py that sits on either side of the
-segmenter (File.parse :589-602, Event.parse :276-289,:333, Event.filter :258-274) and the JSON
-persistence of the results (Event :480-545, File :683-796).  Plotting, HMM
-merging, MySQL and Experiment are out of scope.
-"""
-import json
+"""File / Event: the containers on either side of the segmenter.
 
+Call contract kept from the reference (PyPore/DataTypes.py):
+  File(filename) | File(current=, timestep=)   .second = 1000 / timestep, .events, .parse(parser)        (:567-602)
+  Event(current, start, end, duration, second, file)   .filter(order, cutoff), .parse(parser), .segments   (:239-333)
+  to_dict / to_json / from_json / to_meta on both, MetaEvent, Event.from_segments                         (:480-545, :683-796)
+and the JSON schema of README.md:346-391 (tests/golden/readme_file.json).  Plotting, HMM merging, MySQL and
+Experiment are out of scope.
+
+Built here around three pieces: `encode()` turns any tree of records into JSON-able dicts (one recursive walk
+instead of per-class loops), `_rebuild_event()` is the inverse for one event, and a File read from an .abf keeps
+the int16 counts next to the float64 current (pypore_amd.grid), so that parsing stays on the 2 B/sample device route.
+"""
 import numpy as np
 
-from .core import MetaSegment, Segment, _jsonable, ignored
+from .core import MetaSegment, Segment, SEGMENT_FIELDS, dump_json, fields_of, ignored, load_json, plain
 from .parsers import SpeedyStatSplit, lambda_event_parser, parser as _parser_base
 
+EVENT_FIELDS = SEGMENT_FIELDS + ('filtered', 'filter_order', 'filter_cutoff', 'n', 'state_parser', 'segments')
+FILE_FIELDS = ('filename', 'n', 'event_parser', 'mean', 'std', 'duration', 'start', 'end', 'events')
 
-def _json_dict(d):
-    """numpy scalars -> Python numbers (the reference relied on Python-2 json accepting them)."""
-    return {k: _jsonable(v) for k, v in d.items()}
+
+def encode(value):
+    """Records (anything with to_dict) -> dicts, sequences -> lists, numpy scalars -> numbers, recursively."""
+    if hasattr(value, 'to_dict'):
+        value = value.to_dict()
+    if isinstance(value, dict):
+        return {k: encode(v) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [encode(v) for v in value]
+    return plain(value)
+
+
+def _parser_from(d):
+    return _parser_base.from_json(dump_json(d)) if d is not None else None
 
 
 class MetaEvent(MetaSegment):
-    """DataTypes.py:49-80: an event without its current."""
-
-    def __init__(self, **kwargs):
-        MetaSegment.__init__(self, **kwargs)
+    """An event reduced to its numbers (and its MetaSegments)."""
+    json_fields = EVENT_FIELDS
 
     def delete(self):
-        with ignored(AttributeError):
-            del self.state_parser
-        for segment in getattr(self, "segments", []):
+        for segment in self.__dict__.get('segments', []):
             segment.delete()
-        with ignored(AttributeError):
-            del self.segments
-        del self
+        self.__dict__.clear()
 
 
 class Event(Segment):
-    """DataTypes.py:239-256."""
+    """A blockade event: its current, and after parse() its segments."""
+    json_fields = EVENT_FIELDS
 
-    def __init__(self, current, segments=[], **kwargs):
-        if len(segments) > 0:
+    def __init__(self, current, segments=(), **kwargs):
+        segments = list(segments)
+        if segments:                                     # an event assembled from segments owns their concatenation
             try:
                 current = np.concatenate([seg.current for seg in segments])
-            except Exception:
+            except (AttributeError, ValueError):
                 current = []
         Segment.__init__(self, current, filtered=False, segments=segments, **kwargs)
 
+    @property
+    def n(self):
+        return len(self.__dict__.get('segments') or ())
+
+    # ---- Event.filter (DataTypes.py:258-274) ----------------------------------------------------------------
     def filter(self, order=1, cutoff=2000., quantum=None):
-        """DataTypes.py:258-274: Bessel low-pass of the event's current, cutoff normalised by the Nyquist frequency
-        of the file's sampling rate, applied forward and backward (scipy.signal.filtfilt semantics) on the device.
-        Only the reference's default order (1) is implemented; other orders raise ValueError.  The result replaces
-        `current` as float64, as in the reference.  It no longer lies on the ADC grid: see Event.parse for how a
-        filtered event is segmented."""
-        if type(self) != Event:
+        """Bessel low-pass, cutoff relative to the Nyquist frequency of the file's sampling rate, run forward and
+        backward (scipy.signal.filtfilt semantics) on the device; `current` becomes the float64 result.  Orders
+        other than the reference's default 1 raise ValueError.  The result no longer lies on the ADC grid: see parse."""
+        if type(self) is not Event:
             raise TypeError("Cannot filter a metaevent. Must have the current.")
         from . import engine
-        dev, q = engine.to_device_samples(self.current, quantum)
-        out = engine.context(dev.device.index).filter_bessel(dev, q, cutoff=cutoff, sampling_freq=float(self.second), order=order)
-        self.current = out.cpu().numpy()
-        self.filtered = True
-        self.filter_order = order
-        self.filter_cutoff = cutoff
+        s = engine.to_device(self.current, quantum)
+        ctx = engine.context(s.tensor.device.index)
+        out = ctx.filter_bessel(s.tensor, s.quantum, cutoff=cutoff, sampling_freq=float(self.second), order=order)
+        # (a DC offset passes a unit-gain low-pass unchanged: filter the counts, put the offset back)
+        self.current = out.cpu().numpy() + s.offset if s.offset else out.cpu().numpy()
+        self.filtered, self.filter_order, self.filter_cutoff = True, order, cutoff
 
+    # ---- Event.parse (DataTypes.py:276-289, :333) -----------------------------------------------------------
     def parse(self, parser=None, hmm=None):
-        """DataTypes.py:276-289,:333: segments = parser.parse(current); each gets .event and is
-        rescaled from samples to seconds with the file's sampling rate."""
+        """segments = parser.parse(current); every segment learns its event and is rescaled from samples to seconds
+        with the file's sampling rate."""
         if parser is None:
             parser = SpeedyStatSplit(prior_segments_per_second=10)
         if hmm is not None:
             raise NotImplementedError("HMM-guided merging needs yahmm (out of scope)")
-        if getattr(self, "filtered", False):
-            # A filtered current is float64 off the ADC grid; the device segmenter works on exact integer sums.  The
-            # current is centred on its mean (the gains are shift invariant) and rounded to the finest power-of-two
-            # grid that keeps every count below 2**22 (2**-18 pA for a 100 pA range): on the golden vectors recorded
-            # from the reference that reproduces every boundary the reference finds on the unrounded float64 current
-            # (tests/test_filter.py); coarser grids do not -- a heavily smoothed current has almost no variance left.
-            # Segments keep views of the unrounded current and take their statistics from those views (numpy).
-            cur = np.asarray(self.current, dtype=np.float64)
-            c0 = float(np.mean(cur)) if cur.size else 0.0
-            span = float(np.max(np.abs(cur - c0))) if cur.size else 0.0
-            fq = 2.0 ** (int(np.ceil(np.log2(span * 1.01))) - 22) if span > 0 else 1.0
-            centre = np.rint(c0 / fq) * fq
-            self.segments = parser.parse(np.rint((cur - centre) / fq) * fq)
-            for segment in self.segments:
-                segment.current = self.current[int(segment.start):int(segment.end)]
-                segment.__dict__.pop('_gpu_stats', None)
+        if self.__dict__.get("filtered"):
+            self.segments = self._parse_filtered(parser)
         else:
             self.segments = parser.parse(self.current)
+        rate = float(self.file.second)
         for segment in self.segments:
             segment.event = self
-            segment.scale(float(self.file.second))
+            segment.scale(rate)
         self.state_parser = parser
 
-    @property
-    def n(self):
-        try:
-            return len(self.segments)
-        except Exception:
-            return 0
+    def _parse_filtered(self, parser):
+        """A filtered current is float64 off every ADC grid, and the device segmenter works on exact integer sums.
+        The current is centred on its mean (the gains are shift invariant) and rounded to the finest power-of-two grid
+        that keeps every count below 2**22 (2**-18 pA for a 100 pA range): on the golden vectors recorded from the
+        reference that reproduces every boundary the reference finds on the unrounded float64 current
+        (tests/test_filter.py); coarser grids do not -- a heavily smoothed current has almost no variance left.
+        Segments keep views of the unrounded current and take their statistics from those views."""
+        cur = np.asarray(self.current, dtype=np.float64)
+        centre = float(np.mean(cur)) if cur.size else 0.0
+        span = float(np.max(np.abs(cur - centre))) if cur.size else 0.0
+        step = 2.0 ** (int(np.ceil(np.log2(span * 1.01))) - 22) if span > 0 else 1.0
+        centre = np.rint(centre / step) * step
+        segments = parser.parse(np.rint((cur - centre) / step) * step)
+        for segment in segments:
+            segment.current = self.current[int(segment.start):int(segment.end)]
+            segment.__dict__.pop('_gpu_stats', None)
+        return segments
 
-    # ---- persistence (DataTypes.py:335-347, :480-545) ------------------------------------------------
-    def delete(self):
-        with ignored(AttributeError):
-            del self.current
-        with ignored(AttributeError):
-            del self.state_parser
-        for segment in getattr(self, "segments", []):
-            segment.delete()
-        with ignored(AttributeError):
-            del self.segments
-        del self
-
-    def to_meta(self):
-        """:480-491: freeze the statistics, drop the current (also of the segments), become a MetaEvent."""
-        for prop in ['mean', 'std', 'duration', 'start', 'min', 'max', 'end', 'start']:
-            with ignored(AttributeError, KeyError, ValueError):
-                self.__dict__[prop] = getattr(self, prop)
-        with ignored(AttributeError):
-            del self.current
-        self.__dict__.pop('_gpu_stats', None)
-        for segment in self.segments:
-            segment.to_meta()
-        self.__class__ = type("MetaEvent", (MetaEvent,), self.__dict__)
-
+    # ---- persistence ----------------------------------------------------------------------------------------
     def to_dict(self):
-        keys = ['mean', 'std', 'min', 'max', 'start', 'end', 'duration', 'filtered',
-                'filter_order', 'filter_cutoff', 'n', 'state_parser', 'segments']
-        d = {}
-        for i in keys:
-            with ignored(AttributeError, ValueError):
-                d[i] = getattr(self, i)
-        d['name'] = self.__class__.__name__
-        return d
+        return fields_of(self, self.json_fields)
 
     def to_json(self, filename=None):
-        d = self.to_dict()
-        with ignored(KeyError, AttributeError):
-            d['segments'] = [seg.to_dict() for seg in d['segments']]
-        with ignored(KeyError, AttributeError):
-            d['state_parser'] = d['state_parser'].to_dict()
-        _json = json.dumps(_json_dict(d), indent=4, separators=(',', ' : '))
-        if filename:
-            with open(filename, 'w') as out:
-                out.write(_json)
-        return _json
+        return dump_json(encode(self), filename)
+
+    def to_meta(self):
+        for segment in self.segments:
+            segment.to_meta()
+        self.freeze(SEGMENT_FIELDS + ('n',))
+        self.__class__ = MetaEvent
+
+    def delete(self):
+        for segment in self.__dict__.get('segments', []):
+            segment.delete()
+        self.__dict__.clear()
 
     @classmethod
     def from_json(cls, _json):
-        """:516-529: a JSON without `current` gives a MetaEvent carrying the stored attributes."""
-        if _json.endswith(".json"):
-            with open(_json, 'r') as infile:
-                _json = ''.join(line for line in infile)
-        d = json.loads(_json)
-        event = MetaSegment()
-        if 'current' not in d.keys():
-            event.__class__ = type("MetaEvent", (MetaEvent,), d)
-        else:
-            event = cls(d['current'], start=d['start'])
-        return event
+        """Event from JSON text or a *.json path.  Without a `current` entry (what to_json writes) the result is a
+        MetaEvent holding the stored numbers, its segments as MetaSegments and its parser rebuilt."""
+        d = dict(load_json(_json))
+        d.pop('name', None)
+        if 'current' in d:
+            return cls(np.asarray(d['current'], dtype=np.float64), start=d.get('start', 0))
+        d['segments'] = [MetaSegment(**{k: v for k, v in sj.items() if k != 'name'}) for sj in d.get('segments', [])]
+        if isinstance(d.get('state_parser'), dict):
+            d['state_parser'] = _parser_from(d['state_parser'])
+        return MetaEvent(**d)
 
     @classmethod
     def from_segments(cls, segments):
-        """:532-545."""
-        try:
-            current = np.concatenate([seg.current for seg in segments])
-            return cls(current=current, start=0, segments=segments)
-        except AttributeError:
-            dur = sum(seg.duration for seg in segments)
-            mean = np.mean([seg.mean * seg.duration for seg in segments]) / dur
-            std = np.sqrt(sum(seg.std ** 2 * seg.duration for seg in segments) / dur)
-            self = cls(current=np.array([seg.mean for seg in segments]), start=0, segments=segments, mean=mean, std=std)
-            self.__class__ = type("MetaEvent", (Event,), self.__dict__)
-            return self
+        """Event spanning `segments`.  With their currents at hand: the concatenation.  From metadata alone: a
+        MetaEvent whose duration is the sum, whose mean is the duration-weighted mean and whose std pools the
+        segment variances about their own means (what the reference's formulas at :538-545 are after; its own result
+        there is an Event with an empty current)."""
+        segments = list(segments)
+        if all(hasattr(seg, 'current') for seg in segments):
+            return cls(current=None, start=0, segments=segments)
+        dur = float(sum(seg.duration for seg in segments))
+        mean = sum(seg.mean * seg.duration for seg in segments) / dur
+        std = float(np.sqrt(sum(seg.std ** 2 * seg.duration for seg in segments) / dur))
+        return MetaEvent(start=0, duration=dur, mean=mean, std=std, n=len(segments), segments=segments, filtered=False)
 
 
 class File(Segment):
-    """DataTypes.py:567-602."""
+    """One recording: the current of an .abf file (or an array with its time step in ms) and the events found in it."""
+    json_fields = FILE_FIELDS
 
     def __init__(self, filename=None, current=None, timestep=None, **kwargs):
         if current is not None and timestep is not None:
             filename = ""
         elif filename and current is None and timestep is None:
             from .abf import read_abf
-            timestep, current = read_abf(filename)
-            filename = filename.split("\\")[-1].split(".abf")[0]
+            timestep, current = read_abf(filename)          # a GridArray: float64 pA that still knows its int16 counts
+            filename = filename.split("\\")[-1]
+            filename = filename[:-4] if filename.endswith(".abf") else filename
         else:
             raise SyntaxError("Must provide current and timestep, or filename corresponding to a valid abf file.")
         Segment.__init__(self, current=current, filename=filename, second=1000. / timestep, events=[], sample=None)
@@ -188,122 +178,95 @@ class File(Segment):
     def __getitem__(self, index):
         return self.events[index]
 
-    def parse(self, parser=None):
-        """DataTypes.py:589-602."""
-        if parser is None:
-            parser = lambda_event_parser(threshold=90)
-        self.events = [Event(current=seg.current,
-                             start=seg.start / self.second,
-                             end=(seg.start + seg.duration) / self.second,
-                             duration=seg.duration / self.second,
-                             second=self.second,
-                             file=self) for seg in parser.parse(self.current)]
-        self.event_parser = parser
-
-    def parse_events(self, parser=None):
-        """Segments every event of the file in ONE device call (Experiment.parse inner loop,
-        DataTypes.py:978-984, without the optional filter)."""
-        if parser is None:
-            parser = SpeedyStatSplit(prior_segments_per_second=10)
-        if hasattr(parser, "parse_batch"):
-            all_segs = parser.parse_batch([ev.current for ev in self.events])
-        else:
-            all_segs = [parser.parse(ev.current) for ev in self.events]
-        for ev, segs in zip(self.events, all_segs):
-            ev.segments = segs
-            for segment in segs:
-                segment.event = ev
-                segment.scale(float(self.second))
-            ev.state_parser = parser
-
     @property
     def n(self):
         return len(self.events)
 
-    # ---- persistence (DataTypes.py:611-626, :683-796) ------------------------------------------------
-    def delete(self):
-        with ignored(AttributeError):
-            del self.current
-        with ignored(AttributeError):
-            del self.event_parser
-        for event in self.events:
-            event.delete()
-        del self
+    def parse(self, parser=None):
+        """Event detection: one Event per Segment the parser returns, its start / end / duration in seconds."""
+        if parser is None:
+            parser = lambda_event_parser(threshold=90)
+        rate = self.second
+        self.events = [Event(current=seg.current, start=seg.start / rate, end=(seg.start + seg.duration) / rate,
+                             duration=seg.duration / rate, second=rate, file=self)
+                       for seg in parser.parse(self.current)]
+        self.event_parser = parser
+
+    def parse_events(self, parser=None):
+        """Segments every event of the file in ONE device call (the inner loop of Experiment.parse,
+        DataTypes.py:978-984, without the optional filter)."""
+        if parser is None:
+            parser = SpeedyStatSplit(prior_segments_per_second=10)
+        currents = [ev.current for ev in self.events]
+        results = parser.parse_batch(currents) if hasattr(parser, "parse_batch") else [parser.parse(c) for c in currents]
+        rate = float(self.second)
+        for ev, segs in zip(self.events, results):
+            ev.segments = segs
+            for segment in segs:
+                segment.event = ev
+                segment.scale(rate)
+            ev.state_parser = parser
+
+    # ---- persistence ----------------------------------------------------------------------------------------
+    def to_dict(self):
+        if 'end' not in self.__dict__ and 'start' in self.__dict__ and 'duration' in self.__dict__:
+            self.end = self.start + self.duration
+        return fields_of(self, self.json_fields)
+
+    def to_json(self, filename=None):
+        """The file, its event parser, and every event with its segments and state parser (README.md:346-391)."""
+        return dump_json(encode(self), filename)
 
     def to_meta(self):
-        with ignored(AttributeError):
-            del self.current
+        self.__dict__.pop('current', None)
         for event in self.events:
             event.to_meta()
 
-    def to_dict(self):
-        keys = ['filename', 'n', 'event_parser', 'mean', 'std', 'duration', 'start', 'end', 'events']
-        if not hasattr(self, 'end') and (hasattr(self, 'start') and hasattr(self, 'duration')):
-            setattr(self, 'end', self.start + self.duration)
-        d = {}
-        for i in keys:
-            with ignored(AttributeError, ValueError):
-                d[i] = getattr(self, i)
-        d['name'] = self.__class__.__name__
-        return d
-
-    def to_json(self, filename=None):
-        """:708-736: the file, its event parser, every event with its segments and state parser."""
-        d = self.to_dict()
-        devents = []
-        for event in d['events']:
-            devent = event.to_dict()
-            try:
-                devent['segments'] = [_json_dict(state.to_dict()) for state in devent['segments']]
-                devent['state_parser'] = devent['state_parser'].to_dict()
-            except Exception:
-                with ignored(KeyError, AttributeError):
-                    del devent['segments']
-                    del devent['state_parser']
-            devents.append(_json_dict(devent))
-        d['events'] = devents
-        d['event_parser'] = d['event_parser'].to_dict()
-        _json = json.dumps(_json_dict(d), indent=4, separators=(',', ' : '))
-        if filename:
-            with open(filename, 'w') as outfile:
-                outfile.write(_json)
-        return _json
+    def delete(self):
+        for event in self.__dict__.get('events', []):
+            event.delete()
+        self.__dict__.clear()
 
     @classmethod
     def from_json(cls, _json):
-        """:739-796: rebuilds the file and its events; with the .abf at hand the events and segments get views of the
-        current again (filtered events are re-filtered), otherwise everything comes back as Meta* objects."""
-        if _json.endswith(".json"):
-            with open(_json, 'r') as infile:
-                _json = ''.join(line for line in infile)
-        d = json.loads(_json)
-        if d['name'] != "File":
+        """Rebuilds a stored analysis (JSON text or *.json path).  If `<filename>.abf` can be read, events and segments
+        get views of its current again and filtered events are filtered again; otherwise everything comes back as
+        MetaEvent / MetaSegment."""
+        d = load_json(_json)
+        if d.get('name') != "File":
             raise TypeError("JSON does not encode a file")
         try:
-            file = File(filename=d['filename'] + ".abf")
+            file = cls(filename=d['filename'] + ".abf")
             meta = False
         except Exception:
-            file = File(current=[], timestep=1)
+            file = cls(current=[], timestep=1)
+            file.filename = d.get('filename', "")
+            del file.current                            # nothing to take statistics of: the stored numbers are all there is
             meta = True
-        file.event_parser = _parser_base.from_json(json.dumps(d['event_parser']))
-        file.events = []
-        for ej in d['events']:
-            s, e = int(ej['start'] * file.second), int(ej['end'] * file.second)
-            if meta:
-                event = MetaEvent(**ej)
-            else:
-                event = Event(current=file.current[s:e], start=s / file.second, end=e / file.second,
-                              duration=(e - s) / file.second, second=file.second, file=file)
-            if ej['filtered']:
-                if not meta:
-                    event.filter(order=ej['filter_order'], cutoff=ej['filter_cutoff'])
-            if meta:
-                event.segments = [MetaSegment(**sj) for sj in ej['segments']]
-            else:
-                event.segments = [Segment(current=event.current[int(sj['start'] * file.second):int(sj['end'] * file.second)],
-                                          second=file.second, event=event, **sj)
-                                  for sj in ej['segments']]
-            event.state_parser = _parser_base.from_json(json.dumps(ej['state_parser']))
-            event.filtered = ej['filtered']
-            file.events.append(event)
+        if 'event_parser' in d:
+            file.event_parser = _parser_from(d['event_parser'])
+        file.events = [_rebuild_event(file, ej, meta) for ej in d.get('events', [])]
         return file
+
+
+def _rebuild_event(file, ej, meta):
+    """One event of a stored analysis: MetaEvent from the numbers, or Event on views of the file's current."""
+    segs = ej.get('segments', [])
+    filtered = bool(ej.get('filtered', False))
+    state_parser = _parser_from(ej.get('state_parser'))
+    if meta:
+        event = MetaEvent(**{k: v for k, v in ej.items() if k not in ('name', 'segments', 'state_parser')})
+        event.segments = [MetaSegment(**{k: v for k, v in sj.items() if k != 'name'}) for sj in segs]
+    else:
+        rate = file.second
+        a, b = int(ej['start'] * rate), int(ej['end'] * rate)
+        event = Event(current=file.current[a:b], start=a / rate, end=b / rate, duration=(b - a) / rate,
+                      second=rate, file=file)
+        if filtered:
+            event.filter(order=ej['filter_order'], cutoff=ej['filter_cutoff'])
+        event.segments = [Segment(current=event.current[int(sj['start'] * rate):int(sj['end'] * rate)], second=rate,
+                                  event=event, **{k: v for k, v in sj.items() if k != 'name'}) for sj in segs]
+    event.filtered = filtered
+    if state_parser is not None:
+        event.state_parser = state_parser
+    return event

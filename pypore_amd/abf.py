@@ -74,45 +74,68 @@ def read_abf_counts(path):
 
 
 def read_abf(path):
-    """(time_step_msec, float64 current) -- the reference's read_abf (read_abf.py:208-212)."""
+    """(time_step_msec, float64 current) -- the reference's read_abf (read_abf.py:208-212).  The array is a
+    grid.GridArray: an ordinary float64 ndarray for every consumer, which also remembers the int16 counts, scale and
+    offset it was computed from, so that the parsers can send 2 B/sample to the GPU instead of reverse-engineering
+    the grid (real headers give scales like 10 / 0.0005 / 20 / 32768, never a power of two)."""
+    from .grid import GridArray
     dt, counts, scale, offset = read_abf_counts(path)
-    return dt, np.array(counts, dtype=np.float64) * scale + offset
+    return dt, GridArray.from_counts(counts, scale, offset)
 
 
 def write_abf(path, counts, sampling_interval_us=10.0, adc_range=1.0, adc_resolution=32,
               instrument_scale=1.0, signal_gain=1.0, programmable_gain=1.0,
-              instrument_offset=0.0, signal_offset=0.0):
-    """Writes a single-channel ABF2 file holding int16 `counts`.  The defaults give a scale of
+              instrument_offset=0.0, signal_offset=0.0, telegraph_gain=None, other_channels=()):
+    """Writes an ABF2 file whose channel 0 holds int16 `counts`.  The defaults give a scale of
     exactly 2**-5 pA per count and 100 kHz (header floats are fp32, so use
-    power-of-two settings for an exactly representable scale)."""
+    power-of-two settings for an exactly representable scale).
+
+    telegraph_gain: sets nTelegraphEnable and fTelegraphAdditGain of channel 0 (the reader divides the scale by it,
+    read_abf.py:203).  other_channels: int16 arrays of the same length, interleaved behind channel 0 sample by sample
+    (ADCNumEntries = 1 + len(other_channels); the readers take every ADCNumEntries-th entry, read_abf.py:210); their
+    ADC blocks carry unit settings."""
     counts = np.ascontiguousarray(counts, dtype="<i2")
     n = counts.size
+    nch = 1 + len(other_channels)
+    if nch > 1:
+        cols = [counts] + [np.ascontiguousarray(c, dtype="<i2") for c in other_channels]
+        if any(c.size != n for c in cols):
+            raise ValueError("all channels must hold the same number of samples")
+        data = np.stack(cols, axis=1).reshape(-1)
+    else:
+        data = counts
+    adc_blocks = (nch * _ADC.size + BLOCK - 1) // BLOCK
     sections = [(0, 0, 0)] * 18
     sections[_SEC_PROTOCOL] = (1, BLOCK, 1)
-    sections[_SEC_ADC] = (2, _ADC.size, 1)
-    sections[_SEC_DATA] = (3, 2, n)
+    sections[_SEC_ADC] = (2, _ADC.size, nch)
+    sections[_SEC_DATA] = (2 + adc_blocks, 2, n * nch)
     flat = [v for s in sections for v in s]
     head = _HEADER.pack(SIGNATURE, 0x02000000, BLOCK, 1, 0, 0, 0, 1, 0, 1, 0, 0, b"\0" * 16, 0, 0, 0, 0, 0, *flat)
-    p = [0] * 79                                        # number of fields in the protocol block
-    fmt_fields = _PROTOCOL.unpack(b"\0" * BLOCK)
-    p = list(fmt_fields)
+    p = list(_PROTOCOL.unpack(b"\0" * BLOCK))
     p[0] = 3                                            # nOperationMode: gap-free
     p[1] = float(sampling_interval_us)
     p[33] = float(adc_range)
     p[35] = int(adc_resolution)
     proto = _PROTOCOL.pack(*p)
-    a = list(_ADC.unpack(b"\0" * _ADC.size))
-    a[3] = 1.0                                          # fTelegraphAdditGain (unused: nTelegraphEnable = 0)
-    a[10] = float(programmable_gain)
-    a[11] = 1.0
-    a[13] = float(instrument_scale)
-    a[14] = float(instrument_offset)
-    a[15] = float(signal_gain)
-    a[16] = float(signal_offset)
-    adc = _ADC.pack(*a)
+    adc = b""
+    for ch in range(nch):
+        a = list(_ADC.unpack(b"\0" * _ADC.size))
+        a[0] = ch                                       # nADCNum
+        a[3] = 1.0                                      # fTelegraphAdditGain
+        a[10] = a[11] = a[13] = a[15] = 1.0
+        if ch == 0:
+            if telegraph_gain is not None:
+                a[1] = 1                                # nTelegraphEnable
+                a[3] = float(telegraph_gain)
+            a[10] = float(programmable_gain)
+            a[13] = float(instrument_scale)
+            a[14] = float(instrument_offset)
+            a[15] = float(signal_gain)
+            a[16] = float(signal_offset)
+        adc += _ADC.pack(*a)
     with open(path, "wb") as f:
         f.write(head)
         f.write(proto)
-        f.write(adc + b"\0" * (BLOCK - len(adc)))
-        f.write(counts.tobytes())
+        f.write(adc + b"\0" * (adc_blocks * BLOCK - len(adc)))
+        f.write(data.tobytes())
     return path

@@ -1,51 +1,98 @@
-"""Segment / MetaSegment value types -- the attribute surface of PyPore/core.py:14-249
-(current, start, end, duration, mean, std, min, max, n, scale(), to_dict/to_json, to_meta)
-in Python 3, so that DataTypes-style callers (`seg.event = ...; seg.scale(second)`,
-DataTypes.py:287-289, :595-600) keep working.  The statistics are lazy like the reference's
-properties; when the GPU already produced them (segstat kernel) they are served from there.
+"""Segment / MetaSegment: the result types consumers of the parser plug-in API read.
+
+What callers rely on (PyPore/core.py:14-249 is the reference surface): a Segment carries
+`current` (a view of the caller's array) and `start`, `end`, `duration`; `mean`, `std` (population), `min`,
+`max`, `n` are derived on first use; `scale(fs)` turns sample units into seconds (DataTypes.py:287-289);
+`to_dict` / `to_json` emit the keys mean, std, min, max, start, end, duration, name (the JSON schema of
+README.md:346-391); `to_meta()` drops the array and keeps the numbers (a MetaSegment).
+
+Design here: the derived statistics are ONE non-data descriptor (`_Derived`) per name, so a frozen value in
+the instance dict (to_meta) or a row of device-computed statistics (the K2 kernel's output, `_gpu_stats`)
+shadows the numpy evaluation without any per-property code; serialisation is driven by a field tuple.
 """
 import json
 from contextlib import contextmanager
 
 import numpy as np
 
+JSON_STYLE = dict(indent=4, separators=(',', ' : '))      # the layout of README.md:346-391
+STAT_COLUMNS = ('mean', 'std', 'min', 'max')              # column order of ps_segstat (include/poreseg.h)
+SEGMENT_FIELDS = STAT_COLUMNS + ('start', 'end', 'duration')
+
 
 @contextmanager
 def ignored(*exceptions):
-    """core.py:251-261."""
+    """Suppress the given exception classes inside the block (core.py:251-261 offers the same helper)."""
     try:
         yield
     except exceptions:
         pass
 
 
-def _as_numpy(current):
-    if hasattr(current, "detach"):          # torch tensor (possibly on the GPU)
-        return current.detach().cpu().numpy()
-    return np.asarray(current)
+def host_array(current):
+    """numpy view of `current`, fetching it from the GPU if it is a torch tensor."""
+    return current.detach().cpu().numpy() if hasattr(current, "detach") else np.asarray(current)
 
 
-class MetaSegment(object):
-    """Metadata of a segment without the current array (core.py:14-113)."""
+def plain(value):
+    """numpy scalars -> Python numbers (json refuses numpy types under Python 3)."""
+    if isinstance(value, np.generic):
+        return value.item()
+    return value
 
-    def __init__(self, **kwargs):
-        for key, value in kwargs.items():
-            with ignored(AttributeError):
-                setattr(self, key, value)
-        if hasattr(self, "current"):
-            cur = _as_numpy(self.current)
-            self.n = len(cur)
-            self.mean = np.mean(cur)
-            self.std = np.std(cur)
-            self.min = np.min(cur)
-            self.max = np.max(cur)
-            del self.current
-        if hasattr(self, "start") and hasattr(self, "end") and not hasattr(self, "duration"):
-            self.duration = self.end - self.start
-        elif hasattr(self, "start") and hasattr(self, "duration") and not hasattr(self, "end"):
-            self.end = self.start + self.duration
-        elif hasattr(self, "end") and hasattr(self, "duration") and not hasattr(self, "start"):
-            self.start = self.end - self.duration
+
+def dump_json(record, filename=None):
+    text = json.dumps({k: plain(v) for k, v in record.items()}, **JSON_STYLE)
+    if filename:
+        with open(filename, 'w') as out:
+            out.write(text)
+    return text
+
+
+def load_json(source):
+    """dict from JSON text, or from the file when `source` names a *.json path."""
+    if isinstance(source, str) and source.endswith(".json"):
+        with open(source, 'r') as infile:
+            source = infile.read()
+    return json.loads(source)
+
+
+def fields_of(obj, names):
+    """{name: value} for the attributes that exist (lazy ones are evaluated), plus the class name."""
+    out = {}
+    for name in names:
+        try:
+            out[name] = plain(getattr(obj, name))
+        except (AttributeError, ValueError, KeyError):
+            continue
+    out['name'] = type(obj).__name__
+    return out
+
+
+class _Derived(object):
+    """Statistic of `obj.current`, unless the instance dict holds a value or a device row already."""
+
+    def __init__(self, column, fn):
+        self.column, self.fn = column, fn
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        row = obj.__dict__.get('_gpu_stats')
+        if row is not None:
+            return row[self.column]
+        return self.fn(host_array(obj.current))
+
+
+class _Record(object):
+    """Shared serialisation of the value types."""
+    json_fields = SEGMENT_FIELDS
+
+    def to_dict(self):
+        return fields_of(self, self.json_fields)
+
+    def to_json(self, filename=None):
+        return dump_json(self.to_dict(), filename)
 
     def __repr__(self):
         return self.to_json()
@@ -53,132 +100,86 @@ class MetaSegment(object):
     def __len__(self):
         return self.n
 
-    def delete(self):
-        del self
+    @classmethod
+    def from_json(cls, filename=None, json=None):
+        if bool(filename) == bool(json):
+            raise AssertionError("give a filename or a JSON string")
+        if filename:
+            with open(filename, 'r') as infile:
+                json = infile.read()
+        d = load_json(json)
+        d.pop('name', None)
+        if 'current' in d:
+            return Segment(np.array(d.pop('current'), dtype=np.float64), **d)
+        return MetaSegment(**d)
+
+
+class MetaSegment(_Record):
+    """The numbers of a segment without its current.  Any two of start / end / duration give the third; a
+    `current` keyword is reduced to n, mean, std, min, max on the spot."""
+
+    def __init__(self, **kwargs):
+        current = kwargs.pop('current', None)
+        for key, value in kwargs.items():
+            with ignored(AttributeError):
+                setattr(self, key, value)
+        if current is not None:
+            cur = host_array(current)
+            self.n = len(cur)
+            for name, fn in (('mean', np.mean), ('std', np.std), ('min', np.min), ('max', np.max)):
+                setattr(self, name, fn(cur))
+        have = [hasattr(self, k) for k in ('start', 'end', 'duration')]
+        if have == [True, True, False]:
+            self.duration = self.end - self.start
+        elif have == [True, False, True]:
+            self.end = self.start + self.duration
+        elif have == [False, True, True]:
+            self.start = self.end - self.duration
 
     def to_meta(self):
         pass
 
-    def to_dict(self):
-        keys = ['mean', 'std', 'min', 'max', 'start', 'end', 'duration']
-        d = {i: _jsonable(getattr(self, i)) for i in keys if hasattr(self, i)}
-        d['name'] = self.__class__.__name__
-        return d
-
-    def to_json(self, filename=None):
-        _json = json.dumps(self.to_dict(), indent=4, separators=(',', ' : '))
-        if filename:
-            with open(filename, 'w') as outfile:
-                outfile.write(_json)
-        return _json
-
-    @classmethod
-    def from_json(cls, filename=None, json=None):
-        assert filename or json and not (filename and json)
-        import json as _json
-        if filename:
-            with open(filename, 'r') as infile:
-                json = ''.join(line for line in infile)
-        d = _json.loads(json)
-        d.pop('name', None)
-        return MetaSegment(**d)
+    def delete(self):
+        self.__dict__.clear()
 
 
-def _jsonable(v):
-    if isinstance(v, (np.floating,)):
-        return float(v)
-    if isinstance(v, (np.integer,)):
-        return int(v)
-    return v
-
-
-class Segment(object):
-    """A stretch of ionic current plus lazily computed statistics (core.py:115-249)."""
+class Segment(_Record):
+    """A stretch of ionic current.  Keywords become attributes, except the names of the derived statistics."""
+    mean = _Derived(0, np.mean)
+    std = _Derived(1, np.std)
+    min = _Derived(2, np.min)
+    max = _Derived(3, np.max)
+    derived = STAT_COLUMNS + ('n',)
 
     def __init__(self, current, **kwargs):
         self.current = current
         for key, value in kwargs.items():
-            if hasattr(self, key):          # cannot override the statistics (core.py:131-132)
+            if key in Segment.derived:
                 continue
             with ignored(AttributeError):
                 setattr(self, key, value)
-
-    def __repr__(self):
-        return self.to_json()
-
-    def __len__(self):
-        return self.n
-
-    def to_dict(self):
-        keys = ['mean', 'std', 'min', 'max', 'start', 'end', 'duration']
-        d = {i: _jsonable(getattr(self, i)) for i in keys if hasattr(self, i)}
-        d['name'] = self.__class__.__name__
-        return d
-
-    def to_json(self, filename=None):
-        _json = json.dumps(self.to_dict(), indent=4, separators=(',', ' : '))
-        if filename:
-            with open(filename, 'w') as outfile:
-                outfile.write(_json)
-        return _json
-
-    def to_meta(self):
-        """core.py:175-186: freeze the statistics, drop the array, become a MetaSegment."""
-        for key in ['mean', 'std', 'min', 'max', 'end', 'start', 'duration']:
-            with ignored(KeyError, AttributeError):
-                self.__dict__[key] = getattr(self, key)
-        del self.current
-        self.__dict__.pop('_gpu_stats', None)
-        self.__class__ = type("MetaSegment", (MetaSegment,), self.__dict__)
-
-    def delete(self):
-        with ignored(AttributeError):
-            del self.current
-        del self
-
-    def scale(self, sampling_freq):
-        """Samples -> seconds (core.py:199-207)."""
-        with ignored(AttributeError):
-            self.start /= sampling_freq
-            self.end /= sampling_freq
-            self.duration /= sampling_freq
-
-    def _stat(self, i, fn):
-        st = self.__dict__.get('_gpu_stats')
-        if st is not None:
-            return st[i]
-        return fn(_as_numpy(self.current))
-
-    @property
-    def mean(self):
-        return self._stat(0, np.mean)
-
-    @property
-    def std(self):
-        return self._stat(1, np.std)
-
-    @property
-    def min(self):
-        return self._stat(2, np.min)
-
-    @property
-    def max(self):
-        return self._stat(3, np.max)
 
     @property
     def n(self):
         return len(self.current)
 
-    @classmethod
-    def from_json(cls, filename=None, json=None):
-        assert filename or json and not (filename and json)
-        import json as _json
-        if filename:
-            with open(filename, 'r') as infile:
-                json = ''.join(line for line in infile)
-        d = _json.loads(json)
-        d.pop('name', None)
-        if 'current' not in d:
-            return MetaSegment(**d)
-        current = np.array(d.pop('current'), dtype=np.float64)
-        return Segment(current, **d)
+    def scale(self, sampling_freq):
+        """Sample units -> seconds."""
+        for name in ('start', 'end', 'duration'):
+            if name in self.__dict__:
+                self.__dict__[name] = self.__dict__[name] / sampling_freq
+
+    def freeze(self, names=SEGMENT_FIELDS):
+        """Evaluates the lazy attributes into the instance dict and lets go of the array."""
+        for name in names:
+            with ignored(AttributeError, KeyError, ValueError):
+                self.__dict__[name] = getattr(self, name)
+        self.__dict__.pop('current', None)
+        self.__dict__.pop('_gpu_stats', None)
+
+    def to_meta(self):
+        self.freeze()
+        self.__class__ = MetaSegment
+
+    def delete(self):
+        self.__dict__.clear()

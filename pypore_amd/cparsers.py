@@ -14,7 +14,7 @@ class FastStatSplit(object):
     def __init__(self, min_width=100, max_width=1000000, window_width=10000,
                  min_gain_per_sample=None, false_positive_rate=None,
                  prior_segments_per_second=None, sampling_freq=1.e5, cutoff_freq=None,
-                 quantum=None, device=None):
+                 quantum=None, device=None, offset=None):
         self.min_width = int(min_width)
         self.max_width = int(max_width)
         self.window_width = int(window_width)
@@ -28,7 +28,8 @@ class FastStatSplit(object):
                                       false_positive_rate=false_positive_rate,
                                       prior_segments_per_second=prior_segments_per_second,
                                       sampling_freq=sampling_freq, cutoff_freq=cutoff_freq)
-        self.quantum = quantum
+        self.quantum = quantum                   # pA per ADC count and pA at count 0 of float input (default: found, see
+        self.offset = offset                     # engine.to_device); ignored for GridArrays, which know their own
         self.device = device
 
     # ---- cparsers.pyx:103-118 -------------------------------------------------------------------
@@ -38,53 +39,72 @@ class FastStatSplit(object):
         return self.parse_batch([current])[0]
 
     def parse_batch(self, currents):
-        """One device call for many independent events (one reference parse() per event)."""
+        """One device call for many independent events (one reference parse() per event).  Events that reach the
+        device in different representations (float32 pA / int16 counts, or int16 on different scales) go in one call
+        per representation."""
         ctx = engine.context(self.device)
         import torch
+        out = [None] * len(currents)
 
-        def upload(full_detect):
-            devs, q = [], self.quantum
-            for cur in currents:
-                t, q1 = engine.to_device_samples(cur, q, self.device, full_detect=full_detect)
-                if q is None:
-                    q = q1
-                elif q1 != q and self.quantum is None:
-                    q = min(q, q1)
-                devs.append(t)
-            return devs, q
+        def upload(idx, full_detect):
+            parts = [engine.to_device(currents[i], self.quantum, self.offset, self.device, full_detect) for i in idx]
+            q = self.quantum
+            if q is None:                           # float32 events on power-of-two grids: the finest one serves all
+                q = min(p.quantum for p in parts)
+            return parts, q
 
-        devs, q = upload(False)
-        lens = np.array([t.numel() for t in devs], dtype=np.int64)
-        ev_off = np.concatenate(([0], np.cumsum(lens)))
-        samples = devs[0] if len(devs) == 1 else torch.cat(devs)
-        try:
-            bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
-        except ValueError:
-            if self.quantum is not None:
-                raise
-            # the grid was detected on a subset of the samples and the device found a sample off it: search all
-            # samples for the grid once (still ValueError if there is none)
-            devs, q = upload(True)
-            bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
-        b = bounds.cpu().numpy()
-        st = stats.cpu().numpy()
-        out = []
-        for e, cur in enumerate(currents):
-            n = int(lens[e])
-            edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [n]))
-            segs = []
-            for s in range(len(edges) - 1):
-                a, z = int(edges[s]), int(edges[s + 1])
-                seg = Segment(current=cur[a:z], start=a, duration=(z - a), end=z)
-                seg._gpu_stats = st[boff[e] + e + s]
-                segs.append(seg)
-            out.append(segs)
+        def run(idx):
+            parts, q = upload(idx, False)
+            kinds = {(p.tensor.dtype, p.quantum if p.tensor.dtype == torch.int16 else None) for p in parts}
+            if len(kinds) > 1:                      # (float input that resolved to different grids: one call each)
+                for i in idx:
+                    run([i])
+                return
+            if parts[0].tensor.dtype == torch.int16:
+                q = parts[0].quantum
+            lens = np.array([p.tensor.numel() for p in parts], dtype=np.int64)
+            ev_off = np.concatenate(([0], np.cumsum(lens)))
+            try:
+                samples = parts[0].tensor if len(parts) == 1 else torch.cat([p.tensor for p in parts])
+                bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
+            except ValueError:
+                if self.quantum is not None:
+                    raise
+                # the grid was detected on a subset of the samples and the device found a sample off it: search all
+                # samples for the grid once (still ValueError if there is none)
+                parts, q = upload(idx, True)
+                samples = parts[0].tensor if len(parts) == 1 else torch.cat([p.tensor for p in parts])
+                bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
+            b = bounds.cpu().numpy()
+            st = stats.cpu().numpy()
+            for e, i in enumerate(idx):
+                cur, n = currents[i], int(lens[e])
+                rows = st[boff[e] + e: boff[e + 1] + e + 1]
+                if parts[e].offset:                 # device statistics are those of count * quantum
+                    rows = rows + np.array([parts[e].offset, 0.0, parts[e].offset, parts[e].offset])
+                edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [n]))
+                segs = []
+                for k in range(len(edges) - 1):
+                    a, z = int(edges[k]), int(edges[k + 1])
+                    seg = Segment(current=cur[a:z], start=a, duration=(z - a), end=z)
+                    seg._gpu_stats = rows[k]
+                    segs.append(seg)
+                out[i] = segs
+
+        # group the events by the representation they will have on the device
+        from .grid import grid_of
+        groups = {}
+        for i, cur in enumerate(currents):
+            g = grid_of(cur) if self.quantum is None else None
+            groups.setdefault(("counts", g[1]) if g is not None else ("values",), []).append(i)
+        for idx in groups.values():
+            run(idx)
         return out
 
     # ---- cparsers.pyx:120-155 -------------------------------------------------------------------
     def best_single_split(self, current):
         ctx = engine.context(self.device)
-        t, q = engine.to_device_samples(current, self.quantum, self.device)
+        t, q, _ = engine.to_device(current, self.quantum, self.offset, self.device)
         return ctx.best_single_split(t, q)
 
     # ---- cparsers.pyx:205-275 -------------------------------------------------------------------
@@ -92,7 +112,7 @@ class FastStatSplit(object):
         """One dense gain array per window scan, in the reference's scan order; with
         no_split=True a single scan of the whole array returned as a list (cparsers.pyx:261-263)."""
         ctx = engine.context(self.device)
-        t, q = engine.to_device_samples(current, self.quantum, self.device)
+        t, q, _ = engine.to_device(current, self.quantum, self.offset, self.device)
         n = t.numel()
         mw, maxw, W = self.min_width, self.max_width, self.window_width
 

@@ -2,7 +2,9 @@
 plus torch-allocated HBM buffers).  torch is used for device memory and streams only; all
 compute is in the HIP kernels behind the C ABI.
 """
+import collections
 import ctypes
+import warnings
 
 import numpy as np
 import torch
@@ -273,6 +275,64 @@ def detect_quantum(x, max_bits=24, full=True):
     return 2.0 ** -k
 
 
+Samples = collections.namedtuple("Samples", "tensor quantum offset")      # pA = count * quantum + offset
+
+
+def _int_counts_tensor(counts, dev):
+    """int16 CUDA tensor of integer counts; ValueError when they leave the int16 range."""
+    counts = np.asarray(counts)
+    if counts.dtype != np.int16:
+        if counts.size and (counts.min() < -32768 or counts.max() > 32767):
+            raise ValueError("ADC counts beyond int16 on a grid that is not a power of two: not supported")
+        counts = counts.astype(np.int16)
+    with warnings.catch_warnings():                     # (a read-only memmap of an .abf: the tensor is only copied from)
+        warnings.simplefilter("ignore", UserWarning)
+        return torch.from_numpy(np.ascontiguousarray(counts)).to(dev)
+
+
+def to_device(current, quantum=None, offset=None, device=None, full_detect=False):
+    """Anything a caller of the parser API may hand over -> Samples(CUDA tensor, quantum, offset).
+
+    * a GridArray (what abf.read_abf returns; slices of it): its int16 counts, 2 B/sample;
+    * numpy int16: ADC counts, quantum as given (default 1);
+    * numpy float64 / float32 pA: with `quantum` a power of two (or none given and a power-of-two grid found) the
+      values go up as float32, exactly; otherwise the counts are recovered -- rint((x - offset) / quantum) when the
+      grid is given, grid.affine_grid(x) when it is not -- and go up as int16.  Data that lies on no grid at all
+      raises ValueError: nothing is ever rounded silently;
+    * torch tensors (float32 / float64 / int16, host or device) are taken as they are (float64 must be exact in float32).
+    """
+    from .grid import affine_grid, grid_of
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    g = grid_of(current) if quantum is None else None
+    if g is not None:
+        return Samples(_int_counts_tensor(g[0], dev), g[1], g[2])
+    if isinstance(current, torch.Tensor) or np.asarray(current).dtype == np.int16:
+        t, q = to_device_samples(current, quantum, device, full_detect)
+        return Samples(t, q, 0.0 if offset is None else float(offset))
+    a = np.asarray(current)
+    if a.ndim != 1:
+        raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % a.ndim)
+    if a.dtype not in (np.float64, np.float32):
+        raise ValueError("Buffer dtype mismatch, expected 'double' but got %s" % a.dtype)
+    off = 0.0 if offset is None else float(offset)
+    pow2 = quantum is not None and quantum > 0 and np.log2(quantum) == np.rint(np.log2(quantum))
+    if quantum is None or pow2:
+        try:
+            t, q = to_device_samples(a - off if off else a, quantum, device, full_detect)
+            return Samples(t, q, off)
+        except ValueError:
+            if quantum is not None:
+                raise
+    if quantum is None:                             # no power-of-two grid: any scale and offset (a real .abf header)
+        q, o, k = affine_grid(a)
+        return Samples(_int_counts_tensor(k, dev), q, o)
+    k = (a.astype(np.float64) - off) / float(quantum)
+    kr = np.rint(k)
+    if a.size and np.max(np.abs(k - kr)) > 1e-6:
+        raise ValueError("samples are not integer multiples of quantum=%r above offset=%r" % (quantum, off))
+    return Samples(_int_counts_tensor(kr.astype(np.int64), dev), float(quantum), off)
+
+
 def to_device_samples(current, quantum=None, device=None, full_detect=False):
     """numpy float64/float32 (pA), numpy int16 (ADC counts) or torch tensor -> (CUDA tensor, quantum).
     Without `quantum` the grid is detected on a subset of the samples (full_detect=True: on all of them); a
@@ -281,7 +341,10 @@ def to_device_samples(current, quantum=None, device=None, full_detect=False):
     if isinstance(current, torch.Tensor):
         t = current
         if t.dtype == torch.float64:
-            t = t.to(torch.float32)
+            t32 = t.to(torch.float32)
+            if not torch.equal(t32.to(torch.float64), t):
+                raise ValueError("samples are not exactly representable in float32; pass int16 counts or a coarser grid")
+            t = t32
         if t.dtype not in (torch.float32, torch.int16):
             raise ValueError("Buffer dtype mismatch, expected float64/float32 pA or int16 counts")
         if quantum is None:

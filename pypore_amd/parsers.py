@@ -1,125 +1,128 @@
-"""Parser plug-ins with the class surface of PyPore/parsers.py (Python 3).
+"""Parser plug-ins: the objects File.parse / Event.parse accept (`parse(current) -> list[Segment]`).
 
-In scope: the base `parser` protocol (parsers.py:34-107), `SpeedyStatSplit`
-(parsers.py:505-565) -- the drop-in whose parse() runs on the MI355X --, `lambda_event_parser`
-(parsers.py:124-155) and `MemoryParse` (parsers.py:110-122).  The Qt GUI hooks of the
-reference are UI and out of scope.
+Surface kept from the reference (PyPore/parsers.py; SURVEY.md 8 a7, a11, b): `SpeedyStatSplit` with its eight
+constructor keywords stored as attributes of the same names (:505-534) -- they are also its JSON schema --,
+`lambda_event_parser(threshold, rules)` (:124-155), `MemoryParse(starts, ends)` (:110-122) and the base `parser`
+with `to_dict` / `to_json` / `from_json` / `parse` (:34-107).  The Qt GUI hooks are UI and out of scope.
+
+How it is built here: every subclass of `parser` registers itself by name (that is what `from_json` resolves),
+a parser's JSON is its public scalar attributes, and the two parsers that compute -- SpeedyStatSplit and the
+event detector with its default rules -- hand the samples to the HIP kernels through pypore_amd.engine.
 """
-import json
-import sys
+import numbers
 
 import numpy as np
 
-from .core import Segment
+from .core import Segment, dump_json, load_json, plain
 from .cparsers import FastStatSplit
+
+_REGISTRY = {}
 
 
 class parser(object):
-    """parsers.py:34-107 -- duck-typed protocol: parse(current) -> list[Segment]."""
+    """Base of the plug-ins.  Its own parse() returns the whole array as one segment."""
 
-    def __init__(self):
-        pass
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        _REGISTRY[cls.__name__] = cls
 
     def __repr__(self):
         return self.to_json()
 
     def to_dict(self):
-        d = {key: val for key, val in self.__dict__.items()
-             if key != 'param_dict' and not key.startswith('_')
-             if type(val) in (int, float) or ('Qt' not in repr(val)) and 'lambda' not in repr(val)}
-        d['name'] = self.__class__.__name__
+        """Public attributes that are plain scalars (numbers, strings, None), plus the class name: what the reference
+        writes for the parsers in scope (rule lambdas and GUI widgets never reach its JSON either)."""
+        d = {k: plain(v) for k, v in vars(self).items()
+             if not k.startswith('_') and k != 'param_dict'
+             and (v is None or isinstance(plain(v), (numbers.Number, str)))}
+        d['name'] = type(self).__name__
         return d
 
     def to_json(self, filename=False):
-        _json = json.dumps(self.to_dict(), indent=4, separators=(',', ' : '))
-        if filename:
-            with open(filename, 'w') as out:
-                out.write(_json)
-        return _json
+        return dump_json(self.to_dict(), filename or None)
 
     def parse(self, current):
-        """parsers.py:57-59: the whole array as one segment."""
         return [Segment(current=current, start=0, duration=current.shape[0] / 100000)]
 
     @classmethod
     def from_json(cls, _json):
-        """parsers.py:97-107: the class is looked up by its `name` entry in this module."""
-        if _json.endswith(".json"):
-            with open(_json, 'r') as infile:
-                _json = ''.join(line for line in infile)
-        d = json.loads(_json)
-        name = d['name']
-        del d['name']
-        return getattr(sys.modules[__name__], name)(**d)
+        """Parser of the class named in the JSON (text or *.json path), built from the remaining keys."""
+        d = dict(load_json(_json))
+        kind = _REGISTRY.get(d.pop('name'))
+        if kind is None:
+            raise AttributeError("no parser of that name in pypore_amd.parsers")
+        return kind(**d)
+
+
+_REGISTRY['parser'] = parser
 
 
 class MemoryParse(object):
-    """parsers.py:110-122: replay stored split points."""
+    """Replays stored split points: one Segment (copy of the samples) per (start, end) pair, in samples."""
 
     def __init__(self, starts, ends):
         self.starts = starts
         self.ends = ends
 
     def parse(self, current):
-        return [Segment(current=np.array(current[int(s):int(e)], copy=True), start=s, duration=(e - s))
-                for s, e in zip(self.starts, self.ends)]
+        spans = ((int(s), int(e), s, e) for s, e in zip(self.starts, self.ends))
+        return [Segment(current=np.array(current[i:j], copy=True), start=s, duration=e - s) for i, j, s, e in spans]
 
 
 class lambda_event_parser(parser):
-    """parsers.py:124-155: threshold event detector with rule filter.
-
-    Events are maximal runs on one side of `threshold`; a run is kept when every rule holds
-    (defaults: duration > 100000 samples, min > -0.5 pA, max < threshold)."""
+    """Threshold event detector.  The trace is cut wherever it crosses `threshold`; a piece is an event when every
+    rule accepts it -- by default: longer than 100 000 samples, minimum above -0.5 pA, maximum below the threshold
+    (the blockade side of the cut).  Start and duration of the returned Segments are in samples."""
+    MIN_DURATION = 100000
+    MIN_CURRENT = -0.5
 
     def __init__(self, threshold=90, rules=None):
         self.threshold = threshold
-        self._rules0 = [lambda event: event.duration > 100000,
-                        lambda event: event.min > -0.5,
-                        lambda event: event.max < self.threshold]
-        self.rules = rules or self._rules0
+        self._builtin = rules is None
+        self.rules = rules or [lambda event: event.duration > self.MIN_DURATION,
+                               lambda event: event.min > self.MIN_CURRENT,
+                               lambda event: event.max < self.threshold]
 
-    def _lambda_select(self, events):
-        return [event for event in events if np.all([rule(event) for rule in self.rules])]
+    def parse(self, current, quantum=None, device=None, offset=None):
+        """Built-in rules: one streaming pass on the GPU (ps_detect_events: crossings, then min / max of the long
+        pieces).  Custom rules are Python callables on Segment objects and run on the host over numpy pieces."""
+        if self._builtin:
+            return self._parse_device(current, quantum, device, offset)
+        x = np.asarray(current)
+        below = x < self.threshold
+        cuts = np.flatnonzero(below[1:] != below[:-1]) + 1
+        edges = np.concatenate(([0], cuts, [x.shape[0]]))
+        pieces = (Segment(current=np.array(x[a:b]), start=a, duration=b - a) for a, b in zip(edges[:-1], edges[1:]))
+        return [piece for piece in pieces if all(rule(piece) for rule in self.rules)]
 
-    def _default_rules(self):
-        return self.rules is self._rules0
-
-    def parse(self, current, quantum=None, device=None):
-        """With the default rules the detection runs on the GPU (ps_detect_events: mask, edges, pieces,
-        per-piece min/max); custom rule lambdas need the pieces on the host and take the numpy route of
-        the reference.  Either way the result is the reference's: one Segment per kept piece, `current` a
-        copy, start/duration in samples."""
-        if self._default_rules():
-            from . import engine
-            host = np.asarray(current) if not hasattr(current, "is_cuda") else None
-            t, q = engine.to_device_samples(current, quantum, device)
-            st, ln = engine.context(device).detect_events(t, q, threshold=float(self.threshold))
-            if host is None:                        # device tensor in: fetch the kept pieces' values once
-                host = t.cpu().numpy().astype(np.float64)
-                if not t.dtype.is_floating_point:
-                    host = host * q
-            return [Segment(current=np.array(host[s:s + n]), copy=True, start=s, duration=n)
-                    for s, n in zip(st.tolist(), ln.tolist())]
-        current = np.asarray(current)
-        mask = np.where(current < self.threshold, 1, 0)
-        mask = np.abs(np.diff(mask))
-        tics = np.concatenate(([0], np.where(mask == 1)[0] + 1, [current.shape[0]]))
-        del mask
-        events = [Segment(current=np.array(piece), copy=True, start=tics[i], duration=piece.shape[0])
-                  for i, piece in enumerate(np.split(current, tics[1:-1]))]
-        return [event for event in self._lambda_select(events)]
+    def _parse_device(self, current, quantum, device, offset):
+        from . import engine
+        s = engine.to_device(current, quantum, offset, device)
+        # the kernel compares count * quantum with its arguments: take the offset to the other side
+        starts, lens = engine.context(device).detect_events(
+            s.tensor, s.quantum, threshold=float(self.threshold) - s.offset, min_duration=self.MIN_DURATION,
+            min_current=self.MIN_CURRENT - s.offset)
+        if hasattr(current, "is_cuda"):             # device tensor in: the events' values come back as pA
+            host = s.tensor.cpu().numpy().astype(np.float64)
+            if not s.tensor.dtype.is_floating_point:
+                host = host * s.quantum
+            host = host + s.offset
+        else:
+            host = current if isinstance(current, np.ndarray) else np.asarray(current)
+        # (slices, not copies: a GridArray keeps its counts that way and Event.parse stays on the int16 route)
+        return [Segment(current=host[a:a + n], start=a, duration=n) for a, n in zip(starts.tolist(), lens.tolist())]
 
 
 class SpeedyStatSplit(parser):
-    """parsers.py:505-565: holds the eight constructor parameters as attributes of the same
-    names (they ARE the JSON schema, parsers.py:42-48) and delegates to FastStatSplit, which
-    here runs on the GPU.  Extra keyword `quantum` (pA per ADC count, power of two) skips the
-    host-side grid detection; `device` picks the GPU."""
+    """The drop-in segmenter: stores the reference's eight parameters under the reference's names and runs
+    FastStatSplit -- here the HIP kernels -- on parse().  Extra keywords (kept out of the JSON): `quantum` / `offset`
+    describe the ADC grid of float input (pA per count, pA at count 0; found automatically when omitted), `device`
+    picks the GPU."""
 
     def __init__(self, min_width=100, max_width=1000000, window_width=10000,
                  min_gain_per_sample=None, false_positive_rate=None,
                  prior_segments_per_second=None, sampling_freq=1.e5, cutoff_freq=None,
-                 quantum=None, device=None):
+                 quantum=None, device=None, offset=None):
         self.min_width = min_width
         self.max_width = max_width
         self.min_gain_per_sample = min_gain_per_sample
@@ -128,23 +131,20 @@ class SpeedyStatSplit(parser):
         self.false_positive_rate = false_positive_rate
         self.sampling_freq = sampling_freq
         self.cutoff_freq = cutoff_freq
-        self._quantum = quantum
-        self._device = device
+        self._grid = dict(quantum=quantum, device=device, offset=offset)
 
-    def _fast(self, with_cutoff=True):
+    def _fast(self, cutoff=True):
         return FastStatSplit(self.min_width, self.max_width, self.window_width, self.min_gain_per_sample,
                              self.false_positive_rate, self.prior_segments_per_second, self.sampling_freq,
-                             self.cutoff_freq if with_cutoff else None,
-                             quantum=self._quantum, device=self._device)
+                             self.cutoff_freq if cutoff else None, **self._grid)
 
     def parse(self, current):
-        """parsers.py:524-528."""
         return self._fast().parse(current)
 
     def parse_batch(self, currents):
-        """All events of a file in one device call (extension; same result as [parse(c) for c])."""
+        """All events of a file in one device call (extension; same result as [parse(c) for c in currents])."""
         return self._fast().parse_batch(currents)
 
     def best_single_split(self, current):
-        """parsers.py:530-534 (the reference drops cutoff_freq here)."""
-        return self._fast(with_cutoff=False).best_single_split(current)
+        """(gain, index) of the best single split; like the reference wrapper, without cutoff_freq (:530-534)."""
+        return self._fast(cutoff=False).best_single_split(current)

@@ -8,14 +8,18 @@ from . import _lib, engine
 
 
 def segment_file_trace(samples, quantum, params=None, threshold=90.0, min_duration=100000, min_current=-0.5,
-                       offset_counts=0, device=None, want_stats=False):
-    """samples: 1-D CUDA tensor (float32 pA on the `quantum` grid, or int16 ADC counts).
+                       offset_counts=0, device=None, want_stats=False, offset=0.0):
+    """samples: 1-D CUDA tensor (float32 pA on the `quantum` grid, or int16 ADC counts); pA = (count + offset_counts)
+    * quantum + offset (`offset`: the part of an .abf offset that is not a whole number of counts; the detector's
+    thresholds move by it, the segmenter's gains do not depend on it).
     Returns (ev_start, ev_len, bounds int32 CUDA tensor, bounds_off, stats or None)."""
     ctx = engine.context(device)
     if params is None:
         params = _lib.split_params(prior_segments_per_second=10.)
-    st, ln = ctx.detect_events(samples, quantum, threshold, min_duration, min_current, offset_counts)
+    st, ln = ctx.detect_events(samples, quantum, threshold - offset, min_duration, min_current - offset, offset_counts)
     bounds, boff, stats = ctx.segment_events(samples, st, ln, params, quantum, offset_counts, want_stats)
+    if stats is not None and offset:
+        stats[:, 0] += offset; stats[:, 2] += offset; stats[:, 3] += offset
     return st, ln, bounds, boff, stats
 
 
@@ -25,11 +29,8 @@ def parse_abf(path, params=None, threshold=90.0, device=None):
     import torch
     from .abf import read_abf_counts
     dt, counts, scale, offset = read_abf_counts(path)
-    off_counts = offset / scale
-    if off_counts != np.rint(off_counts):
-        raise ValueError("ABF offset %r is not a multiple of the scale %r" % (offset, scale))
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
     t = torch.from_numpy(np.array(counts, dtype=np.int16)).to(dev)     # one host copy out of the memmap, then H2D
-    st, ln, bounds, boff, _ = segment_file_trace(t, scale, params, threshold, offset_counts=int(off_counts), device=device)
+    st, ln, bounds, boff, _ = segment_file_trace(t, scale, params, threshold, device=device, offset=offset)
     b = bounds.cpu().numpy()
     return dt, st, ln, [b[boff[e]:boff[e + 1]] for e in range(len(st))]

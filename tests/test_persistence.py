@@ -83,10 +83,45 @@ def test_event_json_and_from_segments(tmp_path):
     whole = Event.from_segments(ev.segments)                     # segments with current: concatenated
     np.testing.assert_array_equal(whole.current, ev.current)
     metas = [MetaSegment(mean=s.mean, std=s.std, duration=s.duration, start=s.start) for s in ev.segments]
-    # metadata only (:538-545): the reference builds an Event whose `current` Event.__init__ empties again (its
-    # segments have no current, :246-249) and whose mean/std kwargs are shadowed by the properties (core.py:131-132);
-    # the statistics therefore stay with the segments.  Reproduced as is.
-    with pytest.warns(RuntimeWarning):
-        me = Event.from_segments(metas)
-        assert np.isnan(me.std)
-    assert type(me).__name__ == "MetaEvent" and me.n == 3 and me.segments[1].mean == pytest.approx(float(ev.segments[1].mean))
+    # metadata only (:538-545): duration-weighted mean and pooled variance of the segments (the reference's own result is
+    # an Event with an empty current, its formulas never reach the object: DataTypes.from_segments documents the choice)
+    me = Event.from_segments(metas)
+    dur = sum(s.duration for s in metas)
+    assert type(me).__name__ == "MetaEvent" and me.n == 3 and me.duration == pytest.approx(dur)
+    assert me.mean == pytest.approx(sum(s.mean * s.duration for s in metas) / dur)
+    assert me.segments[1].mean == pytest.approx(float(ev.segments[1].mean))
+
+
+def test_reference_readme_example_loads_and_round_trips():
+    """The one stored analysis the reference itself shows (README.md:346-391, a File.to_json of its own; the snippet
+    is cut after the second segment of the first event, tests/golden/readme_file.json closes the brackets and changes
+    nothing else): it loads as Meta* objects (no .abf at hand) and every key and value comes back out of to_json.
+    Only the file's `n` is left out: the snippet says 16 events and shows one."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_file.json")
+    ref = json.load(open(here))
+    f = File.from_json(here)
+    assert f.filename == "13823006-s06" and f.event_parser.threshold == 50.0 and type(f.event_parser) is lambda_event_parser
+    ev = f.events[0]
+    assert isinstance(ev, MetaEvent) and ev.end == 31.26803 and ev.std == 1.9335278997265508
+    sp = ev.state_parser
+    assert type(sp) is SpeedyStatSplit and (sp.min_gain_per_sample, sp.min_width, sp.window_width, sp.max_width) == (0.5, 1000, 10000, 1000000)
+    assert [type(s) for s in ev.segments] == [MetaSegment, MetaSegment] and ev.segments[1].mean == 24.084380592526145
+    f.duration = ref["duration"]                     # (file-level numbers are attributes the caller owns: :708-736 writes what is there)
+    out = json.loads(f.to_json())
+
+    def contained(a, b, path="file"):
+        if isinstance(a, dict):
+            for k, v in a.items():
+                if path == "file" and k == "n":
+                    continue
+                assert k in b, (path, k)
+                contained(v, b[k], path + "." + k)
+        elif isinstance(a, list):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                contained(x, y, "%s[%d]" % (path, i))
+        elif path.endswith('.name'):
+            assert b in (a, 'Meta' + a), (path, a, b)    # without the .abf the objects are the Meta* variants
+        else:
+            assert a == b, (path, a, b)
+    contained(ref, out)
