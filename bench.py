@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s segmented by SpeedyStatSplit on a 10^8-sample trace (BASELINE.json).
 
-One "step" = one pass of the hot path (ps_segment_batch: block-prefix kernel K0 -> spine ->
-bridge -> stitch -> tree -> gather) over one 10^8-sample synthetic trace that is already resident in HBM.  With
---gpus N every rank segments its own trace (weak scaling, no data-path collective; one RCCL
-all_gather of the boundary counts after the timed region).
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM.
+Workloads (`--workload`):
 
-Prints ONE JSON line (rank 0).  `roofline` prices the kernel sequence of one step (sum of the
-launch durations, HIP events on the library's stream) at 4 B per input sample against 8 TB/s, and
-lists every kernel with its own algorithmic bytes and measured HBM traffic; `cpu_baseline` times
-the CPU oracle (oracle/, a port of the reference) on a bounded prefix of the same trace on this host.
+  trace (default)   BASELINE's metric: every rank segments its own 10^8-sample fp32 trace with one ps_segment_batch
+                    (K0 block sums -> spine -> bridge -> stitch -> subtrees -> gather); weak scaling, no data-path
+                    collective, one RCCL all_gather of the boundaries at the end of the K steps.
+  file              BASELINE config 3: one 10^8-sample int16 .abf-shaped trace per rank, lambda_event_parser(threshold=90)
+                    then per-event SpeedyStatSplit, end to end on the GPU.
+  sharded-trace     BASELINE config 5: ONE 10^9-sample fp32 trace for the whole job; rank r holds [S_r, S_{r+1} + halo),
+                    segments it as a stand-alone trace, the boundaries + spine flags are gathered (RCCL) and joined at
+                    common spine anchors inside the timed region; strong scaling.  Rank 0 checks the result against the
+                    same trace cut into 8 pieces (N = 1) or against its own whole piece (N > 1).
+  files             BASELINE config 4: 64 int16 files of 7.5e7 samples, sharded over the ranks (longest first); every
+                    file goes host (pinned) -> HBM on a copy stream while the previous file is detected + segmented on
+                    the library's stream (two streams per GPU); boundaries gathered once at the end.  Inputs start in
+                    HOST memory here, so this line is PCIe-inclusive by construction.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the kernel sequence of one step (two HIP events on the library's
+stream) at the algorithmic bytes of the path against 8 TB/s; `roofline.traffic` is read from the PMC summary committed
+under profiles/ (null when this run's arguments differ from the profiled ones); `cpu_baseline` times the CPU oracle
+(oracle/, a port of the reference) on this host: one thread, and one thread per core over tiles of the trace.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -25,35 +38,70 @@ sys.path.insert(0, ROOT)
 PARAMS = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10.,
               sampling_freq=1e5)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
-BYTES_PER_SAMPLE = 4       # one fp32 read per input sample
-# HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (r01_bs_pmc_summary.txt):
-# FETCH_SIZE (KiB) x2 per the gfx950 correction + WRITE_SIZE (KiB), fp32 trace workload, default build.
-PMC_TRAFFIC = {"blocksum_ms": (2 * 195356 + 196838) * 1024, "spine_ms": (2 * 186039 + 310) * 1024,
-               "bridge_ms": (2 * (3940 + 155) + 86) * 1024, "tree_ms": (2 * 87959 + 1428) * 1024}
-PMC_TRAFFIC_BYTES = sum(PMC_TRAFFIC.values())
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # written by tools/profile_round.sh from the PMC passes
+METRIC = "Msamples/sec segmented (SpeedyStatSplit, 10^8-sample trace); %HBM roofline"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_parse_tiled(x, cores, halo):
+    """The oracle on `cores` threads: contiguous pieces with a halo, each parsed as a stand-alone trace (ctypes releases
+    the GIL), joined at common spine anchors -- the same decomposition the multi-GPU path uses."""
+    import oracle
+    from pypore_amd import dist as pdist
+    n = x.size
+    ranges = pdist.shard_ranges(n, cores, halo)
+    res = [None] * cores
+
+    def work(r):
+        lo, hi = ranges[r]
+        res[r] = oracle.parse_flags(x[lo:hi], **PARAMS)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    pieces = [(ranges[r][0], ranges[r][1], res[r][0], res[r][1]) for r in range(cores)]
+    return pdist.stitch_pieces(pieces, n, PARAMS["window_width"], PARAMS["min_width"])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--samples", type=int, default=100_000_000)
-    ap.add_argument("--cpu-samples", type=int, default=20_000_000)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=None, help="samples per trace / file (default: the workload's BASELINE size)")
+    ap.add_argument("--files", type=int, default=64, help="files of the job (workload files)")
+    ap.add_argument("--cpu-samples", type=int, default=100_000_000, help="samples of rank 0's trace the CPU baseline runs on")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (trace workload)")
     ap.add_argument("--no-detail", action="store_true", help="skip the separate per-kernel timing pass (kernel_ms stays 0)")
     ap.add_argument("--stats", action="store_true", help="also run the per-segment statistics kernel in the step")
     ap.add_argument("--dwell", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="dwell range of the synthetic trace in samples (default: BASELINE's U[1000, 20000))")
-    ap.add_argument("--workload", choices=["trace", "file"], default="trace",
-                    help="trace: one SpeedyStatSplit.parse over the whole 1e8-sample fp32 trace (default); "
-                         "file: BASELINE config 3 -- int16 .abf-shaped trace, lambda_event_parser(threshold=90) "
-                         "then per-event SpeedyStatSplit, end to end on the GPU")
+    ap.add_argument("--workload", choices=["trace", "file", "sharded-trace", "files"], default="trace")
     args = ap.parse_args()
+    wl = args.workload
+    defaults = {"trace": (100, 20, 100_000_000), "file": (100, 20, 100_000_000),
+                "sharded-trace": (20, 5, 1_000_000_000), "files": (3, 1, 75_000_000)}[wl]
+    steps = defaults[0] if args.steps is None else args.steps
+    warmup = defaults[1] if args.warmup is None else args.warmup
+    n = defaults[2] if args.samples is None else args.samples
 
     import torch
     import torch.distributed as dist
     from pypore_amd import _lib, engine, synth
+    from pypore_amd import dist as pdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -67,54 +115,10 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
+    device = torch.device("cuda", dev)
     ctx = engine.context(dev)
-
-    n = args.samples
-    seed = 2024 + rank                                   # rank 0's trace is golden case G7
     params = _lib.split_params(**PARAMS)
-    from pypore_amd import dist as pdist
-    if args.workload == "trace":
-        d = synth.dwell_table(seed, n, *args.dwell) if args.dwell else synth.dwell_table(seed, n)
-        ends = np.cumsum(d)
-        lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
-        trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
-        ev_off = np.array([0, n], dtype=np.int64)
-        out1 = torch.empty(n // PARAMS["min_width"] + 1, dtype=torch.int32, device=trace.device)   # reused result buffer
-
-        def step(k=None):
-            # k: index of a timed batch when the job gathers its boundaries at the end (N > 1): they are written straight
-            # into row k of the send buffer
-            b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats,
-                                          out=acc[k] if k is not None and acc is not None else out1)
-            if k is not None and acc is not None:
-                acc_counts[k] = b.numel()
-            return b, o, st
-    else:
-        ends, lv, _ = synth.file_trace_table(n, seed)
-        trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.int16)     # what read_abf's data section holds
-        from pypore_amd import pipeline
-
-        def step(k=None):
-            st_, ln_, b, o, stt = pipeline.segment_file_trace(trace, synth.QUANTUM, params, threshold=90.0,
-                                                              want_stats=args.stats)
-            if k is not None and acc is not None:
-                acc[k, :b.numel()].copy_(b)
-                acc_counts[k] = b.numel()
-            return b, o, stt
-    torch.cuda.synchronize()
-
-    # The final boundary-index gather (RCCL), as in Experiment.parse (results are collected after all files are
-    # parsed): every rank writes the boundaries of its K batches into a [K, slot] send buffer and ONE all_gather (plus
-    # one of the K counts) runs at the end of the job, inside the timed region.  (dist.BoundaryGather is the per-batch
-    # form, one asynchronous collective per batch; it costs ~65 us of host time per batch.)
-    acc, acc_counts, recv, recv_counts = None, None, None, None
-
-    def final_gather():
-        if not use_dist:
-            return
-        cnt = torch.from_numpy(acc_counts).to(acc.device)
-        dist.all_gather_into_tensor(recv_counts, cnt)
-        dist.all_gather_into_tensor(recv, acc.view(-1))
+    W, mw = PARAMS["window_width"], PARAMS["min_width"]
 
     def barrier():
         torch.cuda.synchronize()
@@ -122,124 +126,340 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if use_dist:                                         # slot size of the gather: twice the largest count seen
-        b0, _, _ = step()
-        most = max(int(t.numel()) for t in pdist.gather_varlen(b0))
-        slot = 1 << int(np.ceil(np.log2(2 * most + 8)))
-        acc = torch.zeros((args.steps, slot), dtype=torch.int32, device=b0.device)
-        acc_counts = np.zeros(args.steps, dtype=np.int64)
-        recv = torch.zeros(world * args.steps * slot, dtype=torch.int32, device=b0.device)
-        recv_counts = torch.zeros(world * args.steps, dtype=torch.int64, device=b0.device)
+    acc = acc_counts = recv = recv_counts = None
+    check = {}                                           # parity evidence gathered outside the timed region
+    final_gather = lambda: None                          # noqa: E731
+    trace = None
+    seed = 2024 + (rank if wl in ("trace", "file") else 0)      # rank 0's trace is golden case G7
+
+    # ------------------------------------------------------------------------------------------------ workloads
+    if wl in ("trace", "file"):
+        if wl == "trace":
+            d = synth.dwell_table(seed, n, *args.dwell) if args.dwell else synth.dwell_table(seed, n)
+            ends = np.cumsum(d)
+            lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+            trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
+            ev_off = np.array([0, n], dtype=np.int64)
+            out1 = torch.empty(n // mw + 1, dtype=torch.int32, device=device)   # reused result buffer
+
+            def step(k=None):
+                # k: index of a timed batch when the job gathers its boundaries at the end (N > 1): they are written
+                # straight into row k of the send buffer
+                b, o, st = ctx.segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats,
+                                              out=acc[k] if k is not None and acc is not None else out1)
+                if k is not None and acc is not None:
+                    acc_counts[k] = b.numel()
+                return b
+        else:
+            ends, lv, _ = synth.file_trace_table(n, seed)
+            trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.int16)     # what read_abf's data section holds
+            from pypore_amd import pipeline
+
+            def step(k=None):
+                st_, ln_, b, o, stt = pipeline.segment_file_trace(trace, synth.QUANTUM, params, threshold=90.0,
+                                                                  want_stats=args.stats)
+                if k is not None and acc is not None:
+                    acc[k, :b.numel()].copy_(b)
+                    acc_counts[k] = b.numel()
+                return b
+        samples_per_step = n * world
+        bytes_per_sample = 4 if wl == "trace" else 2
+        scaling = "weak"
+        if use_dist:
+            # The final boundary-index gather (RCCL), as in Experiment.parse (results are collected after all files are
+            # parsed): every rank writes the boundaries of its K batches into a [K, slot] send buffer and ONE all_gather
+            # (plus one of the K counts) runs at the end of the job, inside the timed region.
+            b0 = step()
+            most = max(int(t.numel()) for t in pdist.gather_varlen(b0))
+            slot = 1 << int(np.ceil(np.log2(2 * most + 8)))
+            acc = torch.zeros((steps, slot), dtype=torch.int32, device=device)
+            acc_counts = np.zeros(steps, dtype=np.int64)
+            recv = torch.zeros(world * steps * slot, dtype=torch.int32, device=device)
+            recv_counts = torch.zeros(world * steps, dtype=torch.int64, device=device)
+
+            def final_gather():                          # noqa: F811
+                cnt = torch.from_numpy(acc_counts).to(device)
+                dist.all_gather_into_tensor(recv_counts, cnt)
+                dist.all_gather_into_tensor(recv, acc.view(-1))
+
+    elif wl == "sharded-trace":
+        halo = 8 * W
+        d = synth.dwell_table(seed, n, *args.dwell) if args.dwell else synth.dwell_table(seed, n)
+        ends = np.cumsum(d)
+        lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+        ranges = pdist.shard_ranges(n, world, halo)
+        lo, hi = ranges[rank]
+        trace = ctx.synth_trace(hi - lo, seed, ends, lv, dtype=torch.float32, start=lo)
+        piece_off = np.array([0, hi - lo], dtype=np.int64)
+        out1 = torch.empty((hi - lo) // mw + 1, dtype=torch.int32, device=device)
+
+        def segment_piece(t, off, out=None):
+            b, o, st, sp = ctx.segment_batch(t, off, params, synth.QUANTUM, want_stats=False, want_spine=True, out=out)
+            return b, sp
+
+        if use_dist:
+            def step(k=None):
+                b, sp = segment_piece(trace, piece_off, out1)
+                allb = pdist.gather_varlen(b)
+                allf = pdist.gather_varlen(sp)
+                pieces = [(ranges[r][0], ranges[r][1], allb[r].cpu().numpy(), allf[r].cpu().numpy()) for r in range(world)]
+                return pdist.stitch_pieces(pieces, n, W, mw)
+        else:
+            def step(k=None):
+                b, sp = segment_piece(trace, piece_off, out1)
+                return b
+        samples_per_step = n
+        bytes_per_sample = 4
+        scaling = "strong"
+
+    else:                                                # files (config 4)
+        n_files = args.files
+        lens = [n] * n_files
+        shards = pdist.shard_units(lens, world)
+        mine = shards[rank]
+        # file contents: four distinct synthetic int16 traces in pinned host memory, file f uses table f % 4 (the
+        # boundaries differ per table; what matters for the bench is the data path: host -> HBM -> kernels)
+        n_tables = min(4, max(1, len(mine)))
+        host = []
+        for t in range(n_tables):
+            ends_t, lv_t, _ = synth.file_trace_table(n, 7000 + t)
+            dtrace = ctx.synth_trace(n, 7000 + t, ends_t, lv_t, dtype=torch.int16)
+            h = torch.empty(n, dtype=torch.int16, pin_memory=True)
+            h.copy_(dtrace)
+            host.append(h)
+            del dtrace
+        torch.cuda.synchronize()
+        dbuf = [torch.empty(n, dtype=torch.int16, device=device) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=device)
+        from pypore_amd import pipeline
+
+        def step(k=None):
+            results = []
+            evs = [torch.cuda.Event() for _ in mine]
+            if mine:
+                with torch.cuda.stream(copy_stream):
+                    dbuf[0].copy_(host[mine[0] % n_tables], non_blocking=True)
+                    evs[0].record(copy_stream)
+            for j, f in enumerate(mine):
+                evs[j].synchronize()                     # file j is in HBM
+                if j + 1 < len(mine):                    # file j+1 travels while file j is segmented (the buffer it
+                    with torch.cuda.stream(copy_stream):  # overwrites was consumed by the blocking call of file j-1)
+                        dbuf[(j + 1) % 2].copy_(host[mine[j + 1] % n_tables], non_blocking=True)
+                        evs[j + 1].record(copy_stream)
+                st_, ln_, b, o, _ = pipeline.segment_file_trace(dbuf[j % 2], synth.QUANTUM, params, threshold=90.0)
+                results.append((st_, ln_, b.clone(), o))
+            if use_dist:                                 # the job's one gather: counts, then the padded payload
+                cat = torch.cat([r[2] for r in results]) if results else torch.zeros(0, dtype=torch.int32, device=device)
+                pdist.gather_varlen(torch.tensor([r[2].numel() for r in results], dtype=torch.int32, device=device))
+                pdist.gather_varlen(cat)
+            return results
+        samples_per_step = n * n_files
+        bytes_per_sample = 2
+        scaling = "strong"
+
+    torch.cuda.synchronize()
     # A fresh process starts cold (GPU clocks, pinned staging buffers, the allocator's pools): settle for a fixed
     # 0.2 s before the W warmup steps so that a small W does not leak start-up effects into the K timed steps.
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < 0.2:
         step()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     kern = dict(blocksum_ms=0.0, spine_ms=0.0, bridge_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, seq_ms=0.0)
     seq_ms = 0.0
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        bounds, boff, _ = step(k)
+    for k in range(steps):
+        result = step(k)
         seq_ms += ctx.seq_ms()                           # HIP events on the library's stream: first upload .. last result copy
     final_gather()                                       # the job's boundary gather is inside the timed region
     barrier()
     dt = time.perf_counter() - t0
-    seq_ms /= args.steps
+    seq_ms /= steps
+    tm = ctx.timings()                                   # work counters of the last timed step
     # Per-kernel breakdown: a separate, untimed pass with an event between the phases (each such event keeps the next
     # kernel from starting back to back, ~6 us of idle GPU, so the timed region above runs without them).
-    tm = ctx.timings()                                   # work counters of the last timed step
+    detail = wl in ("trace", "file", "sharded-trace") and not args.no_detail
     ctx.set_option("timing", 2)
-    for _ in range(0 if args.no_detail else args.steps):
+    for _ in range(min(steps, 20) if detail else 0):
         step()
-        tm = ctx.timings()
+        t2 = ctx.timings()
         for k in kern:
-            kern[k] += tm[k]
+            kern[k] += t2[k]
     ctx.set_option("timing", 1)
+    for k in kern:
+        kern[k] /= max(1, min(steps, 20))
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        all_counts = recv_counts.view(world, args.steps).cpu().numpy()
-        n_bounds = [int(c) for c in all_counts[:, -1]]            # the last batch's boundaries, all ranks
-        mine = recv.view(world, args.steps, -1)[rank, args.steps - 1, :n_bounds[rank]]
-        assert torch.equal(mine, bounds), "boundary gather returned something else for this rank"
+    ms_per_step = dt / steps * 1e3
+    value = samples_per_step / (dt / steps) / 1e6
+
+    # ------------------------------------------------------------------------------------------------ parity evidence
+    if wl in ("trace", "file"):
+        bounds = result
+        if use_dist:
+            all_counts = recv_counts.view(world, steps).cpu().numpy()
+            n_bounds = [int(c) for c in all_counts[:, -1]]            # the last batch's boundaries, all ranks
+            mine_row = recv.view(world, steps, -1)[rank, steps - 1, :n_bounds[rank]]
+            assert torch.equal(mine_row, bounds), "boundary gather returned something else for this rank"
+        else:
+            n_bounds = [int(bounds.numel())]
+    elif wl == "sharded-trace":
+        got = np.asarray(result.cpu().numpy() if hasattr(result, "cpu") else result, dtype=np.int64)
+        n_bounds = [int(got.size)]
+        if rank == 0:
+            if world == 1:
+                # the same trace as 8 stand-alone pieces with halo on this GPU, joined at common spine anchors
+                pr = pdist.shard_ranges(n, 8, halo)
+                pieces = []
+                for (plo, phi) in pr:
+                    b, sp = segment_piece(trace[plo:phi], np.array([0, phi - plo], dtype=np.int64))
+                    pieces.append((plo, phi, b.cpu().numpy(), sp.cpu().numpy()))
+                ref = pdist.stitch_pieces(pieces, n, W, mw)
+                check["whole_trace_equals_8_stitched_pieces"] = bool(np.array_equal(ref, got))
+            else:
+                b, sp = segment_piece(trace, piece_off)
+                mine_g = b.cpu().numpy().astype(np.int64) + lo
+                lim = ranges[0][1] - 2 * W - 2 * mw
+                check["rank0_piece_prefix_equal"] = bool(np.array_equal(mine_g[mine_g <= lim], got[got <= lim]))
+            assert all(check.values()), check
     else:
-        n_bounds = [int(bounds.numel())]
-    for k in kern:
-        kern[k] /= args.steps
-    ms_per_step = dt / args.steps * 1e3
-    value = world * n / (dt / args.steps) / 1e6
+        n_bounds = [int(sum(r[2].numel() for r in result))]
 
     if rank == 0:
-        bytes_per_sample = BYTES_PER_SAMPLE if args.workload == "trace" else 2      # int16 counts in config 3
-        # The path is a sequence of kernels; only K0 (blocksum) streams the samples, the scans work on its 2 B/sample
-        # digest.  The roofline figure is therefore quoted for the whole sequence: algorithmic bytes of the path
-        # (one read of every sample) over the duration of the sequence, measured with two HIP events on the
-        # library's stream in the timed region (first upload .. last result copy).
-        achieved = bytes_per_sample * n / (seq_ms * 1e-3) / 1e9 if seq_ms > 0 else 0.0
+        seq = seq_ms if wl != "files" else ms_per_step    # (files: many calls per step; the step is PCIe-inclusive)
+        per_gpu_bytes = bytes_per_sample * samples_per_step / world
+        achieved = per_gpu_bytes / (seq * 1e-3) / 1e9 if seq > 0 else 0.0
         names = ("blocksum_ms", "spine_ms", "bridge_ms", "tree_ms")
         dom = max(names, key=lambda k: kern[k])
-        # per-kernel algorithmic bytes: K0 reads every sample and writes 16 B per 8-sample block; the scans read the
-        # block prefix (16 B per block and window pass: two passes of overlapping windows on the spine) -- listed, not priced
-        k0_bytes = (bytes_per_sample + 2) * n
+        k0_bytes = (bytes_per_sample + 2) * (trace.numel() if trace is not None else n)
+        traffic = None
+        if wl == "trace" and os.path.exists(PMC_FILE) and not args.dwell and not args.stats and n == 100_000_000 \
+                and not os.environ.get("PORESEG_LIB"):
+            with open(PMC_FILE) as f:
+                traffic = json.load(f)                   # {"source": ..., "total": bytes, "per_kernel": {...}}
+        workload_text = {
+            "trace": "one %.0e-sample fp32 trace per GPU (5-level step signal, dwell U[1000,20000), sigma 1 pA, 2^-5 pA grid), "
+                     "single SpeedyStatSplit.parse over the whole trace" % n,
+            "file": "BASELINE config 3: one %.0e-sample int16 .abf-shaped trace per GPU @100 kHz (110 pA open channel, blockade "
+                    "events 1.5-10 s with dwells U[1000,20000)); lambda_event_parser(threshold=90) -> per-event "
+                    "SpeedyStatSplit, end to end on the GPU" % n,
+            "sharded-trace": "BASELINE config 5: ONE %.0e-sample fp32 trace for the job, rank r segments [S_r, S_r+1 + 8 W) as a "
+                             "stand-alone trace, boundaries + spine flags gathered and joined at common spine anchors inside "
+                             "the timed region" % n,
+            "files": "BASELINE config 4: %d int16 files of %.1e samples (.abf data sections in pinned host memory) sharded over "
+                     "the ranks; per file host->HBM on a copy stream overlapped with lambda_event_parser + SpeedyStatSplit of "
+                     "the previous file; PCIe-inclusive" % (args.files, n),
+        }[wl] + "; min_width=100 max_width=1e6 window_width=10000 prior_segments_per_second=10"
         out = {
-            "metric": "Msamples/sec segmented (SpeedyStatSplit, 10^8-sample trace); %HBM roofline",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("one %.0e-sample fp32 trace per GPU (5-level step signal, dwell U[1000,20000), "
-                                    "sigma 1 pA, 2^-5 pA grid), single SpeedyStatSplit.parse over the whole trace; "
-                                    "min_width=100 max_width=1e6 window_width=10000 prior_segments_per_second=10" % n)
-                       if args.workload == "trace" else
-                       ("BASELINE config 3: one %.0e-sample int16 .abf-shaped trace per GPU @100 kHz (110 pA open channel, "
-                        "blockade events 1.5-10 s with dwells U[1000,20000)); lambda_event_parser(threshold=90) -> "
-                        "per-event SpeedyStatSplit(prior_segments_per_second=10), end to end on the GPU" % n),
-                       "samples_per_gpu": n, "boundaries": n_bounds, "segment_stats_in_step": bool(args.stats)},
-            "roofline": {"bound": "hbm", "kernel": "kernel sequence of one ps_segment_batch (blocksum+spine+bridge+stitch+tree+gather)",
+            "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None,
+            "dtype": "int32/f64 (exact integer block sums of fp32 or int16 samples; decisions in fp64)", "data": "synthetic",
+            "config": {"workload": workload_text, "name": wl, "samples_per_step": samples_per_step, "boundaries": n_bounds,
+                       "segment_stats_in_step": bool(args.stats), "checks": check},
+            "roofline": {"bound": "hbm", "kernel": "kernel sequence of one ps_segment_batch (blocksum+spine+bridge+stitch+tree+gather)"
+                         if wl != "files" else "whole step incl. the host->HBM copies (PCIe-bound)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
-                         "traffic": PMC_TRAFFIC_BYTES if args.workload == "trace" else None,
-                         "algorithmic_bytes_per_launch": bytes_per_sample * n,
+                         "traffic": traffic["total"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "traffic_over_algorithmic": round(traffic["total"] / per_gpu_bytes, 3) if traffic else None,
+                         "algorithmic_bytes_per_launch": int(per_gpu_bytes),
                          "longest_kernel": dom.replace("_ms", "_kernel"),
                          "streaming_kernel": {"name": "blocksum_kernel", "ms": round(kern["blocksum_ms"], 4),
                                               "algorithmic_bytes": k0_bytes,
                                               "achieved": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / 1e9, 1) if kern["blocksum_ms"] > 0 else None,
-                                              "frac": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / HBM_PEAK, 4) if kern["blocksum_ms"] > 0 else None,
-                                              "traffic": PMC_TRAFFIC["blocksum_ms"] if args.workload == "trace" else None},
-                         "traffic_per_kernel": {k.replace("_ms", ""): v for k, v in PMC_TRAFFIC.items()} if args.workload == "trace" else None,
+                                              "frac": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / HBM_PEAK, 4) if kern["blocksum_ms"] > 0 else None},
+                         "traffic_per_kernel": traffic["per_kernel"] if traffic else None,
                          "sequence_ms": round(seq_ms, 4),
                          "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
                          "kernel_ms_note": "per-phase HIP events, separate untimed pass of the same steps (an event between "
                                            "two kernels costs ~6 us of idle GPU, so the timed region records only start and end)"},
-            "whole_step_frac_of_hbm_roofline": round(bytes_per_sample * n / (ms_per_step * 1e-3) / HBM_PEAK, 5),
-            "work": {k: tm[k] for k in ("windows", "candidates", "tiles", "tree_jobs", "repairs", "exact_rescans", "full_exact_scans")},
+            "whole_step_frac_of_hbm_roofline": round(per_gpu_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
+            "work": {k: tm[k] for k in ("windows", "candidates", "tiles", "tree_jobs", "exact_rescans", "full_exact_scans")},
+            # fallbacks of the last step: host-stitch repairs (a seam gave up: BR_MAX anchors), calls redone on the
+            # LDS-window path (counts too wide for the block sums), full fp64 window scans
+            "fallbacks": {"host_stitch": int(tm["repairs"] >= 1000000), "seam_repairs": int(tm["repairs"] % 1000000),
+                          "wide_range_redo": int(tm.get("wide_redo", 0)), "full_exact_scans": int(tm["full_exact_scans"])},
         }
-        if not args.no_cpu:
+        # ---- PCIe-inclusive rate (report H2D-inclusive separately; never `value`) ------------------
+        if wl == "trace" and not args.no_h2d and world == 1:
+            P = 8
+            pr = pdist.shard_ranges(n, P, 8 * W)
+            plen = max(hi_ - lo_ for lo_, hi_ in pr)
+            hbuf = torch.empty(n, dtype=torch.float32, pin_memory=True)
+            hbuf.copy_(trace)
+            torch.cuda.synchronize()
+            dbuf = [torch.empty(plen, dtype=torch.float32, device=device) for _ in range(2)]
+            cs = torch.cuda.Stream(device=device)
+
+            def h2d_step():
+                evs = [torch.cuda.Event() for _ in pr]
+                with torch.cuda.stream(cs):
+                    dbuf[0][:pr[0][1] - pr[0][0]].copy_(hbuf[pr[0][0]:pr[0][1]], non_blocking=True)
+                    evs[0].record(cs)
+                pieces = []
+                for j, (plo, phi) in enumerate(pr):
+                    evs[j].synchronize()
+                    if j + 1 < P:
+                        with torch.cuda.stream(cs):
+                            dbuf[(j + 1) % 2][:pr[j + 1][1] - pr[j + 1][0]].copy_(hbuf[pr[j + 1][0]:pr[j + 1][1]], non_blocking=True)
+                            evs[j + 1].record(cs)
+                    b, o, st, sp = ctx.segment_batch(dbuf[j % 2][:phi - plo], np.array([0, phi - plo], dtype=np.int64), params,
+                                                     synth.QUANTUM, want_stats=False, want_spine=True)
+                    pieces.append((plo, phi, b.cpu().numpy(), sp.cpu().numpy()))
+                return pdist.stitch_pieces(pieces, n, W, mw)
+
+            for _ in range(2):
+                hb = h2d_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                hb = h2d_step()
+            torch.cuda.synchronize()
+            th = (time.perf_counter() - t1) / reps
+            out["h2d_inclusive"] = {"value": round(n / th / 1e6, 1), "unit": "Msamples/s", "ms_per_trace": round(th * 1e3, 3),
+                                    "how": "trace in pinned host memory, %d pieces with an 8 W halo, piece k+1 copied on a second "
+                                           "stream while piece k is segmented, pieces joined at common spine anchors" % P,
+                                    "pcie_GBps": round(4 * n / th / 1e9, 1),
+                                    "boundaries_equal_resident_run": bool(np.array_equal(hb, bounds.cpu().numpy()))}
+            del hbuf, dbuf
+        # ---- CPU baseline: the oracle on this host, one thread and one thread per core ------------------------
+        if not args.no_cpu and wl in ("trace", "file"):
             import oracle
             m = min(n, args.cpu_samples)
             x = trace[:m].cpu().numpy().astype(np.float64)
-            if args.workload == "file":
+            if wl == "file":
                 x = x * synth.QUANTUM
+            cores = os.cpu_count() or 1
             t1 = time.perf_counter()
-            if args.workload == "file":
+            if wl == "file":
                 es, el = oracle.lambda_events(x, threshold=90.0)
-                refs = [oracle.parse(x[a:a + l], **{k: v for k, v in PARAMS.items()}) for a, l in zip(es, el)]
+                refs = [oracle.parse(x[a:a + l], **PARAMS) for a, l in zip(es, el)]
                 ref = np.concatenate(refs) if refs else np.zeros(0, np.int32)
             else:
-                ref = oracle.parse(x, **{k: v for k, v in PARAMS.items()})
+                ref = oracle.parse(x, **PARAMS)
             t2 = time.perf_counter()
             got = bounds.cpu().numpy()
             # prefix property: parse(x[:m]) agrees with parse(x) away from the cut
-            k = int(np.searchsorted(ref, m - 4 * PARAMS["window_width"])) if args.workload == "trace" else \
-                int(sum(len(r) for r in refs[:-1]))
+            kcut = int(np.searchsorted(ref, m - 4 * W)) if wl == "trace" else int(sum(len(r) for r in refs[:-1]))
             out["cpu_baseline"] = {"value": round(m / (t2 - t1) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-                                   "kind": "port",
+                                   "kind": "port", "cpu_model": cpu_model(), "host_cores": cores,
                                    "sample": "first %d samples of rank 0's trace, oracle/statsplit_oracle.c "
                                              "(gcc -O2), single thread" % m,
-                                   "prefix_boundaries_equal": bool(np.array_equal(ref[:k], got[:k]))}
+                                   "prefix_boundaries_equal": bool(np.array_equal(ref[:kcut], got[:kcut]))}
+            if wl == "trace" and cores > 1:
+                t3 = time.perf_counter()
+                refp = cpu_parse_tiled(x, cores, 8 * W)
+                t4 = time.perf_counter()
+                out["cpu_baseline"]["all_cores"] = {"value": round(m / (t4 - t3) / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+                                                    "how": "one thread per host core over contiguous tiles with an 8 W halo, "
+                                                           "joined at common spine anchors (same samples)",
+                                                    "equal_single_thread": bool(np.array_equal(refp, ref))}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -966,8 +966,10 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
         // block-sum scan: candidates must avoid the ragged ends of a window (min_width >= 8) and a window must fit
         // the single-wave sweep (W <= 90 000); otherwise the LDS-window kernels take the call
         bool use_bs = ctx->scan_bs && mw >= 8 && W <= 90000 && ctx->mode != MODE_EXACT;
-        if (use_bs && ctx->wide_skip > 0 && fmt->quantum == ctx->wide_quantum) { use_bs = false; --ctx->wide_skip; }
+        bool wide = false;
+        if (use_bs && ctx->wide_skip > 0 && fmt->quantum == ctx->wide_quantum) { use_bs = false; --ctx->wide_skip; wide = true; }
         rc = device_stitch_batch(ctx, cfg, use_bs, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+        if (wide) ctx->counters[7] = 1;              // counts too wide for the block sums: the LDS-window kernels took the call
         if (rc == RC_WIDE) {                          // counts too wide for uint32 block sums: LDS-window scan instead
             ctx->wide_quantum = fmt->quantum;         // (the next calls on this grid skip the attempt)
             ctx->wide_skip = 16;
@@ -975,6 +977,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
             for (int64_t &c : ctx->counters) c = 0;
             HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
             rc = device_stitch_batch(ctx, cfg, false, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+            ctx->counters[7] = 1;
         }
         if (rc != RC_FALLBACK) return rc;
         // a seam could not be bridged on the device: redo with the host stitch (halo tiles + repairs)

@@ -58,7 +58,7 @@ class Context(object):
         _lib.check(self.L.ps_get_timings(self.handle, ms, 8, cnt, 8))
         return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4], bridge_ms=ms[5], blocksum_ms=ms[6], seq_ms=ms[7],
                     windows=cnt[0], candidates=cnt[1], tiles=cnt[2], tree_jobs=cnt[3], repairs=cnt[4],
-                    exact_rescans=cnt[5], full_exact_scans=cnt[6])
+                    exact_rescans=cnt[5], full_exact_scans=cnt[6], wide_redo=cnt[7])
 
     # ---- the hot path ---------------------------------------------------------------------------
     def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None,
@@ -213,11 +213,19 @@ class Context(object):
                                          ctypes.c_void_p(status.data_ptr())), self.handle)
         return scores[:n_seq], paths[:int(off[-1])], status[:n_seq]
 
-    def synth_trace(self, n, seed, seg_end, level_counts, dtype=torch.float32):
-        """Synthetic step trace generated directly in HBM (csrc synth_kernel == pypore_amd.synth)."""
+    def synth_trace(self, n, seed, seg_end, level_counts, dtype=torch.float32, start=0):
+        """Synthetic step trace generated directly in HBM (csrc synth_kernel == pypore_amd.synth).  start > 0: the
+        samples [start, start + n) of the trace the table describes (a rank's piece of one long trace): the noise hash
+        of sample i is splitmix64(seed + (i + 1) * GOLDEN), so the piece is the same generator with a shifted seed and a
+        table cut at `start`."""
         out = torch.empty(n, dtype=dtype, device="cuda:%d" % self.device)
         seg_end = np.ascontiguousarray(seg_end, dtype=np.int64)
         level_counts = np.ascontiguousarray(level_counts, dtype=np.int32)
+        if start:
+            first = int(np.searchsorted(seg_end, start, side="right"))
+            seg_end = np.ascontiguousarray(seg_end[first:] - start)
+            level_counts = np.ascontiguousarray(level_counts[first:])
+            seed = (int(seed) + int(start) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         torch.cuda.current_stream(out.device).synchronize()
         _lib.check(self.L.ps_synth_trace(self.handle, ctypes.c_void_p(out.data_ptr()),
                                          _lib.PS_DTYPE_F32 if dtype == torch.float32 else _lib.PS_DTYPE_I16,

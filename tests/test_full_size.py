@@ -1,0 +1,137 @@
+"""BASELINE.json's configurations at their full sizes on one GPU.
+
+config 2: 1 024 events x 50 000 samples in one device call, every event against the oracle.
+config 5: ONE 10^9-sample trace: the whole-trace result on one GPU == the same trace cut into 8 stand-alone pieces
+          with halo, joined at common spine anchors (the multi-GPU decomposition, dist.stitch_pieces) == the oracle run
+          on 10 overlapping ~10^8-sample chunks on the host's cores and joined the same way (the reference
+          itself cannot hold 10^9 samples in one call here).
+config 4: the file loop (host -> HBM on a copy stream, detector + segmenter per file) on 6 files of 7.5e6 samples with
+          two of them checked event by event against the oracle; bench.py --workload files runs the 64 x 7.5e7 shape.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from pypore_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEF = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pypore_amd import engine
+    return engine.context(0)
+
+
+def test_config2_full_1024_events(ctx):
+    import torch
+    from pypore_amd import _lib
+    n_ev, n = 1024, 50000
+    counts = np.stack([synth.step_counts(n, 10000, ev) for ev in range(n_ev)])            # config2_event(ev): seed = event id
+    t = torch.from_numpy(synth.counts_to_pa(counts.reshape(-1), np.float32)).cuda()
+    ev_off = np.arange(n_ev + 1, dtype=np.int64) * n
+    bounds, boff, stats = ctx.segment_batch(t, ev_off, _lib.split_params(**DEF), synth.QUANTUM, want_stats=True)
+    b, st = bounds.cpu().numpy(), stats.cpu().numpy()
+    total = 0
+    for ev in range(n_ev):
+        x = synth.counts_to_pa(counts[ev], np.float64)
+        ref = oracle.parse(x, **DEF)
+        np.testing.assert_array_equal(b[boff[ev]:boff[ev + 1]], ref, err_msg="event %d" % ev)
+        if ev % 64 == 0:
+            rs = oracle.segment_stats(x, ref)
+            np.testing.assert_allclose(st[boff[ev] + ev: boff[ev + 1] + ev + 1, :2], rs[:, :2], rtol=1e-5)
+        total += len(ref)
+    assert total == boff[-1] and total > 4 * n_ev
+
+
+def test_config5_1e9_trace_whole_vs_pieces_vs_oracle_chunks(ctx):
+    import torch
+    from pypore_amd import _lib
+    from pypore_amd.dist import shard_ranges, stitch_pieces
+    n, seed, W, mw = 1_000_000_000, 2024, DEF["window_width"], DEF["min_width"]
+    d = synth.dwell_table(seed, n)
+    ends = np.cumsum(d)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    t = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
+    params = _lib.split_params(**DEF)
+    whole, _, _, flags = ctx.segment_batch(t, np.array([0, n]), params, synth.QUANTUM, want_stats=False, want_spine=True)
+    whole = whole.cpu().numpy().astype(np.int64)
+    assert np.all(np.diff(whole) >= mw) and whole[0] >= mw and whole[-1] <= n - mw
+    # (a) 8 stand-alone pieces on the GPU, stitched
+    pieces = []
+    for lo, hi in shard_ranges(n, 8, 8 * W):
+        pb, _, _, pf = ctx.segment_batch(t[lo:hi], np.array([0, hi - lo]), params, synth.QUANTUM, want_stats=False, want_spine=True)
+        pieces.append((lo, hi, pb.cpu().numpy(), pf.cpu().numpy()))
+    np.testing.assert_array_equal(stitch_pieces(pieces, n, W, mw), whole)
+    # (b) the piece generator equals the whole-trace generator (what bench.py --workload sharded-trace relies on)
+    lo, hi = shard_ranges(n, 8, 8 * W)[5]
+    assert torch.equal(ctx.synth_trace(hi - lo, seed, ends, lv, dtype=torch.float32, start=lo), t[lo:hi])
+    # (c) the oracle on 10 overlapping chunks of ~1e8 samples (one host thread each), joined the same way
+    ranges = shard_ranges(n, 10, 8 * W)
+    res = [None] * len(ranges)
+
+    def work(r):
+        clo, chi = ranges[r]
+        x = t[clo:chi].cpu().numpy().astype(np.float64)
+        res[r] = oracle.parse_flags(x, **DEF)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(len(ranges))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    ref = stitch_pieces([(ranges[r][0], ranges[r][1], res[r][0], res[r][1]) for r in range(len(ranges))], n, W, mw)
+    np.testing.assert_array_equal(ref, whole)
+    # the first chunk's spine flags are the whole trace's up to its trusted end
+    lim = ranges[0][1] - 2 * W - 2 * mw
+    k = int(np.searchsorted(whole, lim))
+    np.testing.assert_array_equal(flags.cpu().numpy()[:k], res[0][1][:k])
+
+
+def test_config4_file_loop_two_streams(ctx, tmp_path):
+    """Six .abf files: read_abf_counts -> pinned host -> HBM on a copy stream while the previous file is detected and
+    segmented (the loop of bench.py --workload files, from real files)."""
+    import os
+    import torch
+    from pypore_amd import _lib, abf, pipeline
+    n, params = 7_500_000, _lib.split_params(**DEF)
+    paths, tables = [], []
+    for f in range(6):
+        counts, events = synth.file_trace_counts(n, 900 + f)
+        p = os.path.join(str(tmp_path), "f%d.abf" % f)
+        abf.write_abf(p, counts.astype(np.int16))
+        paths.append(p)
+        tables.append((counts, events))
+    host = []
+    for p in paths:
+        dt, raw, scale, offset = abf.read_abf_counts(p)
+        assert (dt, scale, offset) == (0.01, synth.QUANTUM, 0.0)
+        h = torch.empty(n, dtype=torch.int16, pin_memory=True)
+        h.copy_(torch.from_numpy(np.array(raw)))
+        host.append(h)
+    dbuf = [torch.empty(n, dtype=torch.int16, device="cuda") for _ in range(2)]
+    cs = torch.cuda.Stream()
+    evs = [torch.cuda.Event() for _ in paths]
+    with torch.cuda.stream(cs):
+        dbuf[0].copy_(host[0], non_blocking=True)
+        evs[0].record(cs)
+    out = []
+    for j in range(len(paths)):
+        evs[j].synchronize()
+        if j + 1 < len(paths):
+            with torch.cuda.stream(cs):
+                dbuf[(j + 1) % 2].copy_(host[j + 1], non_blocking=True)
+                evs[j + 1].record(cs)
+        st, ln, b, o, _ = pipeline.segment_file_trace(dbuf[j % 2], synth.QUANTUM, params, threshold=90.0)
+        out.append((st, ln, b.cpu().numpy(), o))
+    for j, (st, ln, b, o) in enumerate(out):
+        counts, events = tables[j]
+        if j in (0, 5):
+            es, el = oracle.lambda_events(synth.counts_to_pa(counts, np.float64), threshold=90.0)
+            assert list(zip(st.tolist(), ln.tolist())) == list(zip(es.tolist(), el.tolist()))
+            for e, (a, l) in enumerate(zip(st, ln)):
+                ref = oracle.parse(synth.counts_to_pa(counts[a:a + l], np.float64), **DEF)
+                np.testing.assert_array_equal(b[o[e]:o[e + 1]], ref)
