@@ -94,6 +94,8 @@ struct ps_ctx {
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     int spec_tree = 0;        // 1: waves of the spine kernel whose chains have ended run subtree jobs speculatively (spine_spec_kernel; measured slower: the scans are issue-bound)
+    int bridge_single = 1 << 30;   // anchors a single-wave bridge adds before it hands the seam to the look-ahead kernel (measured: handing over early is slower)
+    int tree_tail_pct = 0;    // tree_mw_kernel: share of the job list drawn dynamically (counter in HBM) at the end
     int spec_flags = 1;       // spine_spec_kernel: 1 = chains at high priority, 2 = stop speculating when all chains have ended
     int epoch = 0;            // call counter: tag of this call's queue entries and speculative records
     DevBuf spec_queue, spec_qaux, spec_rec;
@@ -149,7 +151,7 @@ int fail(ps_ctx *ctx, int code, const char *fmt, ...)
 // (hdr: the stitch header lives behind the counters so that one copy brings both back)
 // (SMALL_TAIL bytes behind it hold the per-event offsets of small batches, so that one copy brings everything back)
 constexpr size_t SMALL_TAIL = 64 * 1024;
-struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9], qctl, qhead; AsmHeader hdr; };
+struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9], qctl, qhead, tree_tail; AsmHeader hdr; };
 
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
              double min_gain, DevCfg *c)
@@ -275,7 +277,7 @@ template <int DT> int launch_tree_mw(ps_ctx *ctx, const DevCfg &cfg, unsigned nj
     hipLaunchKernelGGL((tree_mw_kernel<DT>), dim3(grid), dim3(64 * TREE_W), lds, ctx->stream, cfg,
                        ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
                        ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
-                       static_cast<long long>(n_jobs), d_hdr);
+                       static_cast<long long>(n_jobs), d_hdr, &sm->tree_tail, ctx->tree_tail_pct);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -528,7 +530,7 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
     hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
                        ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
-                       &sm->work0, static_cast<int>(nj));
+                       &sm->work0, static_cast<int>(nj), ctx->bridge_single);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -811,6 +813,8 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SPEC_TREE")) ctx->spec_tree = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SPEC_FLAGS")) ctx->spec_flags = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_FILTER_FUSED")) ctx->filter_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
@@ -861,6 +865,8 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
     else if (n == "spec_tree") ctx->spec_tree = value != 0;
     else if (n == "spec_flags") ctx->spec_flags = static_cast<int>(value);
+    else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
+    else if (n == "tree_tail_pct" && value >= 0 && value <= 100) ctx->tree_tail_pct = static_cast<int>(value);
     else if (n == "filter_fused") ctx->filter_fused = value != 0;
     else if (n == "upload_by_kernel") ctx->upload_by_kernel = value != 0;
     else if (n == "timing") ctx->timing = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(2, value)));

@@ -1102,7 +1102,7 @@ constexpr int BR_PATIENCE = 3;     // windows without a hit a single-wave bridge
 template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                        const int4 *meta, int2 *bridges, int4 *bmeta,
-                                                       unsigned *status, unsigned long long *work, int n_jobs)
+                                                       unsigned *status, unsigned long long *work, int n_jobs, int max_single)
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
@@ -1152,6 +1152,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
             }
             if (found != -2 && u != g) { st = BR_JOINED; jt = u; ji = found; break; }
             if (step == BR_MAX) break;
+            // option bridge_single (default: off): hand the seam to the look-ahead kernel after max_single anchors
+            // (measured slower: 0.064 -> 0.076 / 0.083 ms with 2 / 1 anchors -- most seams need no second anchor)
+            if (NT == 64 && c.bsum != nullptr && cnt >= max_single) { st = BR_DEFER; jt = 0; break; }
             int kind;
             // (the samples a bridge reads were validated by the downstream tiles' own spine scans; the first call skips
             // the windows the tile's own chain already scanned without a hit before it gave up)
@@ -1540,25 +1543,40 @@ constexpr int TREE_W = PS_TREE_W;
 template <int DT>
 __global__ __launch_bounds__(64 * TREE_W, 2) void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
-                                                  unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr)
+                                                  unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr,
+                                                  unsigned long long *tail_ctr, int tail_pct)
 {
     extern __shared__ int ys[];                        // TREE_W x SharedT<64> (beyond the static 64 KB for 8 waves)
     __shared__ int next_k;
     const int wave = threadIdx.x >> 6;
     SharedT<64> &sh = reinterpret_cast<SharedT<64> *>(ys)[wave];
     const long long n_jobs = dev_count(hdr, n_jobs_host);
+    // tail_pct > 0 (option tree_tail_pct, default 0): the last tail_pct per cent of the job list are drawn one by one
+    // from a counter in HBM by whoever has finished its static share.  Measured slower at every share (15 %: 0.146 ->
+    // 0.160 ms): the returning atomic sits in front of the job's first loads, as with a fully dynamic draw.
+    const long long n_static = n_jobs - n_jobs * tail_pct / 100;
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
     if (threadIdx.x == 0) next_k = TREE_W;             // the first TREE_W jobs of the list are the waves' own
     __syncthreads();
-    for (long long k = wave;;) {
-        const long long ji = blockIdx.x + k * gridDim.x;
-        if (ji >= n_jobs) break;
+    bool dyn = false;                                  // (one loop, one call site of the job body: a second inlined copy
+    for (long long k = wave;;) {                       //  of the scan code costs registers -- 0.146 -> 0.204 ms)
+        long long ji = blockIdx.x + k * gridDim.x;
+        if (!dyn && ji >= n_static) dyn = true;
+        if (dyn) {
+            if (n_static >= n_jobs) break;
+            unsigned long long t = 0;
+            if (ps_tid<64>() == 0) t = atomicAdd(tail_ctr, 1ULL);
+            ji = n_static + static_cast<long long>(__shfl(t, 0));
+            if (ji >= n_jobs) break;
+        }
         const TreeJob job = jobs[ji];
         if (job.out_cap != 0) tree_job<64, DT>(c, nullptr, job, ji, scratch, spill, counts, sh, bad, wk);
-        int kk = 0;
-        if (ps_tid<64>() == 0) kk = atomicAdd(&next_k, 1);
-        k = __builtin_amdgcn_readfirstlane(kk);
+        if (!dyn) {
+            int kk = 0;
+            if (ps_tid<64>() == 0) kk = atomicAdd(&next_k, 1);
+            k = __builtin_amdgcn_readfirstlane(kk);
+        }
     }
     flush_wave(bad, wk, status, work);
 }
