@@ -236,6 +236,56 @@ class Context(object):
         return out
 
 
+class StreamPool(object):
+    """T contexts on one GPU (each a ps_ctx with its own HIP stream and scratch) fed by T host threads.
+
+    One call of the path is a chain of kernels with idle stretches -- the tails of the spine and subtree kernels, the
+    single-workgroup stitch kernels, the seam bridges that occupy a fraction of the chip.  Batches are independent
+    (events and files are the reference's own unit of work, DataTypes.py:968-984), so the kernels of one batch fill the
+    idle stretches of another when they are submitted on different streams: two streams deliver 1.4x the batches per
+    second of one on the 1e8-sample bench trace, with bit-identical results.  ctypes drops the GIL for the duration of a
+    call, so plain Python threads are enough.  Every call still ends with its own stream synchronisation."""
+
+    def __init__(self, device=None, streams=2):
+        base = context(device)
+        self.contexts = [base] + [Context(base.device) for _ in range(max(1, int(streams)) - 1)]
+
+    def __len__(self):
+        return len(self.contexts)
+
+    def run(self, n_jobs, job):
+        """Runs job(ctx, k, t) for k = 0 .. n_jobs-1, job k on context k % T (thread t = k % T); returns the results in job order."""
+        import threading
+        T = len(self.contexts)
+        results = [None] * n_jobs
+        errors = []
+
+        def work(t):
+            try:
+                for k in range(t, n_jobs, T):
+                    results[k] = job(self.contexts[t], k, t)
+            except BaseException as e:                 # noqa: B036 -- re-raised on the submitting thread
+                errors.append(e)
+
+        if T == 1 or n_jobs <= 1:
+            work(0)
+        else:
+            threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+        if errors:
+            raise errors[0]
+        return results
+
+    def segment_many(self, batches, params, quantum, offset_counts=0, want_stats=False):
+        """batches: list of (samples CUDA tensor, ev_off); one ps_segment_batch each, spread over the streams.  Returns
+        the list of (bounds, bounds_off, stats) in batch order."""
+        return self.run(len(batches), lambda ctx, k, t: ctx.segment_batch(batches[k][0], batches[k][1], params, quantum,
+                                                                          offset_counts=offset_counts, want_stats=want_stats))
+
+
 def context(device=None):
     """The process-wide Context of `device` (default: torch's current device)."""
     if device is None:

@@ -8,12 +8,12 @@ from . import _lib, engine
 
 
 def segment_file_trace(samples, quantum, params=None, threshold=90.0, min_duration=100000, min_current=-0.5,
-                       offset_counts=0, device=None, want_stats=False, offset=0.0):
+                       offset_counts=0, device=None, want_stats=False, offset=0.0, ctx=None):
     """samples: 1-D CUDA tensor (float32 pA on the `quantum` grid, or int16 ADC counts); pA = (count + offset_counts)
     * quantum + offset (`offset`: the part of an .abf offset that is not a whole number of counts; the detector's
     thresholds move by it, the segmenter's gains do not depend on it).
     Returns (ev_start, ev_len, bounds int32 CUDA tensor, bounds_off, stats or None)."""
-    ctx = engine.context(device)
+    ctx = ctx or engine.context(device)
     if params is None:
         params = _lib.split_params(prior_segments_per_second=10.)
     st, ln = ctx.detect_events(samples, quantum, threshold - offset, min_duration, min_current - offset, offset_counts)
