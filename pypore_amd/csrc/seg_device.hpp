@@ -526,6 +526,96 @@ __device__ int scan_screen(const DevCfg &c, const lds_t *ys, int ps, int n, int 
 }
 
 
+// ---- screen for windows whose counts do not fit the int16 LDS image ------------------------------------------
+// A filtered event (Event.filter) is float64 off every ADC grid; Event.parse rounds it to a 2^-18 pA grid, which makes
+// counts of +-2^21.  Such a window used to go straight to scan_exact: two fp64 logs and four fp64 divisions per
+// candidate.  This screen reads the samples from HBM like scan_exact does (each thread owns a contiguous chunk), but
+// evaluates the candidates like the block-sum scan: sums of y = k - m0 (m0 = middle of the window's range) and y^2 in
+// fp64, D = n*S2 - S1^2 per side in fp64, everything after the conversion of D in fp32 (v_rcp_f32, v_log_f32).
+// Accuracy: the fp64 sums carry a relative error of at most (chunk + log2 NT) * 2^-53 ~ 2^-47, D loses
+// kappa = n*S2/D of that, and kappa <= (R/2)^2 / V is kept below 2^22 by the variance floor: D is good to 2^-25, the
+// rest of the budget is that of the block-sum screen (delta(n) = 0.02 + 8e-6 n log2 units).  Decisions: the same
+// threshold band / unique-winner rule; anything else is decided by scan_exact.
+template <int NT, int DT>
+__device__ int scan_screen_wide(const DevCfg &c, int64_t g0, int ps, int n, int cand_lo, int cand_hi, double thresh,
+                                int kmin, int kmax, SharedT<NT> &sh, int *split, unsigned &bad)
+{
+    constexpr int NW = NT / 64;
+    const int ch = ((n + NT - 1) / NT) | 1;
+    const int lo = min(n, static_cast<int>(ps_tid<NT>()) * ch);
+    const int hi = min(n, lo + ch);
+    const long long R = static_cast<long long>(kmax) - kmin;
+    if (R >= (1LL << 24)) return 0;                   // (n * (R/2)^2 must stay below 2^60 or so: fp64 has the room, stay modest)
+    const int m0 = kmin + static_cast<int>(R >> 1);
+    double s1 = 0, s2 = 0;
+    for (int j = lo; j < hi; ++j) {
+        const double y = static_cast<double>(load_count<DT>(c, g0 + j, bad) - m0);
+        s1 += y; s2 = fma(y, y, s2);
+    }
+    double a1, a2, t1, t2;
+    block_exscan2<NT>(s1, s2, a1, a2, t1, t2, sh);
+    const double dn = static_cast<double>(n);
+    const double Dtot = dn * t2 - t1 * t1;
+    if (!(Dtot > 0.0)) return 0;
+    const float rn = __builtin_amdgcn_rcpf(static_cast<float>(n));
+    const float c0 = __builtin_amdgcn_logf(static_cast<float>(Dtot) * rn * rn);
+    const f2 cc = {c0, c0};
+    const float mabs = fmaxf(fabsf(static_cast<float>(kmin)), fabsf(static_cast<float>(kmax)));
+    const float half = 0.5f * static_cast<float>(R);
+    const float vfloor = fmaxf(mabs * mabs * 1.0e-9f, half * half * 2.4e-7f);       // 2^-22
+    const int clo = max(lo, cand_lo - ps), chi = min(hi, cand_hi - ps + 1);
+    Top2 top = {-INFINITY, -INFINITY, -1};
+    unsigned flag = 0;
+    if (clo < chi) {
+        for (int j = lo; j < clo; ++j) {
+            const double y = static_cast<double>(load_count<DT>(c, g0 + j, bad) - m0);
+            a1 += y; a2 = fma(y, y, a2);
+        }
+        float umin = INFINITY;
+        for (int j = clo; j < chi; ++j) {
+            const double nl = static_cast<double>(j), nr = dn - nl;
+            const double b1 = t1 - a1, b2 = t2 - a2;
+            const double DL = fma(nl, a2, -(a1 * a1)), DR = fma(nr, b2, -(b1 * b1));
+            const f2 D = {static_cast<float>(DL), static_cast<float>(DR)};
+            const f2 nv = {static_cast<float>(j), static_cast<float>(n - j)};
+            const f2 r = {__builtin_amdgcn_rcpf(nv.x), __builtin_amdgcn_rcpf(nv.y)};
+            const f2 u = D * r * r;
+            umin = fminf(umin, fminf(u.x, u.y));
+            const f2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+            const f2 t = nv * (lg - cc);
+            top2_push(top, -(t.x + t.y), j);
+            const double y = static_cast<double>(load_count<DT>(c, g0 + j, bad) - m0);
+            a1 += y; a2 = fma(y, y, a2);
+        }
+        if (!(umin >= vfloor)) flag = 1;              // also catches NaN
+    }
+    const int lane = threadIdx.x & 63, wave = ps_tid<NT>() >> 6;
+#define PS_STEP(CTRL, RM) { const float ob = dpp_movf<CTRL, RM>(-INFINITY, top.b), os = dpp_movf<CTRL, RM>(-INFINITY, top.s); \
+                            const int oi = dpp_mov<CTRL, RM>(-1, top.i); const int of = dpp_mov<CTRL, RM>(0, static_cast<int>(flag)); \
+                            top2_merge(top, ob, os, oi); flag |= static_cast<unsigned>(of); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    ps_sync<NT>();                                     // (block_exscan2's slots are not reused here, but fbest.. may be by a caller)
+    if (lane == 63) { sh.fbest[wave] = top.b; sh.fsecond[wave] = top.s; sh.fidx[wave] = top.i; sh.wflag[wave] = flag; }
+    ps_sync<NT>();
+    Top2 all = {sh.fbest[0], sh.fsecond[0], sh.fidx[0]};
+    unsigned anyflag = sh.wflag[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        top2_merge(all, sh.fbest[w], sh.fsecond[w], sh.fidx[w]);
+        anyflag |= sh.wflag[w];
+    }
+    ps_sync<NT>();
+    if (anyflag) return 0;
+    const float dlt = screen_delta_log2(n);
+    const float thr_log2 = static_cast<float>(thresh * 1.4426950408889634);
+    const float dthr = dlt + 3.0e-6f * static_cast<float>(n) + 1.0e-6f * fabsf(thr_log2);
+    if (all.b < thr_log2 - dthr) { *split = -1; return 1; }
+    if (all.b > thr_log2 + dthr && all.s < all.b - 2.0f * dlt) { *split = ps + all.i; return 1; }
+    return 0;
+}
+
+
 // ---- fp32 screen with exact block pruning -----------------------------------------------------------
 // Most candidates never need an evaluation.  For a block of candidates j in [jb, je) the sums of
 // squared deviations are monotone: SS_L(j) >= SS_L(jb) (the left part only grows) and
@@ -899,9 +989,15 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 #pragma unroll
     for (int w = 1; w < NW; ++w) { kmin = min(kmin, sh.wmin[w]); kmax = max(kmax, sh.wmax[w]); }
     if (DT == PS_DTYPE_F32 && (kmin <= -8388608 || kmax >= 8388608)) bad |= ST_OFF_GRID;   // |count| >= 2^23
-    if (kmin < -32768 || kmax > 32767) {               // counts do not fit the int16 LDS image: exact path from HBM
+    if (kmin < -32768 || kmax > 32767) {               // counts do not fit the int16 LDS image: screen / exact path from HBM
+        int wsplit = -1;
+        const bool try_screen = c.mode != MODE_EXACT && scores == nullptr && best_gain_out == nullptr;
+        const int wdone = try_screen ? scan_screen_wide<NT, DT>(c, g0, ps, n, cand_lo, cand_hi, thresh, kmin, kmax, sh, &wsplit, bad) : 0;
+        if (wdone && c.mode == MODE_FAST) return wsplit;
         if (threadIdx.x == 0) wk.exact += 1;
-        return scan_exact<NT, DT>(c, nullptr, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
+        const int ex = scan_exact<NT, DT>(c, nullptr, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
+        if (wdone && c.mode == MODE_VERIFY && ex != wsplit) bad |= ST_VERIFY_MISMATCH;
+        return ex;
     }
     PS_STAMP_AT(wk, 1);                                // min/max reduce + barrier
 

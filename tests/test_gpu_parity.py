@@ -254,8 +254,9 @@ def test_spine_flags_and_sharded_trace_on_device(ctx):
 
 def test_counts_beyond_int16_take_the_exact_path(ctx):
     """LDS-window scan: quantum 2^-10 turns 50 pA into 51200 counts, the window does not fit the int16 LDS
-    image and is scanned by the exact fp64 path straight from HBM -- same boundaries.  The block-sum scan
-    (default) centres on the first sample and handles the same input without any fallback."""
+    image and is scanned straight from HBM -- by the wide-count screen (fp64 sums, fp32 logs) where that decides,
+    by the exact fp64 path otherwise, and by the exact path alone in mode 1 -- same boundaries each time.  The
+    block-sum scan (default) centres on the first sample and handles the same input without any fallback."""
     from pypore_amd.parsers import SpeedyStatSplit
     x = synth.config2_event(5)
     ref = oracle.parse(x, prior_segments_per_second=10.)
@@ -265,9 +266,17 @@ def test_counts_beyond_int16_take_the_exact_path(ctx):
     try:
         segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -10).parse(x)
         np.testing.assert_array_equal(_bounds(segs), ref)
-        assert ctx.timings()["exact_rescans"] > 0
+        screened = ctx.timings()["exact_rescans"]
+        ctx.set_option("mode", 1)                      # exact scans only
+        segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -10).parse(x)
+        np.testing.assert_array_equal(_bounds(segs), ref)
+        assert ctx.timings()["exact_rescans"] > screened
+        ctx.set_option("mode", 2)                      # verify: screen and exact scan must agree on every window
+        segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -10).parse(x)
+        np.testing.assert_array_equal(_bounds(segs), ref)
     finally:
         ctx.set_option("scan_bs", 1)
+        ctx.set_option("mode", 0)
 
 
 def test_wide_range_counts_fall_back_from_block_sums(ctx):

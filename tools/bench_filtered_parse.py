@@ -18,4 +18,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5):
     b, boff, _ = ctx.segment_batch(t, off, p, fq, want_stats=False)
 torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
+ctx.set_option("timing", 2); ctx.segment_batch(t, off, p, fq, want_stats=False); tm = ctx.timings(); ctx.set_option("timing", 1)
+print({k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")})
 print("filtered 1e6-sample event on the 2^%d grid: %.3f ms, %d boundaries" % (int(np.log2(fq)), ms, b.numel()), ctx.timings())
