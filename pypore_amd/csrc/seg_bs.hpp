@@ -243,6 +243,8 @@ static_assert(sizeof(QEnt) * SharedT<64>::QN >= sizeof(BsQ) * BS_QN + sizeof(BsC
 __device__ __forceinline__ double bs_exact_gain(const DevCfg &c, int m, int a1, double a2, int T1, double T2, int nl, int n,
                                                 double var_summed)
 {
+#pragma clang fp contract(off)
+    // (the caller guarantees n * max|k|^2 < 2^53: every product and sum below is then an exact integer in fp64)
     const double dm = static_cast<double>(m);
     // uncentred sums: sum k = a1 + nl*m ; sum k^2 = a2 + 2*m*a1 + nl*m^2   (exact integers below 2^53)
     const double l1 = static_cast<double>(a1) + static_cast<double>(nl) * dm;
@@ -541,7 +543,10 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         Tprune = Tc - 2.0f * dlt;
     }
 #undef PS_COLLECT
-    if (result == -2 && !anyflag && ccount <= BS_NC) {
+    // The contenders are decided from UNCENTRED sums (sum k, sum k^2 as the reference forms them): exact only while
+    // n * max|k|^2 < 2^53.  Beyond that (a large DC offset on a fine grid) the window takes the whole-window fp64 scan.
+    const bool sums_exact = static_cast<double>(n) * static_cast<double>(mabs) * static_cast<double>(mabs) < 9007199254740992.0;
+    if (result == -2 && !anyflag && ccount <= BS_NC && sums_exact) {
         ps_sync<64>();                              // contender stores visible to the other lanes
         const double var_summed = static_cast<double>(n) *
             log(ref_var(T1d + dn * static_cast<double>(m),

@@ -468,3 +468,23 @@ def test_dwell_and_parameter_regimes(regime, ctx):
     finally:
         ctx.set_option("mode", 0)
         ctx.set_tiling(0, 0)
+
+
+def test_large_dc_offset_on_a_fine_grid(ctx):
+    """counts near 2^21 (a 50 pA baseline on a 2^-15 pA grid): n * max|k|^2 exceeds 2^53, so the uncentred
+    sums the contender path would form are no longer exact integers in fp64 -- those windows take the whole-window
+    fp64 scan instead (the block sums about the event's first sample stay exact: |k - m| < 23 000).  The reference's own
+    cumsums round in this regime; boundaries still agree (oracle on the same float64 values), also in verify mode."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    k = (synth.random_dwell_counts(400000, 77).astype(np.int64) - 1500) * 16 + 1638400
+    assert np.abs(k).max() < 2 ** 23 and 10000 * float(np.abs(k).max()) ** 2 > 2.0 ** 53
+    x = k.astype(np.float64) * 2.0 ** -15
+    ref = oracle.parse(x, prior_segments_per_second=10.)
+    for mode in (0, 2):
+        ctx.set_option("mode", mode)
+        try:
+            segs = SpeedyStatSplit(prior_segments_per_second=10., quantum=2.0 ** -15).parse(x)
+        finally:
+            ctx.set_option("mode", 0)
+        np.testing.assert_array_equal(_bounds(segs), ref)
+        assert ctx.timings()["wide_redo"] == 0

@@ -9,7 +9,7 @@ cd /tmp
 run() {  # name counters...
   name=$1; shift
   rm -rf /tmp/prof_$name
-  rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -o out --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu > /tmp/prof_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -o out --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --streams 1 > /tmp/prof_$name.log 2>&1
   python3 - "$name" <<'PY' >> $ROOT/gpurun_out/${TAG}_summary.txt
 import sys, csv, glob, collections
 name = sys.argv[1]

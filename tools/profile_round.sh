@@ -1,16 +1,47 @@
 #!/bin/bash
-# Collects the evidence committed under profiles/: rocprofv3 kernel stats of the default bench command, the PMC
-# passes (tools/pmc_run.sh) and the bench JSON line.  Run on the GPU box: gpurun -- 'bash tools/profile_round.sh TAG'
-TAG=${1:-r01}
+# Collects the evidence committed under profiles/ for one round.  Run on the GPU box:
+#   gpurun -- 'bash tools/profile_round.sh r02'
+# Outputs (gpurun_out/, copy to profiles/):
+#   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the DEFAULT bench command (4 streams: kernels of
+#                               different calls overlap, so single launches run longer than alone)
+#   <tag>_s1_kernel_stats.csv   the same with --streams 1 (one call at a time: the per-kernel durations of roofline.kernel_ms)
+#   <tag>_bench.json            the default bench line (incl. cpu_baseline, h2d_inclusive)
+#   <tag>_pmc_summary.txt       PMC passes (tools/pmc_run.sh, --streams 1), <tag>_pmc_traffic.json: HBM bytes per launch
+TAG=${1:-r02}
 ROOT=$PWD
 export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out
-cd /tmp && rm -rf /tmp/kstats
-rocprofv3 --kernel-trace --stats -d /tmp/kstats -o out --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu > /tmp/kstats.log 2>&1
-cp $(find /tmp/kstats -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/${TAG}_kernel_stats.csv
+cd /tmp
+for s in 4 1; do
+  rm -rf /tmp/kstats
+  rocprofv3 --kernel-trace --stats -d /tmp/kstats -o out --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-h2d --streams $s > /tmp/kstats_$s.log 2>&1
+  out=$ROOT/gpurun_out/${TAG}_kernel_stats.csv
+  [ $s = 1 ] && out=$ROOT/gpurun_out/${TAG}_s1_kernel_stats.csv
+  cp $(find /tmp/kstats -name '*kernel_stats.csv' | head -1) $out
+  tail -1 /tmp/kstats_$s.log | cut -c1-400
+done
 cd $ROOT
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 bash tools/pmc_run.sh ${TAG}_pmc > /dev/null 2>&1
-head -20 gpurun_out/${TAG}_kernel_stats.csv
-cat gpurun_out/${TAG}_bench.json
-grep -E "^(fetch|write) " gpurun_out/${TAG}_pmc_summary.txt | grep -E "blocksum|spine|bridge|tree_"
+python3 - $TAG <<'PY'
+import sys, re, json, ast
+tag = sys.argv[1]
+per = {}
+for line in open('gpurun_out/%s_pmc_summary.txt' % tag):
+    m = re.match(r'(fetch|write) (?:void )?ps::(\w+)(?:<[^>]*>)? (\{.*\})', line.strip())
+    if not m: continue
+    d = ast.literal_eval(m.group(3))
+    k = m.group(2)
+    per.setdefault(k, {})
+    if m.group(1) == 'fetch': per[k]['fetch_kib'] = d['FETCH_SIZE']
+    else: per[k]['write_kib'] = d['WRITE_SIZE']
+names = ['blocksum_kernel', 'spine_kernel', 'bridge_kernel', 'bridge_la_kernel', 'tree_mw_kernel', 'assemble_tiles_kernel',
+         'assemble_items_kernel', 'item_scan_kernel', 'gather_kernel', 'upload_kernel']
+pk = {k: (2 * per[k].get('fetch_kib', 0) + per[k].get('write_kib', 0)) * 1024 for k in names if k in per}
+json.dump({"source": "profiles/%s_pmc_summary.txt: FETCH_SIZE (KiB) x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE (KiB) per "
+                     "launch, rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --streams 1`" % tag,
+           "total": sum(pk.values()), "per_kernel": pk}, open('gpurun_out/%s_pmc_traffic.json' % tag, 'w'), indent=1)
+print(json.dumps(pk))
+PY
+head -12 gpurun_out/${TAG}_s1_kernel_stats.csv | cut -c1-60,200-400
+cat gpurun_out/${TAG}_bench.json | cut -c1-600
