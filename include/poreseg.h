@@ -173,11 +173,13 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
                      double threshold, int64_t min_duration, double min_current,
                      int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out);
 
-/* Replaces Event.filter (DataTypes.py:258-274) for the reference's default order: scipy.signal.bessel(1,
- * cutoff / (sampling_freq / 2), btype='low', analog=0) applied with scipy.signal.filtfilt (forward and backward,
- * odd extension by padlen = 6, initial state lfilter_zi * first value).  Input as for the segmenter (fp32 on the
- * grid or int16 counts, n samples), output d_out[n] in pA as fp64 (the reference replaces Event.current by the
- * float64 result).  order != 1 and n <= 6 return PS_ERR_ARG (scipy raises ValueError for the latter). */
+/* Replaces Event.filter (DataTypes.py:258-274): scipy.signal.bessel(order, cutoff / (sampling_freq / 2), btype='low',
+ * analog=0) applied with scipy.signal.filtfilt (forward and backward, odd extension by padlen = 3 (order + 1), initial
+ * state lfilter_zi * first value).  order 1 (the reference's default): the scan / fused-halo kernels; orders 2..4: one
+ * thread per segment with a halo (seg_filter.hpp).  Input as for the segmenter (fp32 on the grid or int16 counts,
+ * n samples), output d_out[n] in pA as fp64 (the reference replaces Event.current by the float64 result).
+ * PS_ERR_ARG for order outside 1..4, n <= padlen (scipy raises ValueError), a cutoff outside (0, Nyquist), and for a
+ * filter of order >= 2 whose state needs more than 8192 samples to forget (cutoffs below ~0.2 % of Nyquist). */
 int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int32_t order,
                      double cutoff, double sampling_freq, double *d_out);
 

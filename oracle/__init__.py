@@ -48,6 +48,10 @@ def lib():
         L.so_lambda_events.restype = ctypes.c_long
         L.so_bessel1_filtfilt.argtypes = [dp, ctypes.c_long, ctypes.c_double, ctypes.c_double, dp]
         L.so_bessel1_filtfilt.restype = ctypes.c_int
+        L.so_bessel_filtfilt.argtypes = [dp, ctypes.c_long, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
+        L.so_bessel_filtfilt.restype = ctypes.c_int
+        L.so_bessel_ba.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
+        L.so_bessel_ba.restype = ctypes.c_int
         L.so_align.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp, dp, dp, ctypes.c_int,
                                dp, ctypes.POINTER(ctypes.c_uint)]
         L.so_align.restype = ctypes.c_int
@@ -141,15 +145,28 @@ def lambda_events(x, threshold=90.0, min_duration=100000, min_current=-0.5):
         cap = n
 
 
-def bessel_filtfilt(x, cutoff=2000.0, second=1.0e5):
-    """Event.filter with the reference's default order 1 (DataTypes.py:258-274): float64 in, float64 out."""
+def bessel_filtfilt(x, cutoff=2000.0, second=1.0e5, order=1):
+    """Event.filter (DataTypes.py:258-274): Bessel low-pass of `order`, filtfilt semantics; float64 in, float64 out.
+    order 1 takes the closed form (so_bessel1_filtfilt), any order 1..8 the general restatement (so_bessel_filtfilt)."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty_like(x)
-    rc = lib().so_bessel1_filtfilt(_dptr(x), x.size, float(cutoff), float(second), _dptr(out))
+    if order == 1:
+        rc = lib().so_bessel1_filtfilt(_dptr(x), x.size, float(cutoff), float(second), _dptr(out))
+    else:
+        rc = lib().so_bessel_filtfilt(_dptr(x), x.size, int(order), float(cutoff), float(second), _dptr(out))
     if rc != 0:
-        raise ValueError("The length of the input vector x must be greater than padlen, which is 6." if x.size <= 6
-                         else "cutoff must lie strictly between 0 and the Nyquist frequency")
+        pad = 3 * (int(order) + 1)
+        raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % pad if x.size <= pad
+                         else "cutoff must lie strictly between 0 and the Nyquist frequency (orders 1..8)")
     return out
+
+
+def bessel_ba(order, wn):
+    """(b, a) of scipy.signal.bessel(order, wn, 'low', analog=False, output='ba') as the oracle restates it."""
+    b = np.zeros(order + 1); a = np.zeros(order + 1)
+    if lib().so_bessel_ba(int(order), float(wn), _dptr(b), _dptr(a)):
+        raise ValueError("order must be 1..8 and 0 < wn < 1")
+    return b, a
 
 
 ALIGN_ERRORS = {1: ValueError, 2: IndexError, 3: ZeroDivisionError, 4: IndexError}

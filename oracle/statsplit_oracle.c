@@ -295,6 +295,117 @@ int so_bessel1_filtfilt(const double *x, long n, double cutoff, double second, d
     return 0;
 }
 
+/* ---- Event.filter for any order (DataTypes.py:258-274 passes `order` straight to scipy.signal.bessel) ----------
+ * scipy.signal.bessel(N, Wn, 'low', analog=False, output='ba') (norm='phase', the default), restated:
+ *   analog prototype: the poles of the phase-normalised Bessel filter of order N (table below: what
+ *     scipy.signal.besselap(N, 'phase') returns, 17 significant digits; conjugates implied), gain 1, no zeros;
+ *   lp2lp: poles * wo, gain * wo^N, wo = 2 fs tan(pi Wn / fs) with fs = 2 (pre-warping);
+ *   bilinear (fs = 2): p_z = (4 + p) / (4 - p), N zeros at -1, gain * Re(1 / prod(4 - p));
+ *   b = gain * (z + 1)^N, a = prod(z - p_z)   (real coefficients).
+ * scipy.signal.filtfilt(b, a, x): padlen = 3 (N + 1), odd extension, zi = lfilter_zi(b, a) -- the steady state of the
+ * direct-form-II-transposed delays for a unit step: solve (I - A) zi = B with A[k][0] = -a[k+1], A[k][k+1] = 1,
+ * B[k] = b[k+1] - a[k+1] b[0] --, forward lfilter from zi * ext[0], backward lfilter from zi * (last forward value).
+ * Orders 1..8.  Returns 0; -1 for n <= padlen or a cutoff outside (0, Nyquist); -3 for an order outside 1..8. */
+#include <complex.h>
+#define SO_MAXORD 8
+static const double so_bessel_poles[SO_MAXORD + 1][4][2] = {      /* [order][pair][re, im]; im == 0: a single real pole */
+    {{0, 0}},
+    {{-0.9999999999999998, 0.0}},
+    {{-0.8660254037844384, 0.4999999999999999}},
+    {{-0.9416000265332067, 0.0}, {-0.7456403858480766, 0.7113666249728351}},
+    {{-0.9047587967882447, 0.27091873300387465}, {-0.6572111716718827, 0.830161435004873}},
+    {{-0.9264420773877602, 0.0}, {-0.8515536193688396, 0.44271746394433265}, {-0.5905759446119191, 0.9072067564574549}},
+    {{-0.9093906830472273, 0.1856964396793047}, {-0.7996541858328288, 0.5621717346937318}, {-0.5385526816693109, 0.9616876881954278}},
+    {{-0.919487155649029, 0.0}, {-0.8800029341523375, 0.32166527623077396}, {-0.7527355434093214, 0.6504696305522552},
+     {-0.4966917256672317, 1.0025085084544205}},
+    {{-0.909683154665291, 0.1412437976671423}, {-0.8473250802359334, 0.42590175382729345}, {-0.7111381808485397, 0.7186517314108402},
+     {-0.4621740412532123, 1.0343886811269012}},
+};
+
+int so_bessel_ba(int order, double wn, double *b, double *a)
+{
+    if (order < 1 || order > SO_MAXORD) return -3;
+    if (!(wn > 0.0) || !(wn < 1.0)) return -1;
+    const double wo = 4.0 * tan(3.14159265358979323846 * wn / 2.0);
+    double complex p[SO_MAXORD];
+    int np = 0;
+    for (int k = 0; k < (order + 1) / 2; ++k) {
+        const double re = so_bessel_poles[order][k][0], im = so_bessel_poles[order][k][1];
+        if (im == 0.0) p[np++] = re * wo;
+        else { p[np++] = (re + I * im) * wo; p[np++] = (re - I * im) * wo; }
+    }
+    double complex den = 1.0;
+    for (int k = 0; k < order; ++k) den *= (4.0 - p[k]);
+    const double gain = pow(wo, order) * creal(1.0 / den);
+    double complex ac[SO_MAXORD + 1] = {1.0};                     /* prod (z - pz) */
+    for (int k = 0; k < order; ++k) {
+        const double complex pz = (4.0 + p[k]) / (4.0 - p[k]);
+        for (int j = k + 1; j >= 1; --j) ac[j] = ac[j] - pz * ac[j - 1];
+    }
+    double bc[SO_MAXORD + 1] = {1.0};                             /* (z + 1)^order */
+    for (int k = 0; k < order; ++k)
+        for (int j = k + 1; j >= 1; --j) bc[j] = bc[j] + bc[j - 1];
+    for (int j = 0; j <= order; ++j) { a[j] = creal(ac[j]); b[j] = gain * bc[j]; }
+    return 0;
+}
+
+int so_lfilter_zi(int order, const double *b, const double *a, double *zi)
+{
+    double M[SO_MAXORD][SO_MAXORD + 1];                           /* (I - A | B), Gaussian elimination with pivoting */
+    for (int r = 0; r < order; ++r) {
+        for (int c = 0; c < order; ++c) M[r][c] = (r == c ? 1.0 : 0.0) - ((c == 0 ? -a[r + 1] : 0.0) + (c == r + 1 ? 1.0 : 0.0));
+        M[r][order] = b[r + 1] - a[r + 1] * b[0];
+    }
+    for (int c = 0; c < order; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < order; ++r) if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (M[piv][c] == 0.0) return -1;
+        for (int k = 0; k <= order; ++k) { const double t = M[c][k]; M[c][k] = M[piv][k]; M[piv][k] = t; }
+        for (int r = 0; r < order; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c] / M[c][c];
+            for (int k = c; k <= order; ++k) M[r][k] -= f * M[c][k];
+        }
+    }
+    for (int r = 0; r < order; ++r) zi[r] = M[r][order] / M[r][r];
+    return 0;
+}
+
+static void so_lfilter(int order, const double *b, const double *a, double *v, long m, long step, const double *zi, double scale)
+{
+    double z[SO_MAXORD];
+    for (int k = 0; k < order; ++k) z[k] = zi[k] * scale;
+    double *q = step > 0 ? v : v + (m - 1);
+    for (long i = 0; i < m; ++i, q += step) {
+        const double x = *q, y = z[0] + b[0] * x;                 /* scipy's lfilter, in its operation order */
+        for (int k = 0; k < order - 1; ++k) z[k] = (z[k + 1] + x * b[k + 1]) - y * a[k + 1];
+        z[order - 1] = x * b[order] - y * a[order];
+        *q = y;
+    }
+}
+
+int so_bessel_filtfilt(const double *x, long n, int order, double cutoff, double second, double *out)
+{
+    double b[SO_MAXORD + 1], a[SO_MAXORD + 1], zi[SO_MAXORD];
+    const int rc = so_bessel_ba(order, cutoff / (second / 2.0), b, a);
+    if (rc) return rc;
+    const long pad = 3 * (order + 1);
+    if (n <= pad) return -1;
+    if (so_lfilter_zi(order, b, a, zi)) return -2;
+    const long m = n + 2 * pad;
+    double *ext = (double *)malloc(sizeof(double) * (size_t)m);
+    if (!ext) return -2;
+    for (long i = 0; i < m; ++i) {
+        const long j = i - pad;
+        ext[i] = j < 0 ? 2.0 * x[0] - x[-j] : j >= n ? 2.0 * x[n - 1] - x[2 * (n - 1) - j] : x[j];
+    }
+    so_lfilter(order, b, a, ext, m, 1, zi, ext[0]);
+    so_lfilter(order, b, a, ext, m, -1, zi, ext[m - 1]);
+    for (long j = 0; j < n; ++j) out[j] = ext[j + pad];
+    free(ext);
+    return 0;
+}
+
 /* ==== calignment.pyx:20-100  cSegmentAligner =========================
  * TEST INFRASTRUCTURE like the rest of this file.  Pinned against the compiled, unmodified
  * reference by tests/golden/make_golden_align.py -> tests/golden/golden_align.npz.

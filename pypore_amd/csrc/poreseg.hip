@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <complex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1331,19 +1332,112 @@ int ps_synth_trace(ps_ctx *ctx, void *d_out, int32_t dtype, int64_t n, uint64_t 
     return PS_OK;
 }
 
+namespace {
+// scipy.signal.bessel(N, wn, 'low', analog=False, output='ba') for N = 2..4: poles of the phase-normalised analog
+// prototype (what scipy.signal.besselap(N, 'phase') returns; conjugates implied), lp2lp with the pre-warped frequency,
+// bilinear transform with fs = 2, polynomial expansion.  Then lfilter_zi (steady state of the delays for a unit step:
+// (I - A) zi = B), the halo from the powers of the state matrix, and one launch of filt_halo_kernel.
+int filter_order_n(ps_ctx *ctx, const DevCfg &cfg, int64_t n, int order, double wn, double *d_out)
+{
+    typedef std::complex<double> cd;
+    static const double poles[FILT_MAXORD + 1][2][2] = {
+        {{0, 0}}, {{-0.9999999999999998, 0.0}},
+        {{-0.8660254037844384, 0.4999999999999999}},
+        {{-0.9416000265332067, 0.0}, {-0.7456403858480766, 0.7113666249728351}},
+        {{-0.9047587967882447, 0.27091873300387465}, {-0.6572111716718827, 0.830161435004873}}};
+    const double wo = 4.0 * std::tan(3.14159265358979323846 * wn / 2.0);
+    std::vector<cd> p;
+    for (int k = 0; k < (order + 1) / 2; ++k) {
+        const double re = poles[order][k][0], im = poles[order][k][1];
+        if (im == 0.0) p.push_back(cd(re * wo, 0.0));
+        else { p.push_back(cd(re, im) * wo); p.push_back(cd(re, -im) * wo); }
+    }
+    cd den(1.0, 0.0);
+    for (const cd &q : p) den *= (cd(4.0, 0.0) - q);
+    const double gain = std::pow(wo, order) * (cd(1.0, 0.0) / den).real();
+    std::vector<cd> ac(order + 1, cd(0.0, 0.0));
+    ac[0] = cd(1.0, 0.0);
+    for (int k = 0; k < order; ++k) {
+        const cd pz = (cd(4.0, 0.0) + p[k]) / (cd(4.0, 0.0) - p[k]);
+        for (int j = k + 1; j >= 1; --j) ac[j] = ac[j] - pz * ac[j - 1];
+    }
+    std::vector<double> bc(order + 1, 0.0);
+    bc[0] = 1.0;
+    for (int k = 0; k < order; ++k)
+        for (int j = k + 1; j >= 1; --j) bc[j] += bc[j - 1];
+    FiltN f = {};
+    f.order = order; f.pad = 3 * (order + 1);
+    for (int j = 0; j <= order; ++j) { f.a[j] = ac[j].real(); f.b[j] = gain * bc[j]; }
+    // state matrix A (z' = A z + B x) and zi = (I - A)^-1 B by Gaussian elimination with pivoting
+    double A[FILT_MAXORD][FILT_MAXORD] = {}, M[FILT_MAXORD][FILT_MAXORD + 1] = {};
+    for (int r = 0; r < order; ++r) {
+        A[r][0] = -f.a[r + 1];
+        if (r + 1 < order) A[r][r + 1] += 1.0;
+        for (int c2 = 0; c2 < order; ++c2) M[r][c2] = (r == c2 ? 1.0 : 0.0) - A[r][c2];
+        M[r][order] = f.b[r + 1] - f.a[r + 1] * f.b[0];
+    }
+    for (int c2 = 0; c2 < order; ++c2) {
+        int piv = c2;
+        for (int r = c2 + 1; r < order; ++r) if (std::fabs(M[r][c2]) > std::fabs(M[piv][c2])) piv = r;
+        if (M[piv][c2] == 0.0) return fail(ctx, PS_ERR_ARG, "filter has no steady state");
+        for (int k = 0; k <= order; ++k) std::swap(M[c2][k], M[piv][k]);
+        for (int r = 0; r < order; ++r) {
+            if (r == c2) continue;
+            const double g = M[r][c2] / M[c2][c2];
+            for (int k = c2; k <= order; ++k) M[r][k] -= g * M[c2][k];
+        }
+    }
+    for (int r = 0; r < order; ++r) f.zi[r] = M[r][order] / M[r][r];
+    // halo: smallest multiple of 64 with ||A^H||_inf <= 2^-70 (A^64 by squaring, then one factor per step)
+    auto mul = [&](const double X[FILT_MAXORD][FILT_MAXORD], const double Y[FILT_MAXORD][FILT_MAXORD], double Z[FILT_MAXORD][FILT_MAXORD]) {
+        double T[FILT_MAXORD][FILT_MAXORD] = {};
+        for (int i = 0; i < order; ++i) for (int j = 0; j < order; ++j) for (int k = 0; k < order; ++k) T[i][j] += X[i][k] * Y[k][j];
+        std::memcpy(Z, T, sizeof(T));
+    };
+    double A64[FILT_MAXORD][FILT_MAXORD], P[FILT_MAXORD][FILT_MAXORD];
+    std::memcpy(A64, A, sizeof(A));
+    for (int k = 0; k < 6; ++k) mul(A64, A64, A64);
+    std::memcpy(P, A64, sizeof(P));
+    int H = 0;
+    for (int h = 64; h <= 8192; h += 64) {
+        double nrm = 0.0;
+        for (int i = 0; i < order; ++i) { double r = 0.0; for (int j = 0; j < order; ++j) r += std::fabs(P[i][j]); nrm = std::max(nrm, r); }
+        if (nrm <= 8.47e-22) { H = h; break; }          // 2^-70
+        mul(P, A64, P);
+    }
+    if (!H) return fail(ctx, PS_ERR_ARG, "a Bessel filter of order %d this slow (cutoff / Nyquist = %g) does not run on the device", order, wn);
+    const int S = std::max(1024, 4 * H);
+    const int64_t m = n + 2LL * f.pad, nseg = (m + S - 1) / S;
+    HIP_TRY(ctx, ctx->filt_fwd.reserve(static_cast<size_t>(nseg) * static_cast<size_t>(S + H) * sizeof(double)));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    unsigned *st = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->status);
+    const dim3 grid(static_cast<unsigned>((nseg + 63) / 64));
+    if (cfg.dtype == PS_DTYPE_F32) hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_F32>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
+    else                           hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_I16>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
+}
+}  // namespace
+
 int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int32_t order,
                      double cutoff, double sampling_freq, double *d_out)
 {
     if (!ctx) return PS_ERR_ARG;
     if (!d_samples || !d_out) return fail(ctx, PS_ERR_ARG, "null pointer");
-    if (order != 1) return fail(ctx, PS_ERR_ARG, "only the first-order Bessel filter (the reference default) runs on the device");
-    if (n <= FILT_PAD) return fail(ctx, PS_ERR_ARG, "the length of the input must be greater than padlen, which is %d", FILT_PAD);
+    if (order < 1 || order > FILT_MAXORD)
+        return fail(ctx, PS_ERR_ARG, "Bessel orders 1..%d run on the device (the reference's default is 1)", FILT_MAXORD);
+    const int padlen = 3 * (order + 1);                  // scipy: 3 * max(len(a), len(b))
+    if (n <= padlen) return fail(ctx, PS_ERR_ARG, "the length of the input must be greater than padlen, which is %d", padlen);
     const double wn = cutoff / (sampling_freq / 2.0);
     if (!(wn > 0.0) || !(wn < 1.0)) return fail(ctx, PS_ERR_ARG, "cutoff must lie strictly between 0 and the Nyquist frequency");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevCfg cfg;
     int rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);
     if (rc) return rc;
+    if (order > 1) return filter_order_n(ctx, cfg, n, order, wn, d_out);
     // scipy.signal.bessel(1, wn, 'low', analog=False): one real pole, bilinear transform with pre-warping (fs = 2)
     FiltCoef f;
     const double wo = 4.0 * std::tan(3.14159265358979323846 * wn / 2.0);

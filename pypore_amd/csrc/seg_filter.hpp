@@ -320,4 +320,70 @@ __global__ __launch_bounds__(FILT_NT, PS_FILT_OCC) void filt_fused_kernel(DevCfg
     if (bad) atomicOr(status, bad);
 }
 
+// ---- orders 2..4: Event.filter(order=n) (DataTypes.py:258-274 hands `order` to scipy.signal.bessel) -------------------
+// The n-th order section in direct form II transposed carries n delays:  y = b0 x + z0,  z_k <- b_{k+1} x - a_{k+1} y
+// + z_{k+1}.  Orders other than 1 are rare in the reference's workflows (its default and every example use 1), so this
+// path is simple rather than fast: the state of a stable filter forgets (||A^H|| <= 2^-70 for the halo H the host
+// picks from the filter's own matrix), hence every THREAD filters one segment of S outputs of the extended sequence on
+// its own -- forward from H samples before the segment (from the steady state of its first value; the exact zi x_ext[0]
+// at the start of the sequence) to H samples behind it, the forward values kept in a private scratch row, then
+// backward from the end of that row (exact zi * last value at the end of the sequence).  The arithmetic per sample is
+// scipy's lfilter's, in its order; only the warm-up replaces the history.  Work: (S + 2H) + (S + H) samples per S.
+constexpr int FILT_MAXORD = 4;
+struct FiltN { int order, pad; double b[FILT_MAXORD + 1], a[FILT_MAXORD + 1], zi[FILT_MAXORD]; };
+
+template <int DT>
+__global__ __launch_bounds__(64) void filt_halo_kernel(DevCfg c, FiltN f, int64_t n, int S, int H, double *scratch, double *out,
+                                                       unsigned *status)
+{
+    const int64_t m = n + 2LL * f.pad;
+    const int64_t t = blockIdx.x * 64LL + threadIdx.x;
+    const int64_t lo = t * S;
+    if (lo >= m) return;
+    const int64_t hi = min(m, lo + S);
+    const int64_t fs = max(static_cast<int64_t>(0), lo - H), fe = min(m, hi + H);
+    unsigned bad = 0;
+    const double x0 = static_cast<double>(load_count<DT>(c, 0, bad)), xl = static_cast<double>(load_count<DT>(c, n - 1, bad));
+    auto x_ext = [&](int64_t j) {
+        const int64_t jj = j - f.pad;
+        const int64_t idx = jj < 0 ? -jj : (jj >= n ? 2 * (n - 1) - jj : jj);
+        const double v = static_cast<double>(load_count<DT>(c, idx, bad));
+        return (jj < 0 ? 2.0 * x0 - v : (jj >= n ? 2.0 * xl - v : v)) * c.q;
+    };
+    double *row = scratch + t * static_cast<int64_t>(S + H);
+    double z[FILT_MAXORD];
+    auto step = [&](double x) {                        // scipy's lfilter, in its operation order, no FMA contraction
+#pragma clang fp contract(off)
+        const double y = z[0] + f.b[0] * x;
+#pragma unroll
+        for (int k = 0; k < FILT_MAXORD - 1; ++k) {
+            const double mid = (z[k + 1] + x * f.b[k + 1]) - y * f.a[k + 1];
+            const double last = x * f.b[k + 1] - y * f.a[k + 1];
+            z[k] = k + 1 < f.order ? mid : (k + 1 == f.order ? last : 0.0);
+        }
+        z[FILT_MAXORD - 1] = f.order == FILT_MAXORD ? x * f.b[FILT_MAXORD] - y * f.a[FILT_MAXORD] : 0.0;
+        return y;
+    };
+    {
+        const double xs = x_ext(fs);
+#pragma unroll
+        for (int k = 0; k < FILT_MAXORD; ++k) z[k] = k < f.order ? f.zi[k] * xs : 0.0;
+    }
+    for (int64_t j = fs; j < fe; ++j) {
+        const double y = step(x_ext(j));
+        if (j >= lo) row[j - lo] = y;
+    }
+    {
+        const double ys = row[fe - 1 - lo];
+#pragma unroll
+        for (int k = 0; k < FILT_MAXORD; ++k) z[k] = k < f.order ? f.zi[k] * ys : 0.0;
+    }
+    for (int64_t j = fe - 1; j >= lo; --j) {
+        const double y = step(row[j - lo]);
+        const int64_t o = j - f.pad;
+        if (j < hi && o >= 0 && o < n) out[o] = y;
+    }
+    if (bad) atomicOr(status, bad);
+}
+
 }  // namespace ps

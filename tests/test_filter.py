@@ -95,7 +95,7 @@ def test_event_filter_contract_and_parse_of_filtered_event():
         np.testing.assert_array_equal(seg.current, ev.current[a:b])
         assert seg.mean == pytest.approx(float(np.mean(ev.current[a:b])), rel=1e-12)
     with pytest.raises(ValueError):
-        Event(current=x.copy(), second=f.second, file=f).filter(order=2)
+        Event(current=x.copy(), second=f.second, file=f).filter(order=5)       # orders 1..4 run on the device
 
 
 @pytest.mark.gpu
@@ -107,7 +107,9 @@ def test_filter_rejects_bad_arguments():
     with pytest.raises(ValueError):
         ctx.filter_bessel(dev[:6].contiguous(), 1.0)
     with pytest.raises(ValueError):
-        ctx.filter_bessel(dev, 1.0, order=3)
+        ctx.filter_bessel(dev, 1.0, order=5)
+    with pytest.raises(ValueError):
+        ctx.filter_bessel(dev[:12].contiguous(), 1.0, order=3)                 # padlen = 3 * (order + 1) = 12
     with pytest.raises(ValueError):
         ctx.filter_bessel(dev, 1.0, cutoff=60000., sampling_freq=1e5)
 
@@ -136,3 +138,65 @@ def test_fused_filter_equals_three_pass_scan(cutoff, n):
     assert np.max(np.abs(fused - exact)) <= 2e-14 * scale
     ref = oracle.bessel_filtfilt(k * synth.QUANTUM, cutoff, 1e5)
     assert np.max(np.abs(fused - ref)) <= 1e-10 * np.max(np.abs(ref))
+
+
+# ---- orders 2..4 -----------------------------------------------------------------------------
+MAN_O = json.load(open(os.path.join(HERE, "golden", "manifest_filter_order.json")))
+NPZ_O = np.load(os.path.join(HERE, "golden", "golden_filter_order.npz"))
+
+
+def _x_order(case):
+    g = case["gen"]
+    return synth.random_dwell_counts(g["n"], g["seed"], g["lo"], g["hi"])
+
+
+@pytest.mark.parametrize("case", MAN_O["cases"], ids=[c["name"] for c in MAN_O["cases"]])
+def test_oracle_filter_orders_match_scipy_golden(case):
+    """Design (poles of the phase-normalised prototype, bilinear transform) and filtfilt of the oracle against scipy's
+    (b, a) and output.  Tolerance per case: a direct-form filter of order n amplifies last-bit coefficient differences
+    (tests/golden/make_golden_filter_order.py records how much)."""
+    b, a = oracle.bessel_ba(case["order"], case["cutoff"] / (case["second"] / 2.))
+    np.testing.assert_allclose(b, NPZ_O[case["name"] + "/b"], rtol=1e-14)
+    np.testing.assert_allclose(a, NPZ_O[case["name"] + "/a"], rtol=0, atol=1e-13)
+    x = _x_order(case).astype(np.float64) * synth.QUANTUM
+    ref = NPZ_O[case["name"] + "/filtered"]
+    got = oracle.bessel_filtfilt(x, case["cutoff"], case["second"], case["order"])
+    assert np.max(np.abs(got - ref)) <= case["tol"] * np.max(np.abs(ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "i16"])
+@pytest.mark.parametrize("case", MAN_O["cases"], ids=[c["name"] for c in MAN_O["cases"]])
+def test_filter_kernel_orders_match_scipy_golden(case, dtype):
+    import torch
+    from pypore_amd import engine
+    ctx = engine.context(0)
+    k = _x_order(case)
+    dev = torch.from_numpy(k.astype(np.int16)).cuda() if dtype == "i16" else \
+        torch.from_numpy((k * synth.QUANTUM).astype(np.float32)).cuda()
+    got = ctx.filter_bessel(dev, synth.QUANTUM, cutoff=case["cutoff"], sampling_freq=case["second"], order=case["order"]).cpu().numpy()
+    ref = NPZ_O[case["name"] + "/filtered"]
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= case["tol"] * np.max(np.abs(ref))
+    orc = oracle.bessel_filtfilt(k * synth.QUANTUM, case["cutoff"], case["second"], case["order"])
+    assert np.max(np.abs(got - orc)) <= case["tol"] * np.max(np.abs(ref))
+
+
+@pytest.mark.gpu
+def test_filter_order3_large_trace_and_event_api():
+    """5e6 samples (hundreds of segments with halos) against the oracle; Event.filter(order=3) through the class."""
+    import torch
+    from pypore_amd import engine
+    from pypore_amd.DataTypes import Event, File
+    ctx = engine.context(0)
+    k = synth.random_dwell_counts(5_000_000, 19, 1000, 20000)
+    dev = torch.from_numpy(k.astype(np.int16)).cuda()
+    got = ctx.filter_bessel(dev, synth.QUANTUM, cutoff=2000., sampling_freq=1e5, order=3).cpu().numpy()
+    ref = oracle.bessel_filtfilt(k * synth.QUANTUM, 2000., 1e5, 3)
+    assert np.max(np.abs(got - ref)) <= 1e-9 * np.max(np.abs(ref))
+    x = synth.counts_to_pa(k[:200000], np.float64)
+    f = File(current=x, timestep=0.01)
+    ev = Event(current=x.copy(), start=0., end=2., duration=2., second=f.second, file=f)
+    ev.filter(order=3, cutoff=2000.)
+    assert ev.filtered and ev.filter_order == 3
+    assert np.max(np.abs(ev.current - oracle.bessel_filtfilt(x, 2000., 1e5, 3))) <= 1e-9 * np.max(np.abs(x))
