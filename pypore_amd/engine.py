@@ -247,34 +247,54 @@ class StreamPool(object):
     call, so plain Python threads are enough.  Every call still ends with its own stream synchronisation."""
 
     def __init__(self, device=None, streams=2):
+        import queue
+        import threading
         base = context(device)
         self.contexts = [base] + [Context(base.device) for _ in range(max(1, int(streams)) - 1)]
+        # persistent workers for contexts 1 .. T-1 (the caller's thread drives context 0): a run() costs a queue
+        # hand-over per worker, not a thread start
+        self._inbox = [queue.SimpleQueue() for _ in self.contexts]
+        self._done = queue.SimpleQueue()
+        self._threads = []
+        for t in range(1, len(self.contexts)):
+            th = threading.Thread(target=self._worker, args=(t,), daemon=True)
+            th.start()
+            self._threads.append(th)
 
     def __len__(self):
         return len(self.contexts)
 
+    def _share(self, t, n_jobs, job, results, errors):
+        try:
+            for k in range(t, n_jobs, len(self.contexts)):
+                results[k] = job(self.contexts[t], k, t)
+        except BaseException as e:                     # noqa: B036 -- re-raised on the submitting thread
+            errors.append(e)
+
+    def _worker(self, t):
+        while True:
+            task = self._inbox[t].get()
+            if task is None:
+                return
+            self._share(t, *task)
+            self._done.put(t)
+
+    def close(self):
+        for t in range(1, len(self.contexts)):
+            self._inbox[t].put(None)
+        self._threads = []
+
     def run(self, n_jobs, job):
-        """Runs job(ctx, k, t) for k = 0 .. n_jobs-1, job k on context k % T (thread t = k % T); returns the results in job order."""
-        import threading
+        """Runs job(ctx, k, t) for k = 0 .. n_jobs-1, job k on context t = k % T; returns the results in job order."""
         T = len(self.contexts)
         results = [None] * n_jobs
         errors = []
-
-        def work(t):
-            try:
-                for k in range(t, n_jobs, T):
-                    results[k] = job(self.contexts[t], k, t)
-            except BaseException as e:                 # noqa: B036 -- re-raised on the submitting thread
-                errors.append(e)
-
-        if T == 1 or n_jobs <= 1:
-            work(0)
-        else:
-            threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-            for th in threads:
-                th.start()
-            for th in threads:
-                th.join()
+        busy = [t for t in range(1, T) if t < n_jobs]
+        for t in busy:
+            self._inbox[t].put((n_jobs, job, results, errors))
+        self._share(0, n_jobs, job, results, errors)
+        for _ in busy:
+            self._done.get()
         if errors:
             raise errors[0]
         return results
