@@ -135,3 +135,29 @@ def test_config4_file_loop_two_streams(ctx, tmp_path):
             for e, (a, l) in enumerate(zip(st, ln)):
                 ref = oracle.parse(synth.counts_to_pa(counts[a:a + l], np.float64), **DEF)
                 np.testing.assert_array_equal(b[o[e]:o[e + 1]], ref)
+
+
+def test_stream_pool_batches_in_flight_give_the_same_results(ctx):
+    """engine.StreamPool: twelve batches (three different traces) over four contexts / streams / host threads -- every
+    result equals the one-at-a-time result of its trace; segment_many keeps the batch order."""
+    import torch
+    from pypore_amd import _lib, engine
+    params = _lib.split_params(**DEF)
+    traces = []
+    for seed, n in ((31, 20_000_000), (32, 5_000_000), (33, 12_345_678)):
+        d = synth.dwell_table(seed, n)
+        ends = np.cumsum(d)
+        lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+        traces.append((ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32), np.array([0, n], dtype=np.int64)))
+    alone = [ctx.segment_batch(t, off, params, synth.QUANTUM, want_stats=False)[0].cpu().numpy() for t, off in traces]
+    pool = engine.StreamPool(0, 4)
+    try:
+        batches = [traces[k % 3] for k in range(12)]
+        res = pool.segment_many(batches, params, synth.QUANTUM)
+        for k, (b, boff, st) in enumerate(res):
+            np.testing.assert_array_equal(b.cpu().numpy(), alone[k % 3])
+            assert boff[-1] == len(alone[k % 3]) and st is None
+    finally:
+        pool.close()
+    ref = oracle.parse(traces[1][0].cpu().numpy().astype(np.float64), **DEF)
+    np.testing.assert_array_equal(alone[1], ref)

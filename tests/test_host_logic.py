@@ -135,3 +135,32 @@ def test_abf_writer_reader_round_trip(tmp_path):
         fh.write(b"XXXX")
     with pytest.raises(ValueError):
         abf.read_abf(p)
+
+
+def test_stream_pool_scheduling_without_a_gpu():
+    """engine.StreamPool.run: job k runs on context k % T, results come back in job order, an exception on a worker
+    thread is re-raised on the caller's, the pool survives it, close() ends the workers.  (Fake contexts: no GPU.)"""
+    import queue
+    import threading
+    from pypore_amd import engine
+
+    class FakePool(engine.StreamPool):
+        def __init__(self, T):
+            self.contexts = ["ctx%d" % t for t in range(T)]
+            self._inbox = [queue.SimpleQueue() for _ in self.contexts]
+            self._done = queue.SimpleQueue()
+            self._threads = []
+            for t in range(1, T):
+                th = threading.Thread(target=self._worker, args=(t,), daemon=True)
+                th.start()
+                self._threads.append(th)
+
+    pool = FakePool(4)
+    seen = pool.run(10, lambda cx, k, t: (k, cx, t, threading.get_ident()))
+    assert [(k, cx, t) for k, cx, t, _ in seen] == [(k, "ctx%d" % (k % 4), k % 4) for k in range(10)]
+    assert len({ident for _, _, _, ident in seen}) == 4                   # four host threads
+    assert pool.run(2, lambda cx, k, t: k * k) == [0, 1] and pool.run(0, lambda *a: 1) == []
+    with pytest.raises(ZeroDivisionError):
+        pool.run(5, lambda cx, k, t: 1 // (k - 3))
+    assert pool.run(3, lambda cx, k, t: k) == [0, 1, 2]
+    pool.close()
