@@ -233,7 +233,10 @@ struct BsQ { int j, a1; double a2; };                     // queued block (J-8, 
 struct BsC { int j, a1; double a2; float g; int pad; };   // contender: candidate, its exact sums, screened gain
 struct BsOff { int o1, pad; double o2; };                 // sums of the window's chunks before this one (+ the window constant)
 constexpr int BS_NC = 64;                                 // contenders kept per window
-constexpr int BS_G = 5;                                   // rows per group (loads in flight)
+#ifndef PS_BS_G
+#define PS_BS_G 5
+#endif
+constexpr int BS_G = PS_BS_G;                             // rows per group (loads in flight)
 constexpr int BS_QN = 64 * BS_G + 64;                     // queued blocks; a drain is forced when a group may not fit
 constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
 static_assert(sizeof(QEnt) * SharedT<64>::QN >= sizeof(BsQ) * BS_QN + sizeof(BsC) * BS_NC + 64 * 16 + 64 * sizeof(BsOff),
