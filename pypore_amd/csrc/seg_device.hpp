@@ -1633,8 +1633,11 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(D
 // more of them (bench trace: 0.165 -> 0.146 ms; 4 waves: 0.150).  A counter in HBM for all workgroups costs more than
 // it balances: the returning atomic sits in front of the scan's loads in the wave's in-order memory counter.
 #ifndef PS_TREE_W
-#define PS_TREE_W 8           // a whole CU at two waves per SIMD
-#endif
+#define PS_TREE_W 2           // waves per workgroup.  8 (a whole CU at two waves per SIMD) is the fastest for one call at a
+#endif                        // time (0.145 ms against 0.150 with 2 and 0.170 with single-wave workgroups and fixed shares);
+                              // with several calls in flight a workgroup of 8 waves needs an entirely empty CU before it can
+                              // start under another call's spine kernel, 2-wave workgroups fill slots as they free up
+                              // (4 streams: 0.354 -> 0.347 ms per step; single-wave workgroups 0.345)
 constexpr int TREE_W = PS_TREE_W;
 template <int DT>
 __global__ __launch_bounds__(64 * TREE_W, 2) void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
