@@ -268,6 +268,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)      // set 
 // Value of lane-1 (wave_shr:1, the GFX9 whole-wave shift); lane 0 keeps its own.
 __device__ __forceinline__ int from_lane_below(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ float from_lane_below(float x) { return __int_as_float(from_lane_below(__float_as_int(x))); }
+// Value of lane+1 (wave_shl:1); lane 63 keeps its own.
+__device__ __forceinline__ int from_lane_above(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float from_lane_above(float x) { return __int_as_float(from_lane_above(__float_as_int(x))); }
 
 // One wave scans the window [ps, pe) of event `ev` (samples at c.samples[base + .]).
 //
@@ -280,7 +283,7 @@ __device__ __forceinline__ float from_lane_below(float x) { return __int_as_floa
 // Phase 1 (ambiguous windows only, ~1 %): the same sweep with the final maximum known collects the
 // contenders (screened gain within 3 delta of the decision level) and the reference's fp64 arithmetic
 // picks among them.  A whole-window fp64 scan remains for guard failures and contender overflow.
-template <int DT>
+template <int DT, bool ROWSKIP = true>
 __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                               double thresh, SharedT<64> &sh, unsigned &bad, Work &wk)
 {
@@ -364,6 +367,8 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     int result = -2;
     bool anyflag = false;
     float Tprune, Tc = INFINITY;
+    float cbound = INFINITY;                           // bound of the stretch between this lane's sample and the next lane's
+    bool hitlike = false;                              // (uniform) a sampled candidate lies above the threshold band
     {
         // pruning level from the sampled boundary candidates
         const int J = g0 + 8 * tS;
@@ -371,12 +376,35 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         const int a1 = smp.x + off.o1;
         const double a2 = ent2(smp) + off.o2;
         const BsEval e = bs_eval(a1, a2, T1 - a1, T2 - a2, max(J - ps, 1), max(pe - J, 1), cc, vfloor);
-        float bm = (static_cast<unsigned>(J - cand_lo) <= crange && e.okL && e.okR) ? e.g : -INFINITY;
+        const bool inr = static_cast<unsigned>(J - cand_lo) <= crange;
+        const float bmine = (inr && e.okL && e.okR) ? e.g : -INFINITY;
+        float bm = bmine;
 #define PS_STEP(CTRL, RM) { bm = fmaxf(bm, dpp_movf<CTRL, RM>(-INFINITY, bm)); }
         PS_DPP_STEPS(PS_STEP)
 #undef PS_STEP
         bm = __shfl(bm, 63);
         Tprune = fmaxf(thr_log2 - dthr, bm - 2.0f * dlt) - 2.0f * dlt;
+        // A window that holds a split (a sampled gain above the threshold band; rows <= 64: windows up to 32 000
+        // samples): the same monotone bound as for an 8-sample block, applied to the whole stretch [J, Jb) up to the
+        // NEXT lane's sample (left side from this sample, right side from that one; loose by about Jb - J nats, nothing
+        // next to the thousands of nats of a real step).  Nearly every stretch then lies below the pruning level, and
+        // the sweep skips the rows that lie in such stretches altogether, loads included: a candidate there is provably
+        // more than 2 delta below the winner.  Windows without such a sample (all subtree windows, half of the spine's)
+        // skip this and sweep every row: for them the bookkeeping would only cost (measured: +1.6 us per window).
+        hitlike = ROWSKIP && c.prune && rows <= 64 && bm > thr_log2 + dthr;
+        if (hitlike) {
+            const int Jb = from_lane_above(J);
+            const float bRb = from_lane_above(e.lg.y), rreb = from_lane_above(e.r.y);
+            const bool okRb = from_lane_above(static_cast<int>(e.okR)) != 0;
+            const int B = Jb - J, nla = J - ps, nrb = pe - Jb;
+            if (B <= 0) cbound = inr ? bmine == -INFINITY ? INFINITY : bmine : -INFINITY;     // (clamped lanes: the last boundary itself)
+            else {
+                const float Bf = static_cast<float>(B), nlaf = static_cast<float>(nla), nrbf = static_cast<float>(nrb);
+                const float h0 = -fmaf(nlaf, e.lg.x, (nrbf + Bf) * (bRb - Bf * LOG2E * rreb));
+                const float h1 = -fmaf(nlaf + Bf - 1.0f, e.lg.x - (Bf - 1.0f) * LOG2E * e.r.x, (nrbf + 1.0f) * (bRb - LOG2E * rreb));
+                cbound = (e.okL && okRb && nla >= 1 && nrb >= 1) ? fmaxf(h0, h1) : INFINITY;
+            }
+        }
     }
     PS_STAMP_AT(wk, 0);                                // loads, totals, wave scans, pruning level
     int ccount = 0;
@@ -396,6 +424,24 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         Top2 top = {-INFINITY, -INFINITY, -1};
         unsigned flag = 0;
         int qcount = 0;
+        // rows to sweep: bit r of `live` (row r covers boundaries 63 r .. 63 r + 63, i.e. the stretches lo .. hi of the
+        // lanes' samples; it is skipped when all of them are dead at this phase's pruning level).  Lane r works that out
+        // for row r, a ballot makes the mask.  Windows that are not hit-like sweep rows 0 .. rows-1.
+        unsigned long long live = ~0ull;
+        if (hitlike) {
+            const unsigned long long dead = __ballot(cbound < Tprune);
+            const float rr_ = 1.0f / static_cast<float>(rows);
+            const int lo = static_cast<int>((static_cast<float>(BS_STRIDE * lane) + 0.5f) * rr_);          // exact for these small integers
+            const int hi = min(63, static_cast<int>((static_cast<float>(BS_STRIDE * lane + BS_STRIDE) + 0.5f) * rr_));
+            const unsigned long long span = (hi - lo >= 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
+            live = __ballot(lane < rows && (dead & span) != span);
+        }
+        auto take_row = [&]() {                        // next live row, -1: none left (uniform)
+            if (live == 0ull) return -1;
+            const int r = __builtin_ctzll(live);
+            live &= live - 1ull;
+            return r;
+        };
         auto drain = [&]() {
             // drain: interior candidates of the queued blocks
             ps_sync<64>();
@@ -444,12 +490,12 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
             qcount = 0;
             PS_STAMP_AT(wk, 2);                        // drain
         };
-        // per-lane running values of the row sweep: boundary J, its chunk index source, nl as fp32 / fp64
-        int Jr = g0 + 8 * lane, gtr = gbl + lane;
-        float nlf = static_cast<float>(Jr - ps);
-        double nld = static_cast<double>(Jr - ps);
-        auto do_row = [&](bool first_row, const int4 &cur, const BsOff &off) {
-            const int J = Jr, nl = J - ps;
+        // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t)
+        auto do_row = [&](int r, const int4 &cur, const BsOff &off) {
+            const bool first_row = r == 0;
+            const int J = g0 + 8 * (BS_STRIDE * r + lane), nl = J - ps;
+            const float nlf = static_cast<float>(nl);
+            const double nld = static_cast<double>(nl);
             const int a1 = cur.x + off.o1;
             const double a2 = ent2(cur) + off.o2;
             // screened gain of the boundary (bs_eval, with the running nl and the right side from the totals)
@@ -496,29 +542,64 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
                 qcount += __popcll(km);
             }
             if (phase) PS_COLLECT(ge >= Tc, ge, J, a1, a2)
-            Jr += 8 * BS_STRIDE; gtr += BS_STRIDE; nlf += 8.0f * BS_STRIDE; nld += 8.0 * BS_STRIDE;
         };
         // rows in groups of BS_G, double-buffered: the next group's loads are in flight while this one is evaluated
         int4 ga[BS_G], gb[BS_G];
-#pragma unroll
-        for (int i = 0; i < BS_G; ++i) ga[i] = i == 0 ? row0 : bsw[min(i * BS_STRIDE + lane, nblk)];
         BsOff offs[BS_G];                              // the group's chunk offsets: one LDS round trip per group, not per row
-        for (int r0 = 0; r0 < rows; r0 += 2 * BS_G) {
-            if (qcount > BS_QN - 64 * BS_G) drain();
+        auto row_load = [&](int r) { return r == 0 ? row0 : bsw[min(max(r, 0) * BS_STRIDE + lane, nblk)]; };
+        auto row_off = [&](int r) { return coff[min((gbl + max(r, 0) * BS_STRIDE + lane) >> 8, nch - 1)]; };
+        if (!hitlike) {
+            // every row, five at a time in straight-line code (rows past the end are inert): the compiler interleaves the
+            // rows of a group, which is worth 20 % of a window -- no branch may stand between them
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) offs[i] = coff[min((gtr + i * BS_STRIDE) >> 8, nch - 1)];
+            for (int i = 0; i < BS_G; ++i) ga[i] = row_load(i);
+            for (int r0 = 0; r0 < rows; r0 += 2 * BS_G) {
+                if (qcount > BS_QN - 64 * BS_G) drain();
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) gb[i] = bsw[min((r0 + BS_G + i) * BS_STRIDE + lane, nblk)];
+                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(r0 + i);
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) do_row(r0 + i == 0, ga[i], offs[i]);     // (rows past the end are inert)
-            if (r0 + BS_G >= rows) break;
-            if (qcount > BS_QN - 64 * BS_G) drain();
+                for (int i = 0; i < BS_G; ++i) gb[i] = row_load(r0 + BS_G + i);
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) offs[i] = coff[min((gtr + i * BS_STRIDE) >> 8, nch - 1)];
+                for (int i = 0; i < BS_G; ++i) do_row(r0 + i, ga[i], offs[i]);
+                if (r0 + BS_G >= rows) break;
+                if (qcount > BS_QN - 64 * BS_G) drain();
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) ga[i] = bsw[min((r0 + 2 * BS_G + i) * BS_STRIDE + lane, nblk)];
+                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(r0 + BS_G + i);
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) do_row(false, gb[i], offs[i]);
+                for (int i = 0; i < BS_G; ++i) ga[i] = row_load(r0 + 2 * BS_G + i);
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) do_row(r0 + BS_G + i, gb[i], offs[i]);
+            }
+        } else {
+            // live rows only (a window that holds a split: typically 2 .. 4 of 20); an empty slot of a group loads row 0
+            // again, so that no branch stands between the loads
+            int ra[BS_G], rb[BS_G];                    // (uniform) row indices of the two groups, -1: none
+#pragma unroll
+            for (int i = 0; i < BS_G; ++i) ra[i] = take_row();
+#pragma unroll
+            for (int i = 0; i < BS_G; ++i) ga[i] = row_load(ra[i]);
+            for (;;) {
+                if (ra[0] < 0) break;
+                if (qcount > BS_QN - 64 * BS_G) drain();
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(ra[i]);
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) rb[i] = take_row();
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) gb[i] = row_load(rb[i]);
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) if (ra[i] >= 0) do_row(ra[i], ga[i], offs[i]);
+                if (rb[0] < 0) break;
+                if (qcount > BS_QN - 64 * BS_G) drain();
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(rb[i]);
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) ra[i] = take_row();
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) ga[i] = row_load(ra[i]);
+#pragma unroll
+                for (int i = 0; i < BS_G; ++i) if (rb[i] >= 0) do_row(rb[i], gb[i], offs[i]);
+            }
         }
         drain();
         if (phase == 1) break;

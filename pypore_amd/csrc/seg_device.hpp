@@ -878,7 +878,7 @@ namespace ps {
 // ---- one window scan: cparsers.pyx:157-178 ------------------------------------------------------
 // Window [ps, pe) of the event at `base`; candidates cand_lo..cand_hi (inclusive, event-local);
 // returns the first index whose gain strictly exceeds every earlier gain and `thresh`, or -1.
-template <int NT, int DT, bool VALIDATE>
+template <int NT, int DT, bool VALIDATE, bool ROWSKIP = true>
 __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                            double thresh, double *scores, SharedT<NT> &sh, unsigned &bad, Work &wk,
                            double *best_gain_out = nullptr, int pf_end = 0, int ev = 0)
@@ -893,7 +893,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     }
     if constexpr (NT == 64) {                          // single-wave workgroup: block-sum scan (seg_bs.hpp)
         if (c.bsum != nullptr && scores == nullptr && best_gain_out == nullptr)
-            return scan_window_bs<DT>(c, ev, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
+            return scan_window_bs<DT, ROWSKIP>(c, ev, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
     }
     if (n > c.lds_cap) {                               // window larger than LDS: exact path from HBM
         if (threadIdx.x == 0) wk.exact += 1;
@@ -1027,7 +1027,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 // ---- the window loop of _recursive_split: cparsers.pyx:186-201 ---------------------------------
 // Windows j < j0 are known to hold no split (they were scanned with identical bounds by the
 // parent frame, DESIGN.md "memoised left child").
-template <int NT, int DT, bool VALIDATE, bool BSONLY = false>
+template <int NT, int DT, bool VALIDATE, bool BSONLY = false, bool ROWSKIP = true>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
                           SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, int ev = 0,
                           long long stop_lim = 0x7fffffffffffffffLL, int budget = 0x7fffffff)
@@ -1050,10 +1050,10 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
             if constexpr (BSONLY) {
                 static_assert(NT == 64, "block-sum scan: one wave per window");
                 if ((threadIdx.x & 63u) == 0) { wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1; }
-                s = scan_window_bs<DT>(c, ev, base, static_cast<int>(ps), static_cast<int>(pe), static_cast<int>(ps) + c.mw,
-                                       static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
+                s = scan_window_bs<DT, ROWSKIP>(c, ev, base, static_cast<int>(ps), static_cast<int>(pe),
+                                                static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
             } else {
-                s = scan_window<NT, DT, VALIDATE>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
+                s = scan_window<NT, DT, VALIDATE, ROWSKIP>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
                                     static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
                                     c.min_gain, nullptr, sh, bad, wk, nullptr,
                                     static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim), ev);
@@ -1411,7 +1411,7 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
     };
     for (;;) {
         int kind;
-        int s = find_split<NT, DT, false, BSONLY>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
+        int s = find_split<NT, DT, false, BSONLY, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
         if (kind == KIND_NONE) {
             if (sp == 0) break;
             --sp;
