@@ -89,11 +89,13 @@ struct ps_ctx {
     uint8_t *d_is_spine = nullptr;   // optional output of the current call
     int prune = 1;
     double wide_quantum = 0;  // quantum of the last call K0 refused (counts too wide) ...
-    int wide_skip = 0;        // ... and the number of calls with that quantum that still start on the LDS-window path
+    int wide_skip = 0;        // ... and the number of calls with that quantum that still start where that call ended:
+    int wide_mode = 0;        // ... 2 = block-sum scan on the 64-bit digest, 0 = LDS-window scan
     int tree_mw = 1;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
+    int wide_bs = 1;          // 1: counts too wide for the 32-bit digest are retried on the 64-bit digest, 0: straight to the LDS-window scan
     int spec_tree = 0;        // 1: waves of the spine kernel whose chains have ended run subtree jobs speculatively (spine_spec_kernel; measured slower: the scans are issue-bound)
     int bridge_single = 1 << 30;   // anchors a single-wave bridge adds before it hands the seam to the look-ahead kernel (measured: handing over early is slower)
     int tree_tail_pct = 0;    // tree_mw_kernel: share of the job list drawn dynamically (counter in HBM) at the end
@@ -175,7 +177,7 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->mode = ctx->mode;
     c->prune = ctx->prune;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
-    c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr;
+    c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr; c->bs_wide = 0;
     c->dbg = ctx->small.as<SmallLayout>()->stamp;
     c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
@@ -398,7 +400,9 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (n_tj) {
         const unsigned g = static_cast<unsigned>(std::min<size_t>(n_tj, 0x7fffffff));
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
-        int lrc = cfg.bsum != nullptr && ctx->tree_mw
+        int lrc = cfg.bsum != nullptr && cfg.bs_wide
+                      ? (f32 ? launch_tree_mw<PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree_mw<PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr))
+                  : cfg.bsum != nullptr && ctx->tree_mw
                       ? (f32 ? launch_tree_mw<PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree_mw<PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
                   : cfg.bsum != nullptr
                       ? (f32 ? launch_tree<64, PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<64, PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
@@ -540,11 +544,14 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
 // tree jobs, items) -- no host round trip before the final synchronisation.
 // Returns RC_FALLBACK when a seam could not be bridged on the device (rare); the caller then runs
 // the host-stitch pipeline, which repairs seams one by one.
-int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
+int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
                         std::chrono::steady_clock::time_point t_begin)
 {
     DevCfg cfg = cfg_in;
+    const bool use_bs = bs_mode != 0;                  // 1: block-sum scan on the 32-bit digest, 2: on the 64-bit (wide) digest
+    const bool wide = bs_mode == 2;
+    cfg.bs_wide = wide ? 1 : 0;
     int64_t L = ctx->tile_len;
     // The tile tables depend only on the event layout and the parameters: a call that repeats the previous one's
     // (the bench loop; a file segmented with several parameter sets) reuses the tables that are still on the device.
@@ -618,7 +625,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
     }
     const size_t nj = tc.nj, jb = tc.jb, up_bytes = tc.up_bytes;
     const int64_t list_entries = tc.list_entries, total_len = tc.total_len, sample_end = tc.sample_end;
-    const bool spec = use_bs && ctx->spec_tree && nj > 0;
+    const bool spec = use_bs && !wide && ctx->spec_tree && nj > 0;
     const int64_t spec_total = spec ? tc.spec_total : 0;
     ctx->counters[2] = static_cast<int64_t>(nj);
     const int64_t max_items = list_entries + static_cast<int64_t>(nj) * BR_MAX;
@@ -689,25 +696,34 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, bool use_bs, const in
         HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int4)));
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
         HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(k0_grid + 1) * 2 * sizeof(int4)));
-        if (d_stats) {                                 // per-block min/max for the statistics kernel (4 B per block)
+        if (d_stats && !wide) {                        // per-block min/max for the statistics kernel (4 B per block; int16 pairs)
             HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int)));
             cfg.blk_mm = ctx->blk_mm.as<int>();
         }
-        if (f32) hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_F32>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
-                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end,
-                                    ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),
-                                    reinterpret_cast<unsigned *>(&sm->status));
-        else     hipLaunchKernelGGL((blocksum_kernel<PS_DTYPE_I16>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,
-                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end,
-                                    ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),
-                                    reinterpret_cast<unsigned *>(&sm->status));
+#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,                      \
+                                    ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
+                                    ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                          \
+                                    reinterpret_cast<unsigned *>(&sm->status))
+        if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
+        else      { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
+#undef PS_K0
         HIP_TRY(ctx, hipGetLastError());
         cfg.bsum = ctx->bsum.as<int4>();
         cfg.ev_info = ctx->ev_info.as<int4>();
         cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
     }
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if (nj && use_bs) {
+    if (nj && wide) {
+        // (the 64-bit digest: same kernels, compiled for it)
+        const unsigned g = static_cast<unsigned>(nj);
+        int lrc = f32 ? launch_spine<64, PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm, true);
+        if (lrc) return lrc;
+        if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        lrc = f32 ? launch_bridge<64, PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm) : launch_bridge<64, PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm);
+        if (lrc) return lrc;
+        lrc = f32 ? launch_bridge_la<PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm) : launch_bridge_la<PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm);
+        if (lrc) return lrc;
+    } else if (nj && use_bs) {
         const unsigned g = static_cast<unsigned>(nj);
         int lrc = spec ? (f32 ? launch_spine_spec<PS_DTYPE_F32>(ctx, cfg, g, sm, list_entries, tscratch_bound)
                               : launch_spine_spec<PS_DTYPE_I16>(ctx, cfg, g, sm, list_entries, tscratch_bound))
@@ -812,6 +828,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SPEC_TREE")) ctx->spec_tree = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SPEC_FLAGS")) ctx->spec_flags = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
@@ -864,6 +881,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
+    else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "spec_tree") ctx->spec_tree = value != 0;
     else if (n == "spec_flags") ctx->spec_flags = static_cast<int>(value);
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
@@ -973,19 +991,24 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
         // block-sum scan: candidates must avoid the ragged ends of a window (min_width >= 8) and a window must fit
         // the single-wave sweep (W <= 90 000); otherwise the LDS-window kernels take the call
         bool use_bs = ctx->scan_bs && mw >= 8 && W <= 90000 && ctx->mode != MODE_EXACT;
-        bool wide = false;
-        if (use_bs && ctx->wide_skip > 0 && fmt->quantum == ctx->wide_quantum) { use_bs = false; --ctx->wide_skip; wide = true; }
-        rc = device_stitch_batch(ctx, cfg, use_bs, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
-        if (wide) ctx->counters[7] = 1;              // counts too wide for the block sums: the LDS-window kernels took the call
-        if (rc == RC_WIDE) {                          // counts too wide for uint32 block sums: LDS-window scan instead
-            ctx->wide_quantum = fmt->quantum;         // (the next calls on this grid skip the attempt)
+        // Counts too wide for the 32-bit digest (K0 says so: RC_WIDE): the call is redone on the 64-bit digest, and if
+        // that refuses too (|k - m| >= 2^23) on the LDS-window kernels.  The next 16 calls on the same grid start where
+        // this one ended (counters[7]: 1 = 64-bit digest, 2 = LDS-window scan).
+        int bs_mode = use_bs ? 1 : 0, redo = 0;
+        if (use_bs && ctx->wide_skip > 0 && fmt->quantum == ctx->wide_quantum) { bs_mode = ctx->wide_mode; --ctx->wide_skip; redo = bs_mode == 2 ? 1 : 2; }
+        rc = device_stitch_batch(ctx, cfg, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+        while (rc == RC_WIDE) {
+            bs_mode = (bs_mode == 1 && ctx->wide_bs) ? 2 : 0;
+            redo = bs_mode == 2 ? 1 : 2;
+            ctx->wide_quantum = fmt->quantum;
+            ctx->wide_mode = bs_mode;
             ctx->wide_skip = 16;
             for (double &m : ctx->ms) m = 0;
             for (int64_t &c : ctx->counters) c = 0;
             HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
-            rc = device_stitch_batch(ctx, cfg, false, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
-            ctx->counters[7] = 1;
+            rc = device_stitch_batch(ctx, cfg, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
         }
+        if (redo) ctx->counters[7] = redo;
         if (rc != RC_FALLBACK) return rc;
         // a seam could not be bridged on the device: redo with the host stitch (halo tiles + repairs)
         for (double &m : ctx->ms) m = 0;

@@ -18,6 +18,17 @@ namespace ps {
 constexpr int BS_WIDE = 23000;             // |k - m| must stay below this: 8 * BS_WIDE^2 < 2^32, n * BS_WIDE < 2^31
 enum : unsigned { ST_WIDE_RANGE = 16u };
 constexpr int BS_CHUNK = 256;              // blocks per K0 workgroup = extent of one prefix chunk
+// Wide digest (DT & DT_WIDE): both moments as 64-bit integers -- (E1 lo, E1 hi, E2 lo, E2 hi) per block, the chunk
+// totals alike.  |k - m| < BSW_LIM: a block's S2 < 2^49, a chunk prefix < 2^57, a window of 90 000 samples < 2^62.5.
+// Made for events that were filtered and re-quantised on a fine grid (DataTypes.Event.parse: |count| < 2^22).
+constexpr int BSW_LIM = 1 << 23;
+template <int DT> constexpr bool bs_wide() { return (DT & DT_WIDE) != 0; }
+__device__ __forceinline__ long long i64_of(int lo, int hi) { return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo); }
+// int64 -> fp64, correctly rounded (hi * 2^32 and lo are exact, the fma rounds once); exact while |x| < 2^53
+__device__ __forceinline__ double d_of_i64(long long x)
+{
+    return fma(static_cast<double>(static_cast<int>(x >> 32)), 4294967296.0, static_cast<double>(static_cast<unsigned>(x)));
+}
 
 __device__ __forceinline__ unsigned long long u64_of(unsigned lo, unsigned hi) { return (static_cast<unsigned long long>(hi) << 32) | lo; }
 
@@ -47,6 +58,14 @@ __device__ __forceinline__ double wave_incl_scan_f64(double x)
 #undef PS_STEP
     return x;
 }
+__device__ __forceinline__ long long wave_incl_scan_i64(long long x)
+{
+#define PS_STEP(CTRL, RM) { const int lo_ = dpp_mov<CTRL, RM>(0, static_cast<int>(x)), hi_ = dpp_mov<CTRL, RM>(0, static_cast<int>(x >> 32)); \
+                            x += i64_of(lo_, hi_); }
+    PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
 __device__ __forceinline__ int wave_max_i32(int x)            // result in lane 63
 {
 #define PS_STEP(CTRL, RM) { x = max(x, dpp_mov<CTRL, RM>(static_cast<int>(0x80000000), x)); }
@@ -60,7 +79,9 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
                                                        const int64_t *ev_boff, int n_ev, int64_t n_samples, int4 *bs,
                                                        int4 *ev_info, int4 *chunk_tot, unsigned *status)
 {
+    constexpr bool WIDE = bs_wide<DT>();
     __shared__ double w2[4];
+    __shared__ long long wl1[4], wl2[4];               // (wide digest)
     __shared__ int w1[4], smax[4], symax[4];
     const long long wg0 = blockIdx.x * 256LL;
     const long long gb = wg0 + threadIdx.x;
@@ -69,6 +90,7 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
     int mabs = 0, yabs = 0;                        // max |k| over the block's samples, max |k - m|
     int s1 = 0;
     unsigned s2 = 0;
+    unsigned long long s2w = 0;                        // (wide digest: 8 * 2^46)
     // event of the workgroup's first block (uniform search)
     int e_first = 0;
     {
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
             int4 raw[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) raw[v] = reinterpret_cast<const int4 *>(p)[v];
-            if (DT == PS_DTYPE_F32) {
+            if (sdt(DT) == PS_DTYPE_F32) {
                 const f2 iq = {c.inv_q, c.inv_q};
                 const float mf = static_cast<float>(m);                    // |m| < 2^23: exact
                 const f2 mf2 = {mf, mf};
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
                     y[q] = ((q & 1) ? (w[q >> 1] >> 16) : static_cast<int>(static_cast<short>(w[q >> 1] & 0xffff))) + om;
                 PS_MM8
             }
-        } else if (DT == PS_DTYPE_I16 && cnt == 8 && base + i0 >= 1 && base + i0 + 10 <= n_samples) {
+        } else if (sdt(DT) == PS_DTYPE_I16 && cnt == 8 && base + i0 >= 1 && base + i0 + 10 <= n_samples) {
             // int16 block that is not 16-byte aligned (events cut out of a file trace start anywhere):
             // dword loads, shifted by one sample when the block starts on an odd sample
             const uintptr_t a = reinterpret_cast<uintptr_t>(p);
@@ -165,39 +187,59 @@ __global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             s1 += y[q];
-            s2 += static_cast<unsigned>(__mul24(y[q], y[q]));              // |y| < BS_WIDE < 2^23, else the call is redone
+            if constexpr (WIDE) s2w += static_cast<unsigned long long>(static_cast<long long>(y[q]) * static_cast<long long>(y[q]));
+            else s2 += static_cast<unsigned>(__mul24(y[q], y[q]));         // |y| < BS_WIDE < 2^23, else the call is redone
         }
-        if (ymax >= BS_WIDE || ymin <= -BS_WIDE) bad |= ST_WIDE_RANGE;
+        constexpr int LIM = WIDE ? BSW_LIM : BS_WIDE;
+        if (ymax >= LIM || ymin <= -LIM) bad |= ST_WIDE_RANGE;
         const int ka = m + ymin, kb = m + ymax;
         mabs = max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb);
         yabs = max(-ymin, ymax);
-        if (DT == PS_DTYPE_F32 && mabs >= 8388608) bad |= ST_OFF_GRID;     // |count| >= 2^23
-        if (c.blk_mm) c.blk_mm[gb] = (ymin & 0xffff) | (ymax << 16);      // (|y| < BS_WIDE fits int16; otherwise the call is redone)
+        if (sdt(DT) == PS_DTYPE_F32 && mabs >= 8388608) bad |= ST_OFF_GRID;     // |count| >= 2^23
+        if (!WIDE && c.blk_mm) c.blk_mm[gb] = (ymin & 0xffff) | (ymax << 16);      // (|y| < BS_WIDE fits int16; otherwise the call is redone)
         if (b == 0) ev_info[e] = make_int4(m, 0, static_cast<int>(ev_boff[e] & 0xffffffffLL), static_cast<int>(ev_boff[e] >> 32));
     }
     // exclusive prefix over the workgroup: first moments in int32 (256 * 8 * BS_WIDE < 2^31), second moments as exact
     // integers in fp64
-    const int i1 = wave_incl_scan_i32(s1);
-    const double i2 = wave_incl_scan_f64(static_cast<double>(s2));
     mabs = wave_max_i32(mabs);
     yabs = wave_max_i32(yabs);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) { w1[wave] = i1; w2[wave] = i2; smax[wave] = mabs; symax[wave] = yabs; }
-    __syncthreads();
-    int o1 = 0;
-    double o2 = 0.0;
-    for (int w = 0; w < wave; ++w) { o1 += w1[w]; o2 += w2[w]; }
-    if (gb <= nb_total) {
-        const int e1 = o1 + i1 - s1;
-        const double e2 = (o2 + i2) - static_cast<double>(s2);
-        bs[gb] = make_int4(e1, 0, __double2loint(e2), __double2hiint(e2));
+    if constexpr (WIDE) {
+        const long long i1 = wave_incl_scan_i64(static_cast<long long>(s1));
+        const long long i2 = wave_incl_scan_i64(static_cast<long long>(s2w));
+        if (lane == 63) { wl1[wave] = i1; wl2[wave] = i2; smax[wave] = mabs; symax[wave] = yabs; }
+        __syncthreads();
+        long long o1 = 0, o2 = 0;
+        for (int w = 0; w < wave; ++w) { o1 += wl1[w]; o2 += wl2[w]; }
+        if (gb <= nb_total) {
+            const long long e1 = o1 + i1 - s1, e2 = o2 + i2 - static_cast<long long>(s2w);
+            bs[gb] = make_int4(static_cast<int>(e1), static_cast<int>(e1 >> 32), static_cast<int>(e2), static_cast<int>(e2 >> 32));
+        }
+        if (threadIdx.x == 255) {
+            const long long t1 = o1 + i1, t2 = o2 + i2;
+            chunk_tot[2 * blockIdx.x] = make_int4(static_cast<int>(t1), static_cast<int>(t1 >> 32), static_cast<int>(t2), static_cast<int>(t2 >> 32));
+        }
+    } else {
+        const int i1 = wave_incl_scan_i32(s1);
+        const double i2 = wave_incl_scan_f64(static_cast<double>(s2));
+        if (lane == 63) { w1[wave] = i1; w2[wave] = i2; smax[wave] = mabs; symax[wave] = yabs; }
+        __syncthreads();
+        int o1 = 0;
+        double o2 = 0.0;
+        for (int w = 0; w < wave; ++w) { o1 += w1[w]; o2 += w2[w]; }
+        if (gb <= nb_total) {
+            const int e1 = o1 + i1 - s1;
+            const double e2 = (o2 + i2) - static_cast<double>(s2);
+            bs[gb] = make_int4(e1, 0, __double2loint(e2), __double2hiint(e2));
+        }
+        if (threadIdx.x == 255) {
+            const double t2 = o2 + i2;
+            chunk_tot[2 * blockIdx.x] = make_int4(o1 + i1, 0, __double2loint(t2), __double2hiint(t2));
+        }
     }
-    if (threadIdx.x == 255) {
-        const double t2 = o2 + i2;
-        chunk_tot[2 * blockIdx.x] = make_int4(o1 + i1, 0, __double2loint(t2), __double2hiint(t2));
+    if (threadIdx.x == 255)
         chunk_tot[2 * blockIdx.x + 1] = make_int4(max(max(smax[0], smax[1]), max(smax[2], smax[3])),
                                                   max(max(symax[0], symax[1]), max(symax[2], symax[3])), 0, 0);
-    }
     if (bad) atomicOr(status, bad);
 }
 
@@ -209,9 +251,8 @@ __device__ __forceinline__ double ent2(const int4 &v) { return __hiloint2double(
 // part (b1, b2).  D = n*S2 - S1^2 is formed in fp64 (relative error kappa_m * 2^-52 with kappa_m = n*S2/D
 // below 2^24 for |k-m| < BS_WIDE and a variance above the floor), so no re-centring and no conditioning
 // guard are needed; everything after the conversion of D is fp32 (v_pk_*), as in seg_device.hpp.
-__device__ __forceinline__ BsEval bs_eval(int a1, double a2, int b1, double b2, int nl, int nr, f2 cc, float vfloor)
+__device__ __forceinline__ BsEval bs_eval(double a1d, double a2, double b1d, double b2, int nl, int nr, f2 cc, float vfloor)
 {
-    const double a1d = static_cast<double>(a1), b1d = static_cast<double>(b1);
     const double DL = fma(static_cast<double>(nl), a2, -(a1d * a1d));
     const double DR = fma(static_cast<double>(nr), b2, -(b1d * b1d));
     const f2 D = {static_cast<float>(DL), static_cast<float>(DR)};
@@ -232,6 +273,31 @@ __device__ __forceinline__ BsEval bs_eval(int a1, double a2, int b1, double b2, 
 struct BsQ { int j, a1; double a2; };                     // queued block (J-8, J): its end J, sums of [ps, J)
 struct BsC { int j, a1; double a2; float g; int pad; };   // contender: candidate, its exact sums, screened gain
 struct BsOff { int o1, pad; double o2; };                 // sums of the window's chunks before this one (+ the window constant)
+// the same three for the wide digest (64-bit integer sums; |S1| < 2^40 shares a word with the window-relative position)
+struct BsQW { long long ja, a2; };                        // ja = S1 * 2^18 + (J - ps)
+struct BsCW { int j; float g; long long a1, a2; };
+struct BsOffW { long long o1, o2; };
+static_assert(sizeof(BsQW) == sizeof(BsQ) && sizeof(BsCW) == sizeof(BsC) && sizeof(BsOffW) == sizeof(BsOff), "LDS layout shared by both digests");
+template <bool WIDE> struct BsTypes { typedef int s1_t; typedef double s2_t; typedef BsQ Q; typedef BsC C; typedef BsOff Off; };
+template <> struct BsTypes<true> { typedef long long s1_t; typedef long long s2_t; typedef BsQW Q; typedef BsCW C; typedef BsOffW Off; };
+// moments of a digest entry; conversions to the fp64 the screen computes in
+template <bool WIDE> __device__ __forceinline__ typename BsTypes<WIDE>::s1_t bs_s1(const int4 &v)
+{
+    if constexpr (WIDE) return i64_of(v.x, v.y); else return v.x;
+}
+template <bool WIDE> __device__ __forceinline__ typename BsTypes<WIDE>::s2_t bs_s2(const int4 &v)
+{
+    if constexpr (WIDE) return i64_of(v.z, v.w); else return __hiloint2double(v.w, v.z);
+}
+__device__ __forceinline__ double bs_d(int x) { return static_cast<double>(x); }
+__device__ __forceinline__ double bs_d(double x) { return x; }
+__device__ __forceinline__ double bs_d(long long x) { return d_of_i64(x); }
+__device__ __forceinline__ void bs_q_put(BsQ &q, int J, int ps, int a1, double a2) { q.j = J; q.a1 = a1; q.a2 = a2; }
+__device__ __forceinline__ void bs_q_put(BsQW &q, int J, int ps, long long a1, long long a2) { q.ja = a1 * 262144LL + (J - ps); q.a2 = a2; }
+__device__ __forceinline__ int bs_q_j(const BsQ &q, int ps) { return q.j; }
+__device__ __forceinline__ int bs_q_j(const BsQW &q, int ps) { return ps + static_cast<int>(q.ja & 262143LL); }
+__device__ __forceinline__ int bs_q_a1(const BsQ &q) { return q.a1; }
+__device__ __forceinline__ long long bs_q_a1(const BsQW &q) { return q.ja >> 18; }
 constexpr int BS_NC = 64;                                 // contenders kept per window
 #ifndef PS_BS_G
 #define PS_BS_G 5
@@ -239,8 +305,8 @@ constexpr int BS_NC = 64;                                 // contenders kept per
 constexpr int BS_G = PS_BS_G;                             // rows per group (loads in flight)
 constexpr int BS_QN = 64 * BS_G + 64;                     // queued blocks; a drain is forced when a group may not fit
 constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
-static_assert(sizeof(QEnt) * SharedT<64>::QN >= sizeof(BsQ) * BS_QN + sizeof(BsC) * BS_NC + 64 * 16 + 64 * sizeof(BsOff),
-              "SharedT<64>::q too small");
+static_assert(sizeof(QEnt) * SharedT<64>::QN >= sizeof(BsQ) * BS_QN + sizeof(BsC) * BS_NC + 64 * 32 + 64 * sizeof(BsOff),
+              "SharedT<64>::q too small");             // (64 * 32: staged blocks of the wide digest, 8 int32 each)
 
 // Exact (reference-order, fp64) gain of one candidate from its exact integer sums about m.
 __device__ __forceinline__ double bs_exact_gain(const DevCfg &c, int m, int a1, double a2, int T1, double T2, int nl, int n,
@@ -287,6 +353,12 @@ template <int DT, bool ROWSKIP = true>
 __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                               double thresh, SharedT<64> &sh, unsigned &bad, Work &wk)
 {
+    constexpr bool WIDE = bs_wide<DT>();
+    typedef typename BsTypes<WIDE>::s1_t s1_t;         // first / second moments about m: int32 / fp64 (exact integers), or
+    typedef typename BsTypes<WIDE>::s2_t s2_t;         // both int64 with the wide digest
+    typedef typename BsTypes<WIDE>::Q BsQ_t;
+    typedef typename BsTypes<WIDE>::C BsC_t;
+    typedef typename BsTypes<WIDE>::Off BsOff_t;
     const int lane = threadIdx.x & 63;                 // (one wave; possibly one of several in its workgroup)
     const int n = pe - ps;
     const int g0 = (ps + 7) & ~7, g1 = pe & ~7;
@@ -321,33 +393,45 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     wave_incl_scan2(hs1, hs2);
     const double H1d = __shfl(hs1, 31), H2d = __shfl(hs2, 31);
     const double TL1d = __shfl(hs1, 63) - H1d, TL2d = __shfl(hs2, 63) - H2d;
-    const double cs1 = static_cast<double>(ct.x), cs2 = ent2(ct);
-    double ci1 = cs1, ci2 = cs2;
-    wave_incl_scan2(ci1, ci2);
+    const s1_t cs1 = bs_s1<WIDE>(ct);
+    const s2_t cs2 = bs_s2<WIDE>(ct);
+    s1_t cx1;                                          // sums of the chunks before this lane's
+    s2_t cx2;
+    if constexpr (WIDE) {
+        cx1 = wave_incl_scan_i64(cs1) - cs1;
+        cx2 = wave_incl_scan_i64(cs2) - cs2;
+    } else {
+        double ci1 = static_cast<double>(cs1), ci2 = cs2;
+        wave_incl_scan2(ci1, ci2);
+        cx1 = static_cast<int>(ci1 - static_cast<double>(cs1));
+        cx2 = ci2 - cs2;
+    }
     int mabs = cm.x, nymax = -cm.y;                     // max |k| and max |k-m| over the chunks touched
     wave_minmax(nymax, mabs);                          // (the min slot carries -max |k-m|)
     mabs = __shfl(mabs, 63);
     const float ymaxf = static_cast<float>(-__shfl(nymax, 63));
-    BsQ *queue = reinterpret_cast<BsQ *>(sh.q);
-    BsC *cont = reinterpret_cast<BsC *>(queue + BS_QN);
-    int4 *ybuf = reinterpret_cast<int4 *>(cont + BS_NC);               // 64 staged blocks of 8 int16 offsets
-    BsOff *coff = reinterpret_cast<BsOff *>(ybuf + 64);
+    BsQ_t *queue = reinterpret_cast<BsQ_t *>(sh.q);
+    BsC_t *cont = reinterpret_cast<BsC_t *>(queue + BS_QN);
+    int4 *ybuf = reinterpret_cast<int4 *>(cont + BS_NC);               // 64 staged blocks: 8 int16 offsets (wide digest: 8 int32)
+    BsOff_t *coff = reinterpret_cast<BsOff_t *>(ybuf + 128);
     // a(t) = E[t] + off[chunk(t)] : sums of [ps, g0 + 8t) about m  (off includes the head and -E[0])
-    const int K1 = static_cast<int>(H1d) - e0.x;
-    const double K2 = H2d - ent2(e0);
+    // (head and tail: at most 7 samples each, their sums are small exact integers in fp64)
+    const s1_t K1 = static_cast<s1_t>(H1d) - bs_s1<WIDE>(e0);
+    const s2_t K2 = static_cast<s2_t>(H2d) - bs_s2<WIDE>(e0);
     ps_sync<64>();                                  // previous user of sh.q (this wave) is done
     {
-        BsOff o;
-        o.o1 = static_cast<int>(ci1 - cs1) + K1; o.pad = 0; o.o2 = (ci2 - cs2) + K2;
+        BsOff_t o;
+        if constexpr (!WIDE) o.pad = 0;
+        o.o1 = cx1 + K1; o.o2 = cx2 + K2;
         coff[lane] = o;
     }
     ps_sync<64>();
-    const BsOff oN = coff[nch - 1];
-    const int T1 = eN.x + oN.o1 + static_cast<int>(TL1d);
-    const double T2 = ent2(eN) + oN.o2 + TL2d;                        // window totals about m
-    const double T1d = static_cast<double>(T1);
+    const BsOff_t oN = coff[nch - 1];
+    const s1_t T1 = bs_s1<WIDE>(eN) + oN.o1 + static_cast<s1_t>(TL1d);
+    const s2_t T2 = bs_s2<WIDE>(eN) + oN.o2 + static_cast<s2_t>(TL2d);     // window totals about m
+    const double T1d = bs_d(T1), T2d = bs_d(T2);
     const double dn = static_cast<double>(n);
-    const double Dtot = dn * T2 - T1d * T1d;
+    const double Dtot = dn * T2d - T1d * T1d;
     if (!(Dtot > 0.0)) {
         if (lane == 0) wk.exact += 1;
         return scan_exact<64, DT>(c, nullptr, base + ps, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);
@@ -361,7 +445,8 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     const float nf = static_cast<float>(n);
     const float LOG2E = 1.4426950408889634f;
     // variance floor: the reference's own fp64 rounding (mabs^2 * 2^-52 * n) and the fp64 D above (kappa_m <= 2^26)
-    const float vfloor = fmaxf(static_cast<float>(mabs) * static_cast<float>(mabs) * 1.0e-9f, ymaxf * ymaxf * 1.5e-8f);
+    // (wide digest: S2 is rounded to fp64 once, kappa_m <= 2^22 keeps D to 2^-30)
+    const float vfloor = fmaxf(static_cast<float>(mabs) * static_cast<float>(mabs) * 1.0e-9f, ymaxf * ymaxf * (WIDE ? 2.4e-7f : 1.5e-8f));
     const unsigned crange = static_cast<unsigned>(cand_hi - cand_lo);
 
     int result = -2;
@@ -372,10 +457,11 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     {
         // pruning level from the sampled boundary candidates
         const int J = g0 + 8 * tS;
-        const BsOff off = coff[(gbl + tS) >> 8];
-        const int a1 = smp.x + off.o1;
-        const double a2 = ent2(smp) + off.o2;
-        const BsEval e = bs_eval(a1, a2, T1 - a1, T2 - a2, max(J - ps, 1), max(pe - J, 1), cc, vfloor);
+        const BsOff_t off = coff[(gbl + tS) >> 8];
+        const s1_t a1 = bs_s1<WIDE>(smp) + off.o1;
+        const s2_t a2 = bs_s2<WIDE>(smp) + off.o2;
+        const BsEval e = bs_eval(bs_d(a1), bs_d(a2), bs_d(static_cast<s1_t>(T1 - a1)), bs_d(static_cast<s2_t>(T2 - a2)),
+                                 max(J - ps, 1), max(pe - J, 1), cc, vfloor);
         const bool inr = static_cast<unsigned>(J - cand_lo) <= crange;
         const float bmine = (inr && e.okL && e.okR) ? e.g : -INFINITY;
         float bm = bmine;
@@ -415,7 +501,9 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         if (cm_) {                                                                                            \
             const int cs_ = ccount + lanes_below(cm_);                                                        \
             if (cp_ && cs_ < BS_NC) {                                                                         \
-                BsC e_; e_.j = (JJ); e_.a1 = (A1); e_.a2 = (A2); e_.g = (G); e_.pad = 0; cont[cs_] = e_;      \
+                BsC_t e_; e_.j = (JJ); e_.a1 = (A1); e_.a2 = (A2); e_.g = (G);                                \
+                if constexpr (!WIDE) e_.pad = 0;                                                              \
+                cont[cs_] = e_;                                                                               \
             }                                                                                                 \
             ccount += __popcll(cm_);                                                                          \
         }                                                                                                     \
@@ -450,14 +538,19 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
                 // (a) one queued block per lane: its 8 samples, as int16 offsets from m, go to LDS
                 const int nb = min(64, qcount - r);
                 if (lane < nb) {
-                    const int64_t gq = base + queue[r + lane].j - 8;
+                    const int64_t gq = base + bs_q_j(queue[r + lane], ps) - 8;
                     int y[8];
 #pragma unroll
                     for (int w = 0; w < 8; ++w) y[w] = load_count<DT>(c, gq + w, bad) - m;
-                    int4 pk;
-                    pk.x = (y[0] & 0xffff) | (y[1] << 16); pk.y = (y[2] & 0xffff) | (y[3] << 16);
-                    pk.z = (y[4] & 0xffff) | (y[5] << 16); pk.w = (y[6] & 0xffff) | (y[7] << 16);
-                    ybuf[lane] = pk;
+                    if constexpr (WIDE) {
+                        ybuf[2 * lane] = make_int4(y[0], y[1], y[2], y[3]);
+                        ybuf[2 * lane + 1] = make_int4(y[4], y[5], y[6], y[7]);
+                    } else {
+                        int4 pk;
+                        pk.x = (y[0] & 0xffff) | (y[1] << 16); pk.y = (y[2] & 0xffff) | (y[3] << 16);
+                        pk.z = (y[4] & 0xffff) | (y[5] << 16); pk.w = (y[6] & 0xffff) | (y[7] << 16);
+                        ybuf[lane] = pk;
+                    }
                 }
                 ps_sync<64>();
                 // (b) one (block, offset) pair per lane: candidate J - u, u = 1..7 (the block's last u samples removed)
@@ -465,19 +558,31 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
                     const int idx = r0 + lane;
                     const bool valid = idx < nb * 7;
                     const int eidx = valid ? idx / 7 : 0, u = idx - (idx / 7) * 7 + 1;
-                    const BsQ q = queue[r + eidx];
-                    const int4 pk = ybuf[eidx];
-                    const int J = q.j - u;
-                    const int w4[4] = {pk.x, pk.y, pk.z, pk.w};
-                    int x1 = q.a1;
-                    unsigned sq = 0;                        // 7 * BS_WIDE^2 < 2^32
+                    const BsQ_t q = queue[r + eidx];
+                    const int J = bs_q_j(q, ps) - u;
+                    s1_t x1 = bs_q_a1(q);
+                    s2_t x2;
+                    if constexpr (WIDE) {
+                        const int4 pa = ybuf[2 * eidx], pb = ybuf[2 * eidx + 1];
+                        const int yy[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+                        long long sq = 0;                       // 7 * 2^46
 #pragma unroll
-                    for (int w = 1; w < 8; ++w) {
-                        const int y = (w & 1) ? (w4[w >> 1] >> 16) : static_cast<int>(static_cast<short>(w4[w >> 1] & 0xffff));
-                        if (8 - w <= u) { x1 -= y; sq += static_cast<unsigned>(y * y); }
+                        for (int w = 1; w < 8; ++w)
+                            if (8 - w <= u) { x1 -= yy[w]; sq += static_cast<long long>(yy[w]) * static_cast<long long>(yy[w]); }
+                        x2 = q.a2 - sq;
+                    } else {
+                        const int4 pk = ybuf[eidx];
+                        const int w4[4] = {pk.x, pk.y, pk.z, pk.w};
+                        unsigned sq = 0;                        // 7 * BS_WIDE^2 < 2^32
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) {
+                            const int y = (w & 1) ? (w4[w >> 1] >> 16) : static_cast<int>(static_cast<short>(w4[w >> 1] & 0xffff));
+                            if (8 - w <= u) { x1 -= y; sq += static_cast<unsigned>(y * y); }
+                        }
+                        x2 = q.a2 - static_cast<double>(sq);
                     }
-                    const double x2 = q.a2 - static_cast<double>(sq);
-                    const BsEval o = bs_eval(x1, x2, T1 - x1, T2 - x2, J - ps, pe - J, cc, vfloor);   // 1 <= J - ps < n here
+                    const BsEval o = bs_eval(bs_d(x1), bs_d(x2), bs_d(static_cast<s1_t>(T1 - x1)), bs_d(static_cast<s2_t>(T2 - x2)),
+                                             J - ps, pe - J, cc, vfloor);                             // 1 <= J - ps < n here
                     const bool inr = valid && static_cast<unsigned>(J - cand_lo) <= crange;
                     const bool ok = o.okL && o.okR;
                     const float gq = (inr && ok) ? o.g : -INFINITY;
@@ -491,17 +596,20 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
             PS_STAMP_AT(wk, 2);                        // drain
         };
         // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t)
-        auto do_row = [&](int r, const int4 &cur, const BsOff &off) {
+        auto do_row = [&](int r, const int4 &cur, const BsOff_t &off) {
             const bool first_row = r == 0;
             const int J = g0 + 8 * (BS_STRIDE * r + lane), nl = J - ps;
             const float nlf = static_cast<float>(nl);
             const double nld = static_cast<double>(nl);
-            const int a1 = cur.x + off.o1;
-            const double a2 = ent2(cur) + off.o2;
+            const s1_t a1 = bs_s1<WIDE>(cur) + off.o1;
+            const s2_t a2 = bs_s2<WIDE>(cur) + off.o2;
             // screened gain of the boundary (bs_eval, with the running nl and the right side from the totals)
-            const double a1d = static_cast<double>(a1), b1d = T1d - a1d;
-            const double DL = fma(nld, a2, -(a1d * a1d));
-            const double DR = fma(dn - nld, T2 - a2, -(b1d * b1d));
+            const double a1d = bs_d(a1), b1d = T1d - a1d;                  // (exact: |S1| < 2^53)
+            double a2d, b2d;
+            if constexpr (WIDE) { a2d = d_of_i64(a2); b2d = d_of_i64(T2 - a2); }
+            else { a2d = a2; b2d = T2 - a2; }
+            const double DL = fma(nld, a2d, -(a1d * a1d));
+            const double DR = fma(dn - nld, b2d, -(b1d * b1d));
             const float nrf = nf - nlf;
             const f2 D = {static_cast<float>(DL), static_cast<float>(DR)};
             const f2 nv = {nlf, nrf};
@@ -535,8 +643,8 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
             const unsigned long long km = __ballot(keep);
             if (km) {
                 if (keep) {
-                    BsQ q;
-                    q.j = J; q.a1 = a1; q.a2 = a2;
+                    BsQ_t q;
+                    bs_q_put(q, J, ps, a1, a2);
                     queue[qcount + lanes_below(km)] = q;
                 }
                 qcount += __popcll(km);
@@ -545,7 +653,7 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
         };
         // rows in groups of BS_G, double-buffered: the next group's loads are in flight while this one is evaluated
         int4 ga[BS_G], gb[BS_G];
-        BsOff offs[BS_G];                              // the group's chunk offsets: one LDS round trip per group, not per row
+        BsOff_t offs[BS_G];                            // the group's chunk offsets: one LDS round trip per group, not per row
         auto row_load = [&](int r) { return r == 0 ? row0 : bsw[min(max(r, 0) * BS_STRIDE + lane, nblk)]; };
         auto row_off = [&](int r) { return coff[min((gbl + max(r, 0) * BS_STRIDE + lane) >> 8, nch - 1)]; };
         if (!hitlike) {
@@ -629,17 +737,29 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
 #undef PS_COLLECT
     // The contenders are decided from UNCENTRED sums (sum k, sum k^2 as the reference forms them): exact only while
     // n * max|k|^2 < 2^53.  Beyond that (a large DC offset on a fine grid) the window takes the whole-window fp64 scan.
-    const bool sums_exact = static_cast<double>(n) * static_cast<double>(mabs) * static_cast<double>(mabs) < 9007199254740992.0;
+    // Wide digest: the data are a re-quantised float64 current, which the reference's own fp64 sums do not represent
+    // exactly either; the contenders are decided in the same fp64 formulas from the exact 64-bit sums ABOUT m (each
+    // rounded to fp64 once: closer to the true value than any order of summation).
+    const bool sums_exact = WIDE || static_cast<double>(n) * static_cast<double>(mabs) * static_cast<double>(mabs) < 9007199254740992.0;
     if (result == -2 && !anyflag && ccount <= BS_NC && sums_exact) {
         ps_sync<64>();                              // contender stores visible to the other lanes
-        const double var_summed = static_cast<double>(n) *
+        double var_summed;
+        if constexpr (WIDE) var_summed = static_cast<double>(n) * log(ref_var(T1d, T2d, n, c.q, c.q2));
+        else var_summed = static_cast<double>(n) *
             log(ref_var(T1d + dn * static_cast<double>(m),
-                        T2 + 2.0 * static_cast<double>(m) * T1d + dn * static_cast<double>(m) * static_cast<double>(m), n, c.q, c.q2));
+                        T2d + 2.0 * static_cast<double>(m) * T1d + dn * static_cast<double>(m) * static_cast<double>(m), n, c.q, c.q2));
         double eg = thresh;
         int ei = -1;
         if (lane < ccount) {
-            const BsC e = cont[lane];
-            const double gx = bs_exact_gain(c, m, e.a1, e.a2, T1, T2, e.j - ps, n, var_summed);
+            const BsC_t e = cont[lane];
+            double gx;
+            if constexpr (WIDE) {
+                const int nl = e.j - ps;
+                gx = ref_gain(var_summed, nl, ref_var(d_of_i64(e.a1), d_of_i64(e.a2), nl, c.q, c.q2),
+                              n - nl, ref_var(d_of_i64(T1 - e.a1), d_of_i64(T2 - e.a2), n - nl, c.q, c.q2));
+            } else {
+                gx = bs_exact_gain(c, m, e.a1, e.a2, T1, T2, e.j - ps, n, var_summed);
+            }
             if (gx > eg) { eg = gx; ei = e.j; }
         }
 #pragma unroll

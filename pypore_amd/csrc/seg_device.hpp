@@ -56,6 +56,7 @@ struct DevCfg {
     const int4 *ev_info;    // per event: (m, -, block offset lo, block offset hi)
     const int4 *chunk_tot;  // per 256 blocks (K0 workgroup): (S1, -, S2 fp64), (max |k|, max |k-m|, -, -)
     int *blk_mm;            // per block: min / max of k-m as two int16 (written by K0 when statistics are wanted) or nullptr
+    int bs_wide;            // (host side) the digest is the 64-bit one: kernels compiled for DT | DT_WIDE
     unsigned long long *dbg;  // diagnostics scratch (12 words) or nullptr
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
@@ -91,7 +92,7 @@ struct QEnt { int j, jend, p1, r1; unsigned p2, r2; int cL, cR; };
 template <int NT> struct SharedT {
     static constexpr int NWV = NT / 64;
     static constexpr int OB = NT == 64 ? BR_MAX : OBUF;      // buffered outputs (a bridge buffers its whole chain)
-    static constexpr int QN = NT == 64 ? 304 : QMAX;         // queued blocks
+    static constexpr int QN = NT == 64 ? 336 : QMAX;         // queued blocks (NT == 64: the block-sum scan's LDS, seg_bs.hpp)
     static constexpr int LN = NT == 64 ? 128 : LST_MAX;      // cached downstream anchors
     static constexpr int SN = NT == 64 ? 64 : LDS_STACK;     // DFS stack entries before spilling
     double wsum1[NWV], wsum2[NWV];
@@ -135,13 +136,18 @@ struct Work {
 #endif
 
 // ---- sample access --------------------------------------------------------------------------
+// DT of the kernel templates: bit 0 = sample type (PS_DTYPE_F32 / PS_DTYPE_I16), bit 1 = wide K0 digest (seg_bs.hpp:
+// 64-bit integer block sums for counts up to 2^23 from the event's first sample; block-sum scan kernels only)
+constexpr int DT_WIDE = 2;
+constexpr int sdt(int DT) { return DT & 1; }
 template <int DT> struct Raw { typedef float type; };
 template <> struct Raw<PS_DTYPE_I16> { typedef int16_t type; };
+template <> struct Raw<PS_DTYPE_I16 | DT_WIDE> { typedef int16_t type; };
 
 template <int DT>
 __device__ __forceinline__ int to_count(const DevCfg &c, typename Raw<DT>::type v, unsigned &bad)
 {
-    if (DT == PS_DTYPE_F32) {
+    if (sdt(DT) == PS_DTYPE_F32) {
         const float k = static_cast<float>(v) * c.inv_q;
         const int ki = __float2int_rn(k);
         if (static_cast<float>(ki) != k || !(fabsf(k) < 8388608.f)) bad |= ST_OFF_GRID;
@@ -153,7 +159,7 @@ __device__ __forceinline__ int to_count(const DevCfg &c, typename Raw<DT>::type 
 template <int DT>
 __device__ __forceinline__ int load_count(const DevCfg &c, int64_t gi, unsigned &bad)
 {
-    if (DT == PS_DTYPE_F32) {
+    if (sdt(DT) == PS_DTYPE_F32) {
         float x = static_cast<const float *>(c.samples)[gi];
         float k = x * c.inv_q;
         int ki = __float2int_rn(k);
@@ -930,7 +936,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
             const int v = v0 + u * NT;
             if (v < nv) {
                 int k[EPV];
-                if (DT == PS_DTYPE_F32) {
+                if (sdt(DT) == PS_DTYPE_F32) {
                     const float f[4] = {__int_as_float(raw[u].x), __int_as_float(raw[u].y), __int_as_float(raw[u].z),
                                         __int_as_float(raw[u].w)};
 #pragma unroll
@@ -952,14 +958,14 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
                         kmin = min(kmin, min(k[e], k[e + 1]));     // v_min3 / v_max3
                         kmax = max(kmax, max(k[e], k[e + 1]));
                     }
-                    if (VALIDATE && DT == PS_DTYPE_F32) fracbits |= (k_frac[0] | k_frac[1]) | (k_frac[2] | k_frac[3]);
+                    if (VALIDATE && sdt(DT) == PS_DTYPE_F32) fracbits |= (k_frac[0] | k_frac[1]) | (k_frac[2] | k_frac[3]);
                 } else {                                      // first / last vector: mask the elements outside
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) {
                         const bool in = v * EPV + e >= off && v * EPV + e < off + n;
                         kmin = min(kmin, in ? k[e] : 0x7fffffff);
                         kmax = max(kmax, in ? k[e] : static_cast<int>(0x80000000));
-                        if (VALIDATE && DT == PS_DTYPE_F32) fracbits |= in ? k_frac[e & 3] : 0u;
+                        if (VALIDATE && sdt(DT) == PS_DTYPE_F32) fracbits |= in ? k_frac[e & 3] : 0u;
                     }
                 }
 #pragma unroll
@@ -988,7 +994,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     kmin = sh.wmin[0]; kmax = sh.wmax[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) { kmin = min(kmin, sh.wmin[w]); kmax = max(kmax, sh.wmax[w]); }
-    if (DT == PS_DTYPE_F32 && (kmin <= -8388608 || kmax >= 8388608)) bad |= ST_OFF_GRID;   // |count| >= 2^23
+    if (sdt(DT) == PS_DTYPE_F32 && (kmin <= -8388608 || kmax >= 8388608)) bad |= ST_OFF_GRID;   // |count| >= 2^23
     if (kmin < -32768 || kmax > 32767) {               // counts do not fit the int16 LDS image: screen / exact path from HBM
         int wsplit = -1;
         const bool try_screen = c.mode != MODE_EXACT && scores == nullptr && best_gain_out == nullptr;
@@ -1411,6 +1417,8 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
     };
     for (;;) {
         int kind;
+        // (no row skipping in subtree windows: they rarely hold a split, the extra registers cost 2-3 %; filtered events on
+        //  the 64-bit digest, where they mostly do, neither gain nor lose -- measured)
         int s = find_split<NT, DT, false, BSONLY, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
         if (kind == KIND_NONE) {
             if (sp == 0) break;
@@ -1996,7 +2004,7 @@ __global__ __launch_bounds__(DET_NT) void edge_scan_kernel(DevCfg c, int64_t n, 
             int4 raw[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) raw[v] = reinterpret_cast<const int4 *>(p)[v];
-            if (DT == PS_DTYPE_F32) {
+            if (sdt(DT) == PS_DTYPE_F32) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const float f[4] = {__int_as_float(raw[v].x), __int_as_float(raw[v].y), __int_as_float(raw[v].z), __int_as_float(raw[v].w)};

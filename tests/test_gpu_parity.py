@@ -291,6 +291,82 @@ def test_wide_range_counts_fall_back_from_block_sums(ctx):
     np.testing.assert_array_equal(_bounds(segs), ref)
 
 
+def _wide_digest_trace(n, seed):
+    """Steps whose levels lie tens of thousands of counts apart on a grid 64 times finer than the ADC's: |k - m| runs to
+    ~2^21, far beyond the 32-bit digest (23 000), inside the 64-bit one (2^23).  Exact in fp32 (|k| < 2^23)."""
+    k = synth.random_dwell_counts(n, seed, 800, 12000).astype(np.int64) * 64
+    k += np.random.default_rng(seed).integers(-31, 32, n)                    # use the fine grid's low bits too
+    assert 23000 < np.abs(k - k[0]).max() < 2 ** 23 and np.abs(k).max() < 2 ** 23
+    return k
+
+
+@pytest.mark.parametrize("tile", [0, 60000])
+def test_wide_digest_takes_counts_beyond_the_32bit_block_sums(tile, ctx):
+    """K0 refuses such a trace on the 32-bit digest (ST_WIDE_RANGE) and the call is redone with the block-sum scan on the
+    64-bit digest (timings: wide_redo 1) instead of the LDS-window kernels (wide_redo 2, option wide_bs = 0): same
+    boundaries as the oracle on the same float64 values each way, also in verify mode, whole trace and tiled."""
+    import torch
+    from pypore_amd import _lib
+    n = 1_200_000
+    k = _wide_digest_trace(n, 5)
+    q = synth.QUANTUM / 64
+    x = k.astype(np.float64) * q
+    kw = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    ref = oracle.parse(x, **kw)
+    assert len(ref) > 100
+    t = torch.from_numpy(x.astype(np.float32)).cuda()
+    off = np.array([0, n], dtype=np.int64)
+    try:
+        ctx.set_tiling(tile, 0)
+        for wide_bs, mode, want in ((1, 0, 1), (1, 2, 1), (0, 0, 2)):
+            ctx.set_option("wide_bs", wide_bs)
+            ctx.set_option("mode", mode)
+            for _ in range(2):                          # the second call starts on the route the first one ended on
+                b, _, _ = ctx.segment_batch(t, off, _lib.split_params(**kw), q, want_stats=False)
+                np.testing.assert_array_equal(b.cpu().numpy(), ref)
+                assert ctx.timings()["wide_redo"] == want
+    finally:
+        ctx.set_option("wide_bs", 1)
+        ctx.set_option("mode", 0)
+        ctx.set_tiling(0, 0)
+
+
+def test_wide_digest_batch_of_events_with_statistics(ctx):
+    """Several events of different length in one call on the 64-bit digest (int16 input whose levels span more than
+    23 000 counts, and fp32 input): boundaries and per-segment statistics equal the oracle's."""
+    import torch
+    from pypore_amd import _lib
+    rng = np.random.default_rng(12)
+    lens = [50000, 1234, 180001, 99, 70000]
+    kw = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    ks = []
+    for i, ln in enumerate(lens):
+        k = synth.random_dwell_counts(ln, 40 + i, 400, 6000).astype(np.int64)
+        k = (k - 1500) * 58                                           # int16 range, steps up to ~27 000 counts
+        ks.append(np.clip(k, -32768, 32767))
+    allk = np.concatenate(ks)
+    assert max(np.abs(k - k[0]).max() for k in ks) > 24000 and np.abs(allk).max() < 32767
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    q = synth.QUANTUM
+    for dtype in (np.int16, np.float32):
+        t = torch.from_numpy(allk.astype(dtype) if dtype == np.int16 else (allk * q).astype(np.float32)).cuda()
+        b, boff, stats = ctx.segment_batch(t, off, _lib.split_params(**kw), q, want_stats=True)
+        assert ctx.timings()["wide_redo"] == 1
+        b = b.cpu().numpy(); st = stats.cpu().numpy() if hasattr(stats, "cpu") else np.asarray(stats)
+        si = 0
+        for e, ln in enumerate(lens):
+            x = ks[e].astype(np.float64) * q
+            ref = oracle.parse(x, **kw)
+            np.testing.assert_array_equal(b[boff[e]:boff[e + 1]], ref)
+            edges = np.concatenate(([0], ref, [ln])).astype(int)
+            for a, z in zip(edges[:-1], edges[1:]):
+                seg = x[a:z]
+                if len(seg):
+                    np.testing.assert_allclose(st[si][0], seg.mean(), rtol=1e-9, atol=1e-9)
+                    np.testing.assert_allclose(st[si][1], seg.std(), rtol=1e-7, atol=1e-9)
+                si += 1
+
+
 @pytest.mark.parametrize("scan_bs", [0, 1])
 def test_both_scan_implementations_on_goldens(scan_bs, ctx):
     """The LDS-window scan and the block-sum scan give the same boundaries (subset of the goldens)."""
