@@ -4,8 +4,9 @@ Call contract kept from the reference (PyPore/DataTypes.py; SURVEY.md 8 a11, f-3
   File(filename) | File(current=, timestep=)   .second = 1000 / timestep, .events, .parse(parser)        (:567-602)
   Event(current, start, end, duration, second, file)   .filter(order, cutoff), .parse(parser), .segments   (:239-333)
   to_dict / to_json / from_json / to_meta on both, MetaEvent, Event.from_segments                         (:480-545, :683-796)
-and the JSON schema of README.md:346-391 (tests/golden/readme_file.json).  Plotting, HMM merging, MySQL and
-Experiment are out of scope.
+  Experiment(filenames).parse(event_detector, segmenter, filter_params), .files / .events / .segments; Sample   (:938-1049)
+and the JSON schema of README.md:346-391 (tests/golden/readme_file.json).  Plotting, HMM merging and MySQL are out of
+scope.
 
 Built here around three pieces: `encode()` turns any tree of records into JSON-able dicts (one recursive walk
 instead of per-class loops), `_rebuild_event()` is the inverse for one event, and a File read from an .abf keeps
@@ -95,23 +96,29 @@ class Event(Segment):
             segment.scale(rate)
         self.state_parser = parser
 
-    def _parse_filtered(self, parser):
+    def _on_fine_grid(self):
         """A filtered current is float64 off every ADC grid, and the device segmenter works on exact integer sums.
         The current is centred on its mean (the gains are shift invariant) and rounded to the finest power-of-two grid
         that keeps every count below 2**22 (2**-18 pA for a 100 pA range): on the golden vectors recorded from the
         reference that reproduces every boundary the reference finds on the unrounded float64 current
         (tests/test_filter.py); coarser grids do not -- a heavily smoothed current has almost no variance left.
-        Segments keep views of the unrounded current and take their statistics from those views."""
+        Returns (rounded current, grid step)."""
         cur = np.asarray(self.current, dtype=np.float64)
         centre = float(np.mean(cur)) if cur.size else 0.0
         span = float(np.max(np.abs(cur - centre))) if cur.size else 0.0
         step = 2.0 ** (int(np.ceil(np.log2(span * 1.01))) - 22) if span > 0 else 1.0
         centre = np.rint(centre / step) * step
-        segments = parser.parse(np.rint((cur - centre) / step) * step)
+        return np.rint((cur - centre) / step) * step, step
+
+    def _adopt_filtered(self, segments):
+        """Segments found on the rounded current keep views of the unrounded one and take their statistics from those."""
         for segment in segments:
             segment.current = self.current[int(segment.start):int(segment.end)]
             segment.__dict__.pop('_gpu_stats', None)
         return segments
+
+    def _parse_filtered(self, parser):
+        return self._adopt_filtered(parser.parse(self._on_fine_grid()[0]))
 
     # ---- persistence ----------------------------------------------------------------------------------------
     def to_dict(self):
@@ -192,13 +199,32 @@ class File(Segment):
                        for seg in parser.parse(self.current)]
         self.event_parser = parser
 
-    def parse_events(self, parser=None):
-        """Segments every event of the file in ONE device call (the inner loop of Experiment.parse,
-        DataTypes.py:978-984, without the optional filter)."""
+    def parse_events(self, parser=None, filter_params=None):
+        """The inner loop of Experiment.parse (DataTypes.py:975-984) for this file: every event is filtered when
+        `filter_params` = (order, cutoff) is given, then all events are segmented in as few device calls as their
+        representations allow -- one for unfiltered events, one per grid step for filtered ones (events of one file span
+        similar ranges and mostly share a step).  Same result as `event.filter(...); event.parse(parser)` per event."""
         if parser is None:
             parser = SpeedyStatSplit(prior_segments_per_second=10)
-        currents = [ev.current for ev in self.events]
-        results = parser.parse_batch(currents) if hasattr(parser, "parse_batch") else [parser.parse(c) for c in currents]
+        if filter_params is not None:
+            for ev in self.events:
+                ev.filter(*filter_params)
+        batched = hasattr(parser, "parse_batch")
+        results = [None] * len(self.events)
+        plain_idx = [i for i, ev in enumerate(self.events) if not ev.__dict__.get("filtered")]
+        currents = [self.events[i].current for i in plain_idx]
+        for i, segs in zip(plain_idx, parser.parse_batch(currents) if batched else [parser.parse(c) for c in currents]):
+            results[i] = segs
+        by_step = {}
+        for i, ev in enumerate(self.events):
+            if ev.__dict__.get("filtered"):
+                rounded, step = ev._on_fine_grid()
+                by_step.setdefault(step, []).append((i, rounded))
+        for group in by_step.values():
+            currents = [r for _, r in group]
+            found = parser.parse_batch(currents) if batched else [parser.parse(c) for c in currents]
+            for (i, _), segs in zip(group, found):
+                results[i] = self.events[i]._adopt_filtered(segs)
         rate = float(self.second)
         for ev, segs in zip(self.events, results):
             ev.segments = segs
@@ -270,3 +296,85 @@ def _rebuild_event(file, ej, meta):
     if state_parser is not None:
         event.state_parser = state_parser
     return event
+
+
+class Experiment(object):
+    """Several recordings analysed together (DataTypes.py:938-1037): `parse` opens one file after the other, detects its
+    events, filters and segments them, and keeps the files; `.events` / `.segments` run over all of them.
+
+    `filenames` may also hold File objects (e.g. built from arrays), which are taken as they are.  Per file the events
+    go to the device together (File.parse_events) instead of one by one."""
+
+    def __init__(self, filenames, name=None):
+        self.filenames = filenames
+        self.name = name or "Experiment"
+        self.files = []
+
+    _DEFAULT = object()
+
+    def parse(self, event_detector=None, segmenter=_DEFAULT, filter_params=(1, 2000), verbose=True, meta=False):
+        """Defaults as in the reference (:956-960): lambda_event_parser(threshold=90), SpeedyStatSplit with
+        prior_segments_per_second=10 and cutoff_freq=2000, a first-order 2 kHz Bessel filter.  segmenter=None: events
+        are detected (and filtered) only; filter_params=None: no filter; meta=True: the currents are dropped afterwards."""
+        if event_detector is None:
+            event_detector = lambda_event_parser(threshold=90)
+        if segmenter is Experiment._DEFAULT:
+            segmenter = SpeedyStatSplit(prior_segments_per_second=10, cutoff_freq=2000.)
+        for entry in self.filenames:
+            file = entry if isinstance(entry, File) else File(entry)
+            if verbose:
+                print("Opening {}".format(file.filename))
+            file.parse(parser=event_detector)
+            if verbose:
+                print("\tDetected {} Events".format(file.n))
+            if segmenter is not None:
+                file.parse_events(segmenter, filter_params)
+                if verbose:
+                    for i, event in enumerate(file.events):
+                        print("\t\tEvent {} has {} segments".format(i + 1, event.n))
+            elif filter_params is not None:
+                for event in file.events:
+                    event.filter(*filter_params)
+            if meta:
+                file.to_meta()
+            self.files.append(file)
+
+    def apply_hmm(self, hmm, filter=None, indices=None):
+        raise NotImplementedError("HMM decoding needs yahmm (out of scope)")
+
+    def delete(self):
+        for file in self.files:
+            file.delete()
+        self.__dict__.clear()
+
+    @property
+    def n(self):
+        return len(self.files)
+
+    @property
+    def events(self):
+        """All events of all files, in file order."""
+        return [event for file in self.files for event in file.events]
+
+    @property
+    def segments(self):
+        """All segments of all events."""
+        return [segment for event in self.events for segment in event.segments]
+
+
+class Sample(object):
+    """Events (and the files they came from) attributed to one substrate (DataTypes.py:1039-1049)."""
+
+    def __init__(self, events=None, files=None, label=None):
+        self.events = list(events) if events is not None else []
+        self.files = list(files) if files is not None else []
+        self.label = label
+
+    def delete(self):
+        with ignored(AttributeError):
+            for file in self.files:
+                file.delete()
+        for event in self.events:
+            event.delete()
+        del self.events
+        del self.files

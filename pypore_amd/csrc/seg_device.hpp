@@ -118,6 +118,15 @@ typedef SharedT<1024> Shared;  // (size reference for the host-side LDS budget: 
 #ifndef PS_BS_MINW
 #define PS_BS_MINW 2          // waves per SIMD the single-wave (block-sum) kernels are compiled for
 #endif
+// Registers of the block-sum scan kernels: 232, so that two of their waves leave 48 of a SIMD's 512 to a wave of another
+// call's streaming kernels (K0 needs 40) -- several calls are in flight (engine.StreamPool) and K0, which is bound by
+// HBM, then runs UNDER the scans, which are bound by instruction issue.  (The attribute counts architectural VGPRs, half
+// of the unified file on this part: 116 -> 232.  A kernel whose launch bounds allow less -- the NT >= 256 instances,
+// 128 -- ignores it.)
+#ifndef PS_SCAN_VGPRS
+#define PS_SCAN_VGPRS 116
+#endif
+#define PS_SCAN_REGS __attribute__((amdgpu_num_vgpr(PS_SCAN_VGPRS)))
 struct Work {
     long long windows, cands, exact;
     long long dbg[4];        // verify mode: first disagreement (ps, pe, screen result, exact result)
@@ -1135,7 +1144,7 @@ __global__ __launch_bounds__(256) void upload_kernel(const int4 *src, int4 *dst,
 // After the chain stops, the workgroup reserves `count` slots in the dense list with one
 // atomic and copies its anchors there so the host fetches a compact array.
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void spine_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void spine_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch,
                                                    int2 *dense, int4 *meta, unsigned long long *dense_count,
                                                    unsigned *status, unsigned long long *work, int n_jobs)
 {
@@ -1202,7 +1211,7 @@ constexpr int BR_PATIENCE = 3;     // windows without a hit a single-wave bridge
                                    // the seam to the look-ahead kernel (bmeta = (count, next window, -, BR_DEFER))
 
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                        const int4 *meta, int2 *bridges, int4 *bmeta,
                                                        unsigned *status, unsigned long long *work, int n_jobs, int max_single)
 {
@@ -1284,7 +1293,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void bridge_kernel
 // the longest seam sets the kernel's duration.  Semantics: find_split (cparsers.pyx:186-201) window by window.
 constexpr int BR_LA = 4;
 template <int DT>
-__global__ __launch_bounds__(64 * BR_LA, 2) void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+__global__ __launch_bounds__(64 * BR_LA, 2) PS_SCAN_REGS void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                                   const int4 *meta, int2 *bridges, int4 *bmeta,
                                                                   unsigned *status, unsigned long long *work, int n_jobs)
 {
@@ -1489,7 +1498,7 @@ __device__ __forceinline__ int ld_agent_i32(const int *p)
 }
 
 template <int DT>
-__global__ __launch_bounds__(64, PS_BS_MINW) void spine_spec_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch, int4 *meta,
+__global__ __launch_bounds__(64, PS_BS_MINW) PS_SCAN_REGS void spine_spec_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch, int4 *meta,
                                                                     unsigned long long *queue, long long qcap, unsigned long long *qctl,
                                                                     unsigned long long *qhead, int32_t *tscratch, int2 *tspill,
                                                                     long long spec_base, SpecRec *rec, int epoch, int flags,
@@ -1617,7 +1626,7 @@ __global__ __launch_bounds__(64, PS_BS_MINW) void spine_spec_kernel(DevCfg c, co
 }
 
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr)
 {
@@ -1648,7 +1657,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) void tree_kernel(D
                               // (4 streams: 0.354 -> 0.347 ms per step; single-wave workgroups 0.345)
 constexpr int TREE_W = PS_TREE_W;
 template <int DT>
-__global__ __launch_bounds__(64 * TREE_W, 2) void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+__global__ __launch_bounds__(64 * TREE_W, 2) PS_SCAN_REGS void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr,
                                                   unsigned long long *tail_ctr, int tail_pct)

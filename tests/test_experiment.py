@@ -1,0 +1,110 @@
+"""Experiment / Sample (DataTypes.py:938-1049): the reference's default workflow -- files -> events -> filter ->
+segments.  The host logic runs everywhere (parsers that work on numpy); the device route is a GPU test."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from pypore_amd import abf, synth
+from pypore_amd.core import Segment
+from pypore_amd.DataTypes import Event, Experiment, File, MetaEvent, Sample
+from pypore_amd.parsers import SpeedyStatSplit, lambda_event_parser
+
+
+class _Halves(object):
+    """A segmenter that needs no device: two halves."""
+
+    def parse(self, current):
+        n = len(current)
+        return [Segment(current=current[:n // 2], start=0, duration=n // 2, end=n // 2),
+                Segment(current=current[n // 2:], start=n // 2, duration=n - n // 2, end=n)]
+
+
+def _host_detector():
+    # custom rules are evaluated on the host over numpy pieces (parsers.lambda_event_parser.parse)
+    return lambda_event_parser(threshold=90, rules=[lambda ev: ev.duration > 1000, lambda ev: ev.max < 90])
+
+
+def _trace(seed):
+    x = np.full(60000, 110.0)
+    x[5000:20000] = 50.0 + (seed % 3)
+    x[30000:52000] = 42.0
+    x[55000:55500] = 40.0                                  # too short for the rule above
+    return x
+
+
+def test_experiment_walks_files_events_segments(capsys):
+    files = [File(current=_trace(s), timestep=0.01) for s in (1, 2)]
+    exp = Experiment(files, name="pair")
+    exp.parse(event_detector=_host_detector(), segmenter=_Halves(), filter_params=None)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("Opening") and out[1] == "\tDetected 2 Events" and out[2] == "\t\tEvent 1 has 2 segments"
+    assert exp.n == 2 and exp.name == "pair" and [f.n for f in exp.files] == [2, 2]
+    assert len(exp.events) == 4 and len(exp.segments) == 8
+    ev = exp.files[1].events[0]
+    assert ev.start == pytest.approx(0.05) and ev.duration == pytest.approx(0.15) and not ev.filtered
+    seg = ev.segments[1]                                     # segments are rescaled to seconds and know their event
+    assert seg.event is ev and seg.start == pytest.approx(0.075) and seg.mean == pytest.approx(52.0)
+    assert isinstance(ev.state_parser, _Halves) and exp.files[0].event_parser.threshold == 90
+
+
+def test_experiment_without_segmenter_and_as_metadata():
+    exp = Experiment([File(current=_trace(0), timestep=0.01)])
+    exp.parse(event_detector=_host_detector(), segmenter=None, filter_params=None, verbose=False)
+    assert [e.n for e in exp.events] == [0, 0] and exp.segments == []
+    exp2 = Experiment([File(current=_trace(0), timestep=0.01)])
+    exp2.parse(event_detector=_host_detector(), segmenter=_Halves(), filter_params=None, verbose=False, meta=True)
+    assert all(isinstance(e, MetaEvent) for e in exp2.events) and not hasattr(exp2.files[0], "current")
+    assert exp2.events[0].mean == pytest.approx(50.0)
+    exp2.delete()
+    with pytest.raises(NotImplementedError):
+        Experiment([]).apply_hmm(None)
+
+
+def test_sample_holds_events_and_files():
+    f = File(current=_trace(0), timestep=0.01)
+    f.parse(_host_detector())
+    s = Sample(events=f.events, files=[f], label="substrate A")
+    assert s.label == "substrate A" and len(s.events) == 2
+    s.delete()
+    assert not hasattr(s, "events") and not hasattr(s, "files")
+    assert Sample().events == [] and Sample().label is None
+
+
+@pytest.mark.gpu
+def test_default_workflow_on_two_abf_files(tmp_path):
+    """Experiment.parse with the reference's defaults (detector at 90 pA, first-order 2 kHz Bessel filter, SpeedyStatSplit
+    with prior_segments_per_second=10 and cutoff_freq=2000) on two synthetic .abf files.  Per file the events are
+    filtered and then segmented together (File.parse_events); the result equals the reference's loop -- event.filter();
+    event.parse(segmenter) one event at a time -- and the oracle's parse of the same rounded filtered current."""
+    paths = []
+    for f in range(2):
+        counts, _ = synth.file_trace_counts(1_600_000, 40 + f)
+        path = os.path.join(str(tmp_path), "run%d.abf" % f)
+        abf.write_abf(path, counts.astype(np.int16))
+        paths.append(path)
+    exp = Experiment(paths)
+    exp.parse(verbose=False)
+    assert exp.n == 2 and len(exp.events) >= 3
+    seg_kw = dict(prior_segments_per_second=10, cutoff_freq=2000.)
+    for file in exp.files:
+        assert os.path.basename(file.filename).startswith("run") and file.event_parser.threshold == 90
+        starts, lens = oracle.lambda_events(np.asarray(file.current), threshold=90.0)
+        assert [int(round(e.start * file.second)) for e in file.events] == list(starts)
+        for ev, a, n in zip(file.events, starts, lens):
+            assert ev.filtered and ev.filter_order == 1 and ev.filter_cutoff == 2000 and ev.n > 1
+            one = Event(current=np.array(file.current[a:a + n]), start=ev.start, end=ev.end, duration=ev.duration,
+                        second=file.second, file=file)
+            one.filter(1, 2000)
+            np.testing.assert_array_equal(one.current, ev.current)
+            one.parse(SpeedyStatSplit(**seg_kw))
+            got = [int(round(s.start * file.second)) for s in ev.segments]
+            assert got == [int(round(s.start * file.second)) for s in one.segments]
+            rounded, step = one._on_fine_grid()
+            ref = oracle.parse(rounded, **seg_kw)
+            np.testing.assert_array_equal(got[1:], ref)
+            seg = ev.segments[len(ev.segments) // 2]
+            i, j = int(round(seg.start * file.second)), int(round(seg.end * file.second))
+            assert seg.event is ev and seg.mean == pytest.approx(float(np.mean(ev.current[i:j])), rel=1e-12)
+    assert len(exp.segments) == sum(e.n for e in exp.events)
