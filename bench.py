@@ -416,7 +416,8 @@ def main():
                                            "and end; with several streams the kernels of different calls overlap and run longer "
                                            "each)"},
             "whole_step_frac_of_hbm_roofline": round(per_gpu_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
-            "work": {k: tm[k] for k in ("windows", "candidates", "tiles", "tree_jobs", "exact_rescans", "full_exact_scans")},
+            "work": {k: tm[k] for k in ("windows", "windows_spine", "windows_bridge", "windows_tree", "candidates", "tiles", "tree_jobs",
+                                       "exact_rescans", "full_exact_scans")},
             # fallbacks of the last step: host-stitch repairs (a seam gave up: BR_MAX anchors), calls redone on the
             # LDS-window path (counts too wide for the block sums), full fp64 window scans
             "fallbacks": {"host_stitch": int(tm["repairs"] >= 1000000), "seam_repairs": int(tm["repairs"] % 1000000),

@@ -214,7 +214,9 @@ int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_mod
  * -- every such event keeps the next kernel from starting back to back (about 6 us of idle GPU each), so the
  * breakdown is a diagnostic and off by default.  counters[0] window scans, [1] candidate
  * positions covered, [2] tiles, [3] tree jobs, [4] seam repairs, [5] windows decided in fp64 (among
- * contenders or by a whole-window scan), [6] of which whole-window scans. */
+ * contenders or by a whole-window scan), [6] of which whole-window scans, [7] 1 = the call was redone on the 64-bit
+ * digest, 2 = on the LDS-window kernels (counts too wide for the block sums), [8] [9] [10] window scans of the spine /
+ * bridge / subtree kernels. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);
 
 /* Synthetic step-signal generator (bit-identical to pypore_amd/synth.py):

@@ -125,7 +125,7 @@ struct ps_ctx {
     int timing = 1;           // 0: no events, 1: start/end of the sequence, 2: an event between the phases as well (each costs
                               // ~6 us of idle GPU: the next kernel does not start back to back)
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t counters[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -469,6 +469,9 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     ctx->counters[1] = static_cast<int64_t>(hs.work1);
     ctx->counters[5] = static_cast<int64_t>(hs.work2 & 0xffffffffULL) + static_cast<int64_t>(hs.work2 >> 32);   // exact decisions
     ctx->counters[6] = static_cast<int64_t>(hs.work2 >> 32);                                                   // of which full fp64 window scans (block-sum scan)
+#ifndef PS_STAMP
+    for (int k = 0; k < 3; ++k) ctx->counters[8 + k] = static_cast<int64_t>(hs.life[3 * k + 1]);              // window scans of the spine / bridge / subtree kernels
+#endif
 #ifdef PS_STAMP
     {
         static const char *nm[12] = {"stage_tail", "minmax", "chunksum", "scan", "eval", "top2", "exact", "outside", "ld_issue", "ld_wait", "-", "-"};
@@ -1330,7 +1333,7 @@ int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counter
 {
     if (!ctx) return PS_ERR_ARG;
     for (int i = 0; i < n_ms && ms; ++i) ms[i] = i < 8 ? ctx->ms[i] : 0.0;
-    for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 8 ? ctx->counters[i] : 0;
+    for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 12 ? ctx->counters[i] : 0;
     return PS_OK;
 }
 

@@ -902,7 +902,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     const int n = pe - ps;
     const int64_t g0 = base + ps;
     PS_STAMP_AT(wk, 7);                                // time outside scans (recursion control, stack)
-    if (threadIdx.x == 0) {
+    if (ps_tid<NT>() == 0) {                           // (every wave of a multi-wave block-sum workgroup counts its own)
         wk.windows += 1;
         wk.cands += (cand_hi >= cand_lo) ? (cand_hi - cand_lo + 1) : 0;
     }
@@ -1096,6 +1096,9 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
         atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
         if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
         if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
+#ifndef PS_STAMP
+        if (which >= 0) atomicAdd(&work[17 + 3 * which], static_cast<unsigned long long>(wk.windows));   // windows per kernel
+#endif
 #ifdef PS_STAMP
 #ifdef PS_STAMP_K
         if (which == PS_STAMP_K)
@@ -1116,11 +1119,14 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
 }
 
 // the same for one wave of a multi-wave workgroup (every wave keeps its own counters)
-__device__ __forceinline__ void flush_wave(unsigned bad, const Work &wk, unsigned *status, unsigned long long *work)
+__device__ __forceinline__ void flush_wave(unsigned bad, const Work &wk, unsigned *status, unsigned long long *work, int which = -1)
 {
     if (bad) atomicOr(status, bad);
     if ((threadIdx.x & 63u) == 0 && wk.windows) {
         atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
+#ifndef PS_STAMP
+        if (which >= 0) atomicAdd(&work[17 + 3 * which], static_cast<unsigned long long>(wk.windows));
+#endif
         atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
         if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
         if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
@@ -1390,14 +1396,7 @@ __global__ __launch_bounds__(64 * BR_LA, 2) PS_SCAN_REGS void bridge_la_kernel(D
         if (threadIdx.x == 0) bmeta[g] = make_int4(cnt, jt, ji, st);
         __syncthreads();                               // obuf / lst are reused by the next tile
     }
-    // counters: every wave counted its own scans
-    if (bad) atomicOr(status, bad);
-    if ((threadIdx.x & 63) == 0 && wk.windows) {
-        atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
-        atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
-        if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
-        if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
-    }
+    flush_wave(bad, wk, status, work, 1);              // counters: every wave counted its own scans
 }
 
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
@@ -1694,7 +1693,7 @@ __global__ __launch_bounds__(64 * TREE_W, 2) PS_SCAN_REGS void tree_mw_kernel(De
             k = __builtin_amdgcn_readfirstlane(kk);
         }
     }
-    flush_wave(bad, wk, status, work);
+    flush_wave(bad, wk, status, work, 2);
 }
 
 // ---- single scans for the API-completeness entry points -----------------------------------------

@@ -54,11 +54,12 @@ class Context(object):
 
     def timings(self):
         ms = (ctypes.c_double * 8)()
-        cnt = (ctypes.c_int64 * 8)()
-        _lib.check(self.L.ps_get_timings(self.handle, ms, 8, cnt, 8))
+        cnt = (ctypes.c_int64 * 12)()
+        _lib.check(self.L.ps_get_timings(self.handle, ms, 8, cnt, 12))
         return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4], bridge_ms=ms[5], blocksum_ms=ms[6], seq_ms=ms[7],
                     windows=cnt[0], candidates=cnt[1], tiles=cnt[2], tree_jobs=cnt[3], repairs=cnt[4],
-                    exact_rescans=cnt[5], full_exact_scans=cnt[6], wide_redo=cnt[7])
+                    exact_rescans=cnt[5], full_exact_scans=cnt[6], wide_redo=cnt[7],
+                    windows_spine=cnt[8], windows_bridge=cnt[9], windows_tree=cnt[10])
 
     # ---- the hot path ---------------------------------------------------------------------------
     def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None,
