@@ -6,6 +6,7 @@ N=${1:-3000}
 for env in "X=0" "PORESEG_MODE=2" "PORESEG_TREE_MW=0" "PORESEG_SCAN_BS=0" "PORESEG_STITCH=host"; do
   echo "== $env"; env $env timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
 done
-FUZZ_BASE=2000000 timeout 1500 python tools/fuzz_gpu.py $N 2>&1 | tail -1 | cut -c1-60
+FUZZ_BASE=${FUZZ_BASE:-2000000} timeout 1500 python tools/fuzz_gpu.py $N 2>&1 | tail -1 | cut -c1-160
+FUZZ_SCALE=64 FUZZ_BASE=${FUZZ_BASE:-2000000} timeout 1500 python tools/fuzz_gpu.py $((N / 2)) 2>&1 | tail -3 | cut -c1-200
 timeout 900 python tools/regime_parity.py 2>&1 | tail -3
 timeout 600 python tools/fuzz_many_events.py 2>&1 | tail -2
