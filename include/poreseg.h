@@ -183,6 +183,15 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
 int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int32_t order,
                      double cutoff, double sampling_freq, double *d_out);
 
+/* The representation step between ps_filter_bessel and ps_segment_batch for a filtered event (no reference counterpart:
+ * the reference segments the float64 result of Event.filter directly, DataTypes.py:286; this library works on exact
+ * integer sums).  d_in[n]: a filtered current in pA (fp64, device).  Writes d_out[n] (fp32, device): the current minus
+ * *centre_out, rounded to multiples of *step_out -- centre = the mean rounded to the grid, step = the finest power of two
+ * that keeps every count below 2^22 (what DataTypes.Event.parse does on the host for a single event).  Segment d_out with
+ * quantum = *step_out; the gains are shift invariant, so the boundaries are those of the rounded current.  Synchronises
+ * the context's stream once (the statistics come back to the host). */
+int ps_requantise(ps_ctx *ctx, const double *d_in, int64_t n, float *d_out, double *centre_out, double *step_out);
+
 /* Replaces cSegmentAligner(model_means, model_stds, model_durs, skip_penalty, backslip_penalty).align(seq_means,
  * seq_stds, seq_durs) (calignment.pyx:20-100; called from SegmentAligner.align, alignment.py:33-46) for a BATCH of
  * sequences against one model: sequence q is entries [h_seq_off[q], h_seq_off[q+1]) of the three device arrays

@@ -203,9 +203,26 @@ class File(Segment):
         """The inner loop of Experiment.parse (DataTypes.py:975-984) for this file: every event is filtered when
         `filter_params` = (order, cutoff) is given, then all events are segmented in as few device calls as their
         representations allow -- one for unfiltered events, one per grid step for filtered ones (events of one file span
-        similar ranges and mostly share a step).  Same result as `event.filter(...); event.parse(parser)` per event."""
+        similar ranges and mostly share a step).  Same result as `event.filter(...); event.parse(parser)` per event.
+        With a SpeedyStatSplit the filtered currents never leave the device between the two steps
+        (parse_filtered_batch: filter, re-quantisation and segmentation on the device, one copy of the float64 result
+        back for Event.current)."""
         if parser is None:
             parser = SpeedyStatSplit(prior_segments_per_second=10)
+        rate = float(self.second)
+        if filter_params is not None and hasattr(parser, "parse_filtered_batch") and all(type(ev) is Event for ev in self.events):
+            # filter -> grid -> segments without leaving the device: only the filtered float64 currents come back
+            order, cutoff = (tuple(filter_params) + (2000.,))[:2] if len(tuple(filter_params)) else (1, 2000.)
+            done = parser.parse_filtered_batch([ev.current for ev in self.events], order, cutoff, rate)
+            for ev, (cur, segs) in zip(self.events, done):
+                ev.current = cur
+                ev.filtered, ev.filter_order, ev.filter_cutoff = True, order, cutoff
+                ev.segments = segs
+                for segment in segs:
+                    segment.event = ev
+                    segment.scale(rate)
+                ev.state_parser = parser
+            return
         if filter_params is not None:
             for ev in self.events:
                 ev.filter(*filter_params)
@@ -225,7 +242,6 @@ class File(Segment):
             found = parser.parse_batch(currents) if batched else [parser.parse(c) for c in currents]
             for (i, _), segs in zip(group, found):
                 results[i] = self.events[i]._adopt_filtered(segs)
-        rate = float(self.second)
         for ev, segs in zip(self.events, results):
             ev.segments = segs
             for segment in segs:

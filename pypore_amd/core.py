@@ -156,8 +156,10 @@ class Segment(_Record):
         for key, value in kwargs.items():
             if key in Segment.derived:
                 continue
-            with ignored(AttributeError):
+            try:
                 setattr(self, key, value)
+            except AttributeError:                       # (a read-only property of a subclass: the reference skips those)
+                pass
 
     @property
     def n(self):

@@ -101,6 +101,36 @@ class FastStatSplit(object):
             run(idx)
         return out
 
+    def parse_filtered_batch(self, currents, order=1, cutoff=2000., sampling_freq=1.e5):
+        """Event.filter + Event.parse for many events without leaving the device in between (the inner loop of
+        Experiment.parse, DataTypes.py:975-984): every current is filtered (ps_filter_bessel), the float64 result is
+        copied to the host -- it becomes Event.current --, re-quantised on the device (ps_requantise) and the events
+        that share a grid step are segmented in one ps_segment_batch.  Returns [(filtered float64 current,
+        [Segment...])] in input order; the segments hold views of the filtered current, start / end in samples."""
+        import torch
+        ctx = engine.context(self.device)
+        filtered, onto_grid, by_step = [None] * len(currents), [None] * len(currents), {}
+        for i, cur in enumerate(currents):
+            s = engine.to_device(cur, self.quantum, self.offset, self.device)
+            y = ctx.filter_bessel(s.tensor, s.quantum, cutoff=cutoff, sampling_freq=sampling_freq, order=order)
+            z, _, step = ctx.requantise(y)
+            filtered[i], onto_grid[i] = (y, s.offset), z
+            by_step.setdefault(step, []).append(i)
+        # (a DC offset passes a unit-gain low-pass unchanged: the counts were filtered, the offset is put back)
+        filtered = [y.cpu().numpy() + off if off else y.cpu().numpy() for y, off in filtered]
+        out = [None] * len(currents)
+        for step, idx in by_step.items():
+            lens = np.array([onto_grid[i].numel() for i in idx], dtype=np.int64)
+            ev_off = np.concatenate(([0], np.cumsum(lens)))
+            samples = onto_grid[idx[0]] if len(idx) == 1 else torch.cat([onto_grid[i] for i in idx])
+            bounds, boff, _ = ctx.segment_batch(samples, ev_off, self._params, step, want_stats=False)
+            b = bounds.cpu().numpy()
+            for e, i in enumerate(idx):
+                cur = filtered[i]
+                edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [int(lens[e])])).tolist()
+                out[i] = (cur, [Segment(current=cur[a:z], start=a, duration=z - a, end=z) for a, z in zip(edges, edges[1:])])
+        return out
+
     # ---- cparsers.pyx:120-155 -------------------------------------------------------------------
     def best_single_split(self, current):
         ctx = engine.context(self.device)

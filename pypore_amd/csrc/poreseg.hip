@@ -1520,6 +1520,33 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
 }
 
+int ps_requantise(ps_ctx *ctx, const double *d_in, int64_t n, float *d_out, double *centre_out, double *step_out)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!d_in || !d_out || !centre_out || !step_out || n < 1) return fail(ctx, PS_ERR_ARG, "null pointer or empty input");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(1024, (n + 8 * RQ_NT - 1) / (8 * RQ_NT)));
+    HIP_TRY(ctx, ctx->filt_agg.reserve(static_cast<size_t>(grid) * 3 * sizeof(double)));
+    HIP_TRY(ctx, ctx->h_meta.reserve(static_cast<size_t>(grid) * 3 * sizeof(double)));
+    hipLaunchKernelGGL(requant_stats_kernel, dim3(grid), dim3(RQ_NT), 0, ctx->stream, d_in, static_cast<long long>(n), ctx->filt_agg.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->filt_agg.p, static_cast<size_t>(grid) * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double *part = ctx->h_meta.as<double>();
+    double sum = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (unsigned g = 0; g < grid; ++g) { sum += part[3 * g]; mn = std::min(mn, part[3 * g + 1]); mx = std::max(mx, part[3 * g + 2]); }
+    if (!std::isfinite(sum) || !std::isfinite(mn) || !std::isfinite(mx)) return fail(ctx, PS_ERR_ARG, "the current holds NaN or infinity");
+    double centre = sum / static_cast<double>(n);
+    const double span = std::max(mx - centre, centre - mn);              // = max |x - centre| (subtraction is monotone)
+    const double step = span > 0.0 ? std::ldexp(1.0, static_cast<int>(std::ceil(std::log2(span * 1.01))) - 22) : 1.0;
+    centre = std::nearbyint(centre / step) * step;
+    const unsigned rg = static_cast<unsigned>(std::min<int64_t>(65535, (n + 4 * RQ_NT - 1) / (4 * RQ_NT)));
+    hipLaunchKernelGGL(requant_round_kernel, dim3(rg), dim3(RQ_NT), 0, ctx->stream, d_in, static_cast<long long>(n), centre, 1.0 / step, step, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    *centre_out = centre; *step_out = step;
+    return PS_OK;
+}
+
 int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_model_stds, const double *h_model_durs,
                    int32_t m, double skip_penalty, double backslip_penalty, const double *d_seq_means,
                    const double *d_seq_stds, const double *d_seq_durs, const int64_t *h_seq_off, int32_t n_seq,

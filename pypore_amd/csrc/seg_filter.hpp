@@ -386,4 +386,39 @@ __global__ __launch_bounds__(64) void filt_halo_kernel(DevCfg c, FiltN f, int64_
     if (bad) atomicOr(status, bad);
 }
 
+// ---- K5b: a filtered current back onto a grid (ps_requantise) -----------------------------------------------------
+// The segmenter works on exact integer sums; a filtered current is float64 off every grid.  DataTypes.Event.parse
+// centres it on its mean and rounds it to the finest power-of-two grid that keeps every count below 2^22 (DESIGN.md
+// 7c).  These two kernels do that for a current that is still on the device: partial sum / min / max per workgroup
+// (combined on the host in a fixed order), then out[i] = (x[i] - centre) rounded to a multiple of `step`, as fp32
+// (22-bit counts times a power of two: exact).  8 B in, 4 B out per sample and pass: bound by HBM.
+constexpr int RQ_NT = 256;
+__global__ __launch_bounds__(RQ_NT) void requant_stats_kernel(const double *x, long long n, double *part)
+{
+    __shared__ double s_sum[RQ_NT / 64], s_min[RQ_NT / 64], s_max[RQ_NT / 64];
+    double sum = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (long long i = blockIdx.x * static_cast<long long>(RQ_NT) + threadIdx.x; i < n; i += gridDim.x * static_cast<long long>(RQ_NT)) {
+        const double v = x[i];
+        sum += v; mn = fmin(mn, v); mx = fmax(mx, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_down(sum, d); mn = fmin(mn, __shfl_down(mn, d)); mx = fmax(mx, __shfl_down(mx, d));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_sum[wave] = sum; s_min[wave] = mn; s_max[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RQ_NT / 64; ++w) { sum += s_sum[w]; mn = fmin(mn, s_min[w]); mx = fmax(mx, s_max[w]); }
+        part[3 * blockIdx.x] = sum; part[3 * blockIdx.x + 1] = mn; part[3 * blockIdx.x + 2] = mx;
+    }
+}
+__global__ __launch_bounds__(RQ_NT) void requant_round_kernel(const double *x, long long n, double centre, double inv_step, double step,
+                                                           float *out)
+{
+#pragma clang fp contract(off)
+    for (long long i = blockIdx.x * static_cast<long long>(RQ_NT) + threadIdx.x; i < n; i += gridDim.x * static_cast<long long>(RQ_NT))
+        out[i] = static_cast<float>(rint((x[i] - centre) * inv_step) * step);
+}
+
 }  // namespace ps

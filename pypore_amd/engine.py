@@ -187,6 +187,18 @@ class Context(object):
                                            ctypes.c_void_p(out.data_ptr())), self.handle)
         return out[:samples.numel()]
 
+    def requantise(self, current):
+        """ps_requantise: a filtered current (float64 CUDA tensor, pA) centred and rounded to the finest power-of-two
+        grid that keeps its counts below 2**22.  Returns (float32 CUDA tensor on that grid, centre, step): segment it
+        with quantum = step."""
+        assert current.is_cuda and current.is_contiguous() and current.dim() == 1 and current.dtype == torch.float64
+        out = torch.empty(max(1, current.numel()), dtype=torch.float32, device=current.device)
+        centre, step = ctypes.c_double(), ctypes.c_double()
+        torch.cuda.current_stream(current.device).synchronize()
+        _lib.check(self.L.ps_requantise(self.handle, ctypes.c_void_p(current.data_ptr()), current.numel(),
+                                        ctypes.c_void_p(out.data_ptr()), ctypes.byref(centre), ctypes.byref(step)), self.handle)
+        return out[:current.numel()], centre.value, step.value
+
     def align_batch(self, model_means, model_stds, model_durs, skip_penalty, backslip_penalty,
                     seq_means, seq_stds, seq_durs, seq_off):
         """ps_align_batch: cSegmentAligner.align (calignment.pyx:20-100) for a batch of sequences.  Model arrays: host

@@ -145,6 +145,10 @@ class SpeedyStatSplit(parser):
         """All events of a file in one device call (extension; same result as [parse(c) for c in currents])."""
         return self._fast().parse_batch(currents)
 
+    def parse_filtered_batch(self, currents, order=1, cutoff=2000., sampling_freq=None):
+        """event.filter(order, cutoff); event.parse(self) for many events, on the device from end to end (extension)."""
+        return self._fast().parse_filtered_batch(currents, order, cutoff, self.sampling_freq if sampling_freq is None else sampling_freq)
+
     def best_single_split(self, current):
         """(gain, index) of the best single split; like the reference wrapper, without cutoff_freq (:530-534)."""
         return self._fast(cutoff=False).best_single_split(current)

@@ -200,3 +200,30 @@ def test_filter_order3_large_trace_and_event_api():
     ev.filter(order=3, cutoff=2000.)
     assert ev.filtered and ev.filter_order == 3
     assert np.max(np.abs(ev.current - oracle.bessel_filtfilt(x, 2000., 1e5, 3))) <= 1e-9 * np.max(np.abs(x))
+
+
+@pytest.mark.gpu
+def test_requantise_matches_the_host_rounding_of_event_parse():
+    """ps_requantise (filtered current -> centred fp32 on the finest power-of-two grid with counts below 2**22, on the
+    device) against DataTypes.Event._on_fine_grid (the same on the host with numpy): same step, same rounded values --
+    the two means may differ in the last bits, which can move the centre by one grid step at most (a constant shift)."""
+    import torch
+    from pypore_amd import engine
+    from pypore_amd.DataTypes import Event, File
+    ctx = engine.context(0)
+    rng = np.random.default_rng(3)
+    for n, scale, offset in ((13, 1.0, 0.0), (5000, 40.0, 55.0), (1_000_003, 3.0, -20.0), (262144, 1e-3, 1e3), (70000, 250.0, 0.0)):
+        x = offset + scale * np.cumsum(rng.standard_normal(n)) / np.sqrt(n) + 0.01 * scale * rng.standard_normal(n)
+        f = File(current=x, timestep=0.01)
+        rounded, step = Event(current=x, second=f.second, file=f)._on_fine_grid()
+        z, centre, dstep = ctx.requantise(torch.from_numpy(x).cuda())
+        z = z.cpu().numpy().astype(np.float64)
+        assert dstep == step and np.abs(z).max() < 2 ** 22 * step
+        np.testing.assert_array_equal(np.rint(z / step) * step, z)             # on the grid
+        shift = np.unique(np.rint((rounded - z) / step))
+        assert shift.size == 1 and abs(shift[0]) <= 1
+        assert abs(centre - np.mean(x)) <= step
+    const, c0, s0 = ctx.requantise(torch.full((100,), 7.25, dtype=torch.float64, device="cuda"))
+    assert s0 == 1.0 and c0 == 7.0 and float(const.abs().max()) == 0.0        # no spread: unit grid, the mean rounded
+    with pytest.raises(ValueError):
+        ctx.requantise(torch.tensor([1.0, float("nan"), 2.0], dtype=torch.float64, device="cuda"))

@@ -1,0 +1,38 @@
+"""End to end: the reference's DEFAULT workflow, Experiment.parse (DataTypes.py:956-988), on one synthetic .abf file --
+read, detect events at 90 pA, first-order 2 kHz Bessel filtfilt of every event, SpeedyStatSplit(prior_segments_per_second
+=10, cutoff_freq=2000) on every filtered event -- wall clock on the host, everything included.  Beside it the same steps
+on the CPU for the first events (scipy-equivalent filter and segmenter of oracle/, one core), scaled to the file.
+usage: bench_experiment.py [samples, default 1e8]"""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+from pypore_amd import abf, synth
+from pypore_amd.DataTypes import Experiment
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+counts, _ = synth.file_trace_counts(n, 7)
+path = os.path.join(tempfile.mkdtemp(), "bench.abf")
+abf.write_abf(path, counts.astype(np.int16))
+for rep in range(2):                                   # (first pass: allocations, library load)
+    exp = Experiment([path])
+    t0 = time.perf_counter()
+    exp.parse(verbose=False)
+    dt = time.perf_counter() - t0
+ev = exp.events
+ns = sum(len(e.current) for e in ev)
+print("Experiment.parse: %d samples, %d events (%d samples in events), %d segments: %.3f s = %.1f Msamples/s of file"
+      % (n, len(ev), ns, len(exp.segments), dt, n / dt / 1e6))
+# the same on one CPU core for events worth ~4e6 samples
+x = np.asarray(exp.files[0].current)
+done = 0; t0 = time.perf_counter(); k = 0
+for e in ev:
+    a = int(round(e.start * exp.files[0].second)); m = len(e.current)
+    y = oracle.bessel_filtfilt(x[a:a + m], 2000., exp.files[0].second)
+    b = oracle.parse(y, prior_segments_per_second=10, cutoff_freq=2000.)
+    done += m; k += 1
+    if done >= 4_000_000: break
+cpu = time.perf_counter() - t0
+t0 = time.perf_counter(); oracle.lambda_events(x[:20_000_000], threshold=90.0); det = (time.perf_counter() - t0) * n / 20_000_000
+print("CPU (oracle, one core): filter + segmentation of %d events (%d samples) %.2f s -> %.1f s for the file's events, "
+      "+ detection %.1f s: %.1f Msamples/s of file" % (k, done, cpu, cpu * ns / done, det, n / (cpu * ns / done + det) / 1e6))
