@@ -19,6 +19,13 @@ for rep in range(2):                                   # (first pass: allocation
     t0 = time.perf_counter()
     exp.parse(verbose=False)
     dt = time.perf_counter() - t0
+for rep in range(2):                                   # the same without the filter (BASELINE config 3 through the classes)
+    exp2 = Experiment([path])
+    t0 = time.perf_counter()
+    exp2.parse(filter_params=None, segmenter=__import__("pypore_amd.parsers", fromlist=["x"]).SpeedyStatSplit(prior_segments_per_second=10), verbose=False)
+    dt2 = time.perf_counter() - t0
+print("Experiment.parse(filter_params=None): %d events, %d segments: %.3f s = %.1f Msamples/s of file"
+      % (len(exp2.events), len(exp2.segments), dt2, n / dt2 / 1e6))
 ev = exp.events
 ns = sum(len(e.current) for e in ev)
 print("Experiment.parse: %d samples, %d events (%d samples in events), %d segments: %.3f s = %.1f Msamples/s of file"
