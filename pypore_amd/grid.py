@@ -35,7 +35,11 @@ class GridArray(np.ndarray):
     @classmethod
     def from_counts(cls, counts, quantum, offset=0.0):
         """What the reference reader computes (read_abf.py:210): float64(counts) * scale + offset."""
-        return cls(np.array(counts, dtype=np.float64) * quantum + offset, counts, quantum, offset)
+        current = np.array(counts, dtype=np.float64)        # (same two roundings, without the two temporaries)
+        current *= quantum
+        if offset:
+            current += offset
+        return cls(current, counts, quantum, offset)
 
 
 def grid_of(current):
