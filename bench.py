@@ -281,12 +281,20 @@ def main():
         seq_acc[t] += cx.seq_ms()                        # HIP events on the context's stream: first upload .. last result copy
         return r
 
+    # CPython's cyclic collector is stop-the-world: a full collection walks every object torch and numpy created at
+    # import (40 ms here) while holding the GIL, and every host thread of the pool then waits for it on its way out of
+    # the C call (tools/pool_stalls.py: all four contexts stall together, the device sequences stay at 1.2 ms).  A
+    # long-running host does what is done here: collect once, then move what is alive out of the collector's reach.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     results = pool.run(steps, timed)                     # K steps, step k on stream k % T (T = 1: one after the other)
     final_gather()                                       # the job's boundary gather is inside the timed region
     barrier()
     dt = time.perf_counter() - t0
+    gc.unfreeze()
     result = results[-1]
     seq_ms = sum(seq_acc) / steps
     # one batch at a time on one stream (the latency of a single call), outside the timed region

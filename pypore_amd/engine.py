@@ -257,7 +257,12 @@ class StreamPool(object):
     (events and files are the reference's own unit of work, DataTypes.py:968-984), so the kernels of one batch fill the
     idle stretches of another when they are submitted on different streams: two streams deliver 1.4x the batches per
     second of one on the 1e8-sample bench trace, with bit-identical results.  ctypes drops the GIL for the duration of a
-    call, so plain Python threads are enough.  Every call still ends with its own stream synchronisation."""
+    call, so plain Python threads are enough.  Every call still ends with its own stream synchronisation.
+
+    A host that keeps the pool busy for long should take CPython's cyclic collector out of the way (`gc.collect();
+    gc.freeze()` once everything is set up): a full collection holds the GIL for tens of milliseconds and every worker
+    then waits for it on its way out of the C call -- 0.33 instead of 0.35-0.43 ms per 1e8-sample batch over runs of
+    400-2000 batches (tools/pool_stalls.py)."""
 
     def __init__(self, device=None, streams=2):
         import queue
