@@ -282,10 +282,17 @@ class StreamPool(object):
     def __len__(self):
         return len(self.contexts)
 
-    def _share(self, t, n_jobs, job, results, errors):
+    def _share(self, t, n_jobs, job, results, errors, ticket=None):
         try:
-            for k in range(t, n_jobs, len(self.contexts)):
-                results[k] = job(self.contexts[t], k, t)
+            if ticket is None:                         # fixed shares: job k on context k % T
+                for k in range(t, n_jobs, len(self.contexts)):
+                    results[k] = job(self.contexts[t], k, t)
+            else:                                      # whoever is free takes the next job
+                while True:
+                    k = next(ticket)                   # (itertools.count: one C call, atomic under the GIL)
+                    if k >= n_jobs:
+                        break
+                    results[k] = job(self.contexts[t], k, t)
         except BaseException as e:                     # noqa: B036 -- re-raised on the submitting thread
             errors.append(e)
 
@@ -302,15 +309,18 @@ class StreamPool(object):
             self._inbox[t].put(None)
         self._threads = []
 
-    def run(self, n_jobs, job):
-        """Runs job(ctx, k, t) for k = 0 .. n_jobs-1, job k on context t = k % T; returns the results in job order."""
+    def run(self, n_jobs, job, dynamic=False):
+        """Runs job(ctx, k, t) for k = 0 .. n_jobs-1 and returns the results in job order.  Job k runs on context
+        t = k % T, or -- dynamic=True -- on whichever context is free next (jobs of unequal length)."""
+        import itertools
         T = len(self.contexts)
         results = [None] * n_jobs
         errors = []
+        ticket = itertools.count() if dynamic else None
         busy = [t for t in range(1, T) if t < n_jobs]
         for t in busy:
-            self._inbox[t].put((n_jobs, job, results, errors))
-        self._share(0, n_jobs, job, results, errors)
+            self._inbox[t].put((n_jobs, job, results, errors, ticket))
+        self._share(0, n_jobs, job, results, errors, ticket)
         for _ in busy:
             self._done.get()
         if errors:

@@ -163,4 +163,10 @@ def test_stream_pool_scheduling_without_a_gpu():
     with pytest.raises(ZeroDivisionError):
         pool.run(5, lambda cx, k, t: 1 // (k - 3))
     assert pool.run(3, lambda cx, k, t: k) == [0, 1, 2]
+    # dynamic=True: every job runs exactly once, on whichever context is free; a context stuck in a long job takes fewer
+    import time
+    took = pool.run(40, lambda cx, k, t: (time.sleep(0.05 if t == 2 else 0.001), k, t)[1:], dynamic=True)
+    assert [k for k, _ in took] == list(range(40))
+    share = [sum(1 for _, t in took if t == c) for c in range(4)]
+    assert sum(share) == 40 and share[2] < min(share[0], share[1], share[3])
     pool.close()
