@@ -108,3 +108,32 @@ def test_default_workflow_on_two_abf_files(tmp_path):
             i, j = int(round(seg.start * file.second)), int(round(seg.end * file.second))
             assert seg.event is ev and seg.mean == pytest.approx(float(np.mean(ev.current[i:j])), rel=1e-12)
     assert len(exp.segments) == sum(e.n for e in exp.events)
+
+
+@pytest.mark.gpu
+def test_filtered_batch_on_a_real_header_scale_with_offset(tmp_path):
+    """The device-resident chain (parse_filtered_batch) on a file whose header gives a scale that is not a power of two
+    and a non-zero offset: the counts are filtered, the offset is put back, and currents, segment boundaries and segment
+    statistics equal those of event.filter(); event.parse() one event at a time.  An empty list of events is fine too."""
+    counts, _ = synth.file_trace_counts(900_000, 77)
+    path = os.path.join(str(tmp_path), "offset.abf")
+    # 10 V / 0.0005 V/pA / 20 / 32768 = 0.0305... pA per count; the synthetic counts assume 2**-5, so the levels shift a
+    # little -- what matters here is the arithmetic, not the physiology
+    abf.write_abf(path, counts.astype(np.int16), adc_range=10.0, adc_resolution=32768, instrument_scale=0.0005,
+                  signal_gain=20.0, instrument_offset=1.25, signal_offset=0.5)
+    exp = Experiment([path])
+    exp.parse(verbose=False)
+    file = exp.files[0]
+    assert file.n >= 1
+    from pypore_amd.grid import grid_of
+    assert grid_of(file.current)[2] != 0.0                                  # the reader reports an offset
+    seg = SpeedyStatSplit(prior_segments_per_second=10, cutoff_freq=2000.)
+    for ev in file.events:
+        a = int(round(ev.start * file.second)); n = len(ev.current)
+        one = Event(current=file.current[a:a + n], start=ev.start, end=ev.end, duration=ev.duration, second=file.second, file=file)
+        one.filter(1, 2000)
+        np.testing.assert_allclose(ev.current, one.current, rtol=0, atol=1e-9)
+        one.parse(seg)
+        assert [int(round(s.start * file.second)) for s in ev.segments] == [int(round(s.start * file.second)) for s in one.segments]
+        assert ev.segments[0].mean == pytest.approx(one.segments[0].mean, rel=1e-12)
+    assert seg.parse_filtered_batch([]) == []
