@@ -412,6 +412,14 @@ def main():
                                               "achieved": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / 1e9, 1) if kern["blocksum_ms"] > 0 else None,
                                               "frac": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / HBM_PEAK, 4) if kern["blocksum_ms"] > 0 else None},
                          "traffic_per_kernel": traffic["per_kernel"] if traffic else None,
+                         # what bounds the path is instruction issue, not memory: the call's wave-level
+                         # vector instructions (SQ_INSTS_VALU of the same PMC passes) at 4 cycles each on 1 024 SIMDs
+                         "issue_bound": None if not (traffic and traffic.get("valu_per_kernel")) else {
+                             "wave_instructions": int(sum(traffic["valu_per_kernel"].values())),
+                             "ms_at_valu_peak": round(sum(traffic["valu_per_kernel"].values()) * 4 / (1024 * 2.4e9) * 1e3, 4),
+                             "frac_of_valu_peak": round(sum(traffic["valu_per_kernel"].values()) * 4 / (1024 * 2.4e9) * 1e3 / ms_per_step, 4),
+                             "per_kernel": traffic["valu_per_kernel"], "source": traffic.get("valu_source"),
+                             "note": "256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz"},
                          "sequence_ms": round(seq_ms, 4),
                          "single_stream": None if single is None else {
                              "ms_per_step": round(single[0], 4), "sequence_ms": round(single[1], 4),

@@ -28,19 +28,23 @@ import sys, re, json, ast
 tag = sys.argv[1]
 per = {}
 for line in open('gpurun_out/%s_pmc_summary.txt' % tag):
-    m = re.match(r'(fetch|write) (?:void )?ps::(\w+)(?:<[^>]*>)? (\{.*\})', line.strip())
+    m = re.match(r'(fetch|write|sq) (?:void )?ps::(\w+)(?:<[^>]*>)? (\{.*\})', line.strip())
     if not m: continue
     d = ast.literal_eval(m.group(3))
     k = m.group(2)
     per.setdefault(k, {})
     if m.group(1) == 'fetch': per[k]['fetch_kib'] = d['FETCH_SIZE']
-    else: per[k]['write_kib'] = d['WRITE_SIZE']
+    elif m.group(1) == 'write': per[k]['write_kib'] = d['WRITE_SIZE']
+    elif 'SQ_INSTS_VALU' in d: per[k]['valu'] = d['SQ_INSTS_VALU']
 names = ['blocksum_kernel', 'spine_kernel', 'bridge_kernel', 'bridge_la_kernel', 'tree_mw_kernel', 'assemble_tiles_kernel',
          'assemble_items_kernel', 'item_scan_kernel', 'gather_kernel', 'upload_kernel']
 pk = {k: (2 * per[k].get('fetch_kib', 0) + per[k].get('write_kib', 0)) * 1024 for k in names if k in per}
 json.dump({"source": "profiles/%s_pmc_summary.txt: FETCH_SIZE (KiB) x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE (KiB) per "
                      "launch, rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --streams 1`" % tag,
-           "total": sum(pk.values()), "per_kernel": pk}, open('gpurun_out/%s_pmc_traffic.json' % tag, 'w'), indent=1)
+           "total": sum(pk.values()), "per_kernel": pk,
+           "valu_source": "profiles/%s_pmc_summary.txt: SQ_INSTS_VALU (wave-level vector instructions) per launch, same passes" % tag,
+           "valu_per_kernel": {k: per[k]['valu'] for k in names if k in per and 'valu' in per[k]}},
+          open('gpurun_out/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 print(json.dumps(pk))
 PY
 head -12 gpurun_out/${TAG}_s1_kernel_stats.csv | cut -c1-60,200-400
