@@ -1149,6 +1149,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
     HIP_TRY(ctx, ctx->tree_jobs.reserve(std::max<size_t>(1, n_tj) * sizeof(TreeJob)));
     // (item_scan_kernel reads counts[item index] speculatively: cover the items as well)
     HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<size_t>(std::max<size_t>(1, n_tj), static_cast<size_t>(n_items)) * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->tree_counts.p, 0, std::max<size_t>(std::max<size_t>(1, n_tj), static_cast<size_t>(n_items)) * sizeof(int32_t), ctx->stream));   // (tree_job stores only non-zero counts)
     HIP_TRY(ctx, ctx->tree_scratch.reserve(std::max<size_t>(1, static_cast<size_t>(tscratch)) * sizeof(int32_t)));
     HIP_TRY(ctx, ctx->tree_spill.reserve(std::max<size_t>(1, static_cast<size_t>(tscratch)) * sizeof(int2)));
     HIP_TRY(ctx, ctx->items.reserve(std::max<size_t>(1, static_cast<size_t>(n_items)) * sizeof(Item)));

@@ -1461,7 +1461,10 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
     if (cnt > job.out_cap) cnt = job.out_cap;
     ps_sync<NT>();
     for (int i = flushed + tid; i < cnt; i += NT) out[i] = obuf[i - flushed];
-    if (tid == 0 && counts) counts[ji] = cnt;
+    // (the counts are zero before the kernel runs -- assemble_items_kernel, or a memset on the host-stitch path -- and
+    //  most jobs find nothing: no store then, and nothing for the fence below to wait for -- a store's round trip at the
+    //  end of every job is 1-2 us in front of the next job's loads)
+    if (tid == 0 && counts && cnt) counts[ji] = cnt;
     ps_sync<NT>();                                     // obuf / stack are reused by the next job
     return cnt;
 }
