@@ -263,6 +263,14 @@ def main():
         scaling = "strong"
 
     torch.cuda.synchronize()
+    # CPython's cyclic collector is stop-the-world: a full collection walks every object torch and numpy created at
+    # import (40 ms here) while holding the GIL, and every host thread of the pool then waits for it on its way out of
+    # the C call (tools/pool_stalls.py: all four contexts stall together, the device sequences stay at 1.2 ms).  A
+    # long-running host does what is done here: collect once, then move what is alive out of the collector's reach.
+    # (Before the warm-up, not after it: the GPU drops its clocks during a pause of that length.)
+    import gc
+    gc.collect()
+    gc.freeze()
     # A fresh process starts cold (GPU clocks, pinned staging buffers, the allocator's pools): settle for a fixed
     # 0.2 s before the W warmup steps so that a small W does not leak start-up effects into the K timed steps.
     t_settle = time.perf_counter()
@@ -281,13 +289,6 @@ def main():
         seq_acc[t] += cx.seq_ms()                        # HIP events on the context's stream: first upload .. last result copy
         return r
 
-    # CPython's cyclic collector is stop-the-world: a full collection walks every object torch and numpy created at
-    # import (40 ms here) while holding the GIL, and every host thread of the pool then waits for it on its way out of
-    # the C call (tools/pool_stalls.py: all four contexts stall together, the device sequences stay at 1.2 ms).  A
-    # long-running host does what is done here: collect once, then move what is alive out of the collector's reach.
-    import gc
-    gc.collect()
-    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     results = pool.run(steps, timed)                     # K steps, step k on stream k % T (T = 1: one after the other)
