@@ -437,6 +437,8 @@ def main():
                                        "exact_rescans", "full_exact_scans")},
             # fallbacks of the last step: host-stitch repairs (a seam gave up: BR_MAX anchors), calls redone on the
             # LDS-window path (counts too wide for the block sums), full fp64 window scans
+            "host": {"omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "torch_threads": torch.get_num_threads(),
+                     "affinity_cpus": len(os.sched_getaffinity(0)), "under_torchrun": "TORCHELASTIC_RUN_ID" in os.environ},
             "fallbacks": {"host_stitch": int(tm["repairs"] >= 1000000), "seam_repairs": int(tm["repairs"] % 1000000),
                           "wide_range_redo": int(tm.get("wide_redo", 0)), "full_exact_scans": int(tm["full_exact_scans"])},
         }
