@@ -96,12 +96,8 @@ struct ps_ctx {
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     int wide_bs = 1;          // 1: counts too wide for the 32-bit digest are retried on the 64-bit digest, 0: straight to the LDS-window scan
-    int spec_tree = 0;        // 1: waves of the spine kernel whose chains have ended run subtree jobs speculatively (spine_spec_kernel; measured slower: the scans are issue-bound)
     int bridge_single = 1 << 30;   // anchors a single-wave bridge adds before it hands the seam to the look-ahead kernel (measured: handing over early is slower)
     int tree_tail_pct = 0;    // tree_mw_kernel: share of the job list drawn dynamically (counter in HBM) at the end
-    int spec_flags = 1;       // spine_spec_kernel: 1 = chains at high priority, 2 = stop speculating when all chains have ended
-    int epoch = 0;            // call counter: tag of this call's queue entries and speculative records
-    DevBuf spec_queue, spec_qaux, spec_rec;
     // host-side caches: occupancy per kernel, dynamic-LDS attribute last set, the tile tables of the last call
     struct OccKey { const void *fn; int nt; size_t lds; unsigned slots; };
     std::vector<OccKey> occ_cache;
@@ -110,7 +106,7 @@ struct ps_ctx {
         bool valid = false;
         int32_t n_ev = 0; int mw = 0, W = 0; int64_t L = 0; bool use_bs = false;
         std::vector<int64_t> ev_start, ev_len;
-        size_t nj = 0, jb = 0, up_bytes = 0; int64_t list_entries = 0, total_len = 0, sample_end = 0, nb_total = 0, spec_total = 0;
+        size_t nj = 0, jb = 0, up_bytes = 0; int64_t list_entries = 0, total_len = 0, sample_end = 0, nb_total = 0;
     } tile_cache;
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
@@ -236,20 +232,6 @@ template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsig
     hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(),
                        list_mode ? nullptr : ctx->spine_dense.as<int2>(), ctx->spine_meta.as<int4>(), &sm->dense, reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
-                       static_cast<int>(nj));
-    HIP_TRY(ctx, hipGetLastError());
-    return PS_OK;
-}
-
-// block-sum scan: tile chains + speculative subtree jobs in the idle tail (spine_spec_kernel)
-template <int DT> int launch_spine_spec(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, int64_t qcap, int64_t spec_base)
-{
-    const unsigned grid = std::min(nj, resident_slots(ctx, spine_spec_kernel<DT>, 64, 0));
-    hipLaunchKernelGGL((spine_spec_kernel<DT>), dim3(grid), dim3(64), 0, ctx->stream, cfg, ctx->spine_jobs.as<SpineJob>(),
-                       ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(), ctx->spec_queue.as<unsigned long long>(),
-                       static_cast<long long>(qcap), &sm->qctl, &sm->qhead,
-                       ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(), static_cast<long long>(spec_base),
-                       ctx->spec_rec.as<SpecRec>(), ctx->epoch, ctx->spec_flags, reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
                        static_cast<int>(nj));
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
@@ -471,6 +453,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     ctx->counters[6] = static_cast<int64_t>(hs.work2 >> 32);                                                   // of which full fp64 window scans (block-sum scan)
 #ifndef PS_STAMP
     for (int k = 0; k < 3; ++k) ctx->counters[8 + k] = static_cast<int64_t>(hs.life[3 * k + 1]);              // window scans of the spine / bridge / subtree kernels
+    ctx->counters[11] = static_cast<int64_t>(hs.stamp[0]);                                                     // near-tie decisions (seg_bs.hpp: bs_decide)
 #endif
 #ifdef PS_STAMP
     {
@@ -573,7 +556,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
         Lt = std::min<int64_t>(Lt, 0x7fffffff);
         std::vector<SpineJob> jobs;
         std::vector<int64_t> ev_first_tile(static_cast<size_t>(n_ev) + 1, 0);
-        int64_t list_entries = 0, vb_run = 0, spec_total = 0;
+        int64_t list_entries = 0, vb_run = 0;
         for (int e = 0; e < n_ev; ++e) {
             ev_first_tile[e] = static_cast<int64_t>(jobs.size());
             const int64_t len = ev_len[e];
@@ -598,10 +581,6 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
                 j.tile_len = static_cast<int32_t>(Le);
                 j.ev = e;
                 j.vbase = vbase;
-                // speculative subtree outputs of the tile's own pairs: a chain ends before stop + 3 W (its windows start
-                // before stop + 2 W), region of pair i at (pred - start)/mw + i
-                j.spec_off = spec_total;
-                spec_total += 2 * ((std::min<int64_t>(len, static_cast<int64_t>(j.stop) + 3LL * W) - j.start) / mw + 2) + 4;
                 list_entries += j.out_cap;
                 jobs.push_back(j);
             }
@@ -624,12 +603,10 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
         tc.n_ev = n_ev; tc.mw = mw; tc.W = W; tc.L = L; tc.use_bs = use_bs;
         tc.ev_start.assign(ev_start, ev_start + n_ev); tc.ev_len.assign(ev_len, ev_len + n_ev);
         tc.nj = nj; tc.jb = jb; tc.up_bytes = up_bytes; tc.list_entries = list_entries; tc.total_len = total_len;
-        tc.sample_end = sample_end; tc.nb_total = boff[n_ev]; tc.spec_total = spec_total;
+        tc.sample_end = sample_end; tc.nb_total = boff[n_ev];
     }
     const size_t nj = tc.nj, jb = tc.jb, up_bytes = tc.up_bytes;
     const int64_t list_entries = tc.list_entries, total_len = tc.total_len, sample_end = tc.sample_end;
-    const bool spec = use_bs && !wide && ctx->spec_tree && nj > 0;
-    const int64_t spec_total = spec ? tc.spec_total : 0;
     ctx->counters[2] = static_cast<int64_t>(nj);
     const int64_t max_items = list_entries + static_cast<int64_t>(nj) * BR_MAX;
     const int64_t tscratch_bound = total_len / mw + max_items + 1;     // tree output regions: (base+pred)/mw + item
@@ -645,25 +622,13 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
     HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<int64_t>(1, max_items) * sizeof(int32_t)));
     HIP_TRY(ctx, ctx->items.reserve(std::max<int64_t>(1, max_items) * sizeof(Item)));
     HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(max_items) + 1) * sizeof(int64_t)));
-    // (the speculative subtree outputs of the spine kernel live behind the regular regions of the same two buffers)
-    HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound + spec_total) * sizeof(int32_t)));
-    HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound + spec_total) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int2)));
     HIP_TRY(ctx, ctx->first_item.reserve(evb));
     if (evb <= SMALL_TAIL) ctx->bounds_off.alias(ctx->small.as<char>() + sizeof(SmallLayout));   // comes back with the status block
     else HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
     ctx->asm_hdr.alias(&ctx->small.as<SmallLayout>()->hdr);
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
-    if (spec) {
-        // queue of speculative pairs and their records: tagged with the call's epoch, so nothing is cleared per call
-        if (++ctx->epoch == 0x7fffffff) {              // (wrap: clear the tags once every 2^31 calls)
-            ctx->epoch = 1;
-            if (ctx->spec_queue.p) HIP_TRY(ctx, hipMemsetAsync(ctx->spec_queue.p, 0, ctx->spec_queue.cap, ctx->stream));
-            if (ctx->spec_rec.p) HIP_TRY(ctx, hipMemsetAsync(ctx->spec_rec.p, 0, ctx->spec_rec.cap, ctx->stream));
-        }
-        HIP_TRY(ctx, ctx->spec_queue.reserve_zeroed(std::max<int64_t>(1, list_entries) * 4 * sizeof(unsigned long long), ctx->stream));
-        HIP_TRY(ctx, ctx->spec_rec.reserve_zeroed(std::max<int64_t>(1, list_entries) * sizeof(SpecRec), ctx->stream));
-    }
-
     {
         const char *up = ctx->h_up.as<char>();
         void *up_devptr = nullptr;                     // the pinned blob as the device sees it (else: plain copy)
@@ -695,23 +660,25 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
     if (use_bs && nj) {
         // K0: chunk-prefixed block sums (one streaming pass), per-event centre m, totals + max|k| per 256 blocks
         const int64_t nb_total = tc.nb_total;
-        const unsigned k0_grid = static_cast<unsigned>((nb_total + 1 + BS_CHUNK - 1) / BS_CHUNK);   // (+1: the end boundary)
-        HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int4)));
+        // (a wave of K0 takes 256 blocks; the digest arrays are padded to whole waves, +1: the end boundary)
+        const int64_t nb_pad = k0_padded_blocks(nb_total);
+        const unsigned k0_grid = static_cast<unsigned>((nb_pad / K0_WB + K0_WAVES - 1) / K0_WAVES);
+        HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_pad) * (wide ? sizeof(int4) : sizeof(uint2))));
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
-        HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(k0_grid + 1) * 2 * sizeof(int4)));
+        HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(nb_pad / BS_CHUNK + 1) * (wide ? 2 : 1) * sizeof(int4)));
         if (d_stats && !wide) {                        // per-block min/max for the statistics kernel (4 B per block; int16 pairs)
-            HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_total + 1) * sizeof(int)));
+            HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_pad) * sizeof(int)));
             cfg.blk_mm = ctx->blk_mm.as<int>();
         }
-#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(256), 0, ctx->stream, cfg,                      \
+#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), 0, ctx->stream, cfg,            \
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
-                                    ctx->bsum.as<int4>(), ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                          \
+                                    ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
                                     reinterpret_cast<unsigned *>(&sm->status))
         if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
         else      { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
 #undef PS_K0
         HIP_TRY(ctx, hipGetLastError());
-        cfg.bsum = ctx->bsum.as<int4>();
+        cfg.bsum = ctx->bsum.p;
         cfg.ev_info = ctx->ev_info.as<int4>();
         cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
     }
@@ -728,9 +695,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
         if (lrc) return lrc;
     } else if (nj && use_bs) {
         const unsigned g = static_cast<unsigned>(nj);
-        int lrc = spec ? (f32 ? launch_spine_spec<PS_DTYPE_F32>(ctx, cfg, g, sm, list_entries, tscratch_bound)
-                              : launch_spine_spec<PS_DTYPE_I16>(ctx, cfg, g, sm, list_entries, tscratch_bound))
-                       : (f32 ? launch_spine<64, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16>(ctx, cfg, g, sm, true));
+        int lrc = f32 ? launch_spine<64, PS_DTYPE_F32>(ctx, cfg, g, sm, true) : launch_spine<64, PS_DTYPE_I16>(ctx, cfg, g, sm, true);
         if (lrc) return lrc;
         if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // single-wave bridges first; the seams that run into a stretch without splits are finished by the look-ahead kernel
@@ -775,8 +740,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
                            ctx->stream, ctx->spine_jobs.as<SpineJob>(), static_cast<int>(nj), ctx->spine_meta.as<int4>(),
                            ctx->spine_scratch.as<int2>(), ctx->bridges.as<int2>(), ti + 3 * njp,
                            ctx->sp_off.as<long long>(), 0LL, mw, W, ctx->tree_jobs.as<TreeJob>(),
-                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr,
-                           spec ? ctx->spec_rec.as<SpecRec>() : nullptr, ctx->epoch, static_cast<long long>(tscratch_bound));
+                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr, cfg.bsum != nullptr ? cfg.ev_info : nullptr);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
@@ -832,8 +796,6 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_SPEC_TREE")) ctx->spec_tree = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_SPEC_FLAGS")) ctx->spec_flags = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_FILTER_FUSED")) ctx->filter_fused = std::atoi(e) != 0;
@@ -858,7 +820,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
                       &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
-                      &ctx->align_in, &ctx->align_scratch, &ctx->spec_queue, &ctx->spec_qaux, &ctx->spec_rec};
+                      &ctx->align_in, &ctx->align_scratch};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -885,8 +847,6 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
-    else if (n == "spec_tree") ctx->spec_tree = value != 0;
-    else if (n == "spec_flags") ctx->spec_flags = static_cast<int>(value);
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
     else if (n == "tree_tail_pct" && value >= 0 && value <= 100) ctx->tree_tail_pct = static_cast<int>(value);
     else if (n == "filter_fused") ctx->filter_fused = value != 0;
@@ -992,8 +952,8 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
 
     if (!ctx->stitch_host) {
         // block-sum scan: candidates must avoid the ragged ends of a window (min_width >= 8) and a window must fit
-        // the single-wave sweep (W <= 90 000); otherwise the LDS-window kernels take the call
-        bool use_bs = ctx->scan_bs && mw >= 8 && W <= 90000 && ctx->mode != MODE_EXACT;
+        // the single-wave sweep (at most 64 digest chunks: W <= 64 512); otherwise the LDS-window kernels take the call
+        bool use_bs = ctx->scan_bs && mw >= 8 && W <= 63 * 1024 && ctx->mode != MODE_EXACT;
         // Counts too wide for the 32-bit digest (K0 says so: RC_WIDE): the call is redone on the 64-bit digest, and if
         // that refuses too (|k - m| >= 2^23) on the LDS-window kernels.  The next 16 calls on the same grid start where
         // this one ended (counters[7]: 1 = 64-bit digest, 2 = LDS-window scan).
@@ -1117,7 +1077,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
                 tj.j0 = d < 0 ? 0 : static_cast<int32_t>(d / (W / 2)) + 1;
                 tj.out_cap = (an.pos - prev) / mw + 1;
                 tj.out_off = tscratch;
-                tj.ev = e; tj.pad_ = 0;
+                tj.m = 0; tj.pad_ = 0; tj.boff = 0;
                 tscratch += tj.out_cap;
                 it.job = static_cast<int32_t>(tjobs.size());
                 tjobs.push_back(tj);

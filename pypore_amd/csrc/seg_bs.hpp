@@ -1,25 +1,36 @@
 // seg_bs.hpp -- block-sum window scan: one WAVE scans one window, no LDS image of the samples.
 //
-// K0 (blocksum_kernel) streams the trace once.  Per 8 samples it forms S1 = sum (k-m) and
-// S2 = sum (k-m)^2 (m = first count of the event) and leaves their EXCLUSIVE prefix within each
-// chunk of 256 blocks (16 B per block), plus the chunk totals.  The exact sums of [ps, J) at any
-// block boundary J of a window are then one coalesced 16-byte load plus a per-chunk offset: a window
-// scan needs no per-sample work for the blocks the bound discards (98 % of them).  Lane L of the wave
-// takes boundaries L, L+64, ...: the boundary candidates are evaluated from the sums (centred per
-// candidate on the rounded mean, so D = n*p2 - p1^2 never cancels), the monotone block bound of
-// seg_device.hpp prunes with the neighbouring lane's values, and only surviving blocks read raw
-// samples.  No barrier, no cross-wave reduction, ~10 KB of LDS: 8-16 such workgroups fit a CU.
+// K0 (blocksum_kernel) streams the trace once.  Per 8 samples it forms S1 = sum (k-m) and S2 = sum (k-m)^2
+// (m = first count of the event) and leaves their EXCLUSIVE prefix within each chunk of 128 blocks -- 8 bytes per
+// block: 25 + 39 bits (|k-m| < 2^14), or 16 bytes (two int64) for the wide digest -- plus the chunk totals.  The exact
+// sums of [ps, J) at any block boundary J of a window are then one coalesced load plus a per-chunk offset that the
+// window keeps in registers: a window scan needs no per-sample work for the blocks the bound discards (98 % of them).
+// Lane L of the wave takes boundaries L, L+63, ...: the boundary candidates are evaluated from the sums
+// (D = n*S2 - S1^2 in fp64, everything after it in fp32), the monotone block bound prunes with the neighbouring lane's
+// values, and only surviving blocks read raw samples.  No barrier, no cross-wave reduction.
+//
+// Round 3: 8-byte digest (was 16), chunks of 128 blocks handled by half a wave in K0 (four consecutive
+// blocks per thread after a transposition through LDS: one half-wave scan per four blocks instead of a workgroup scan
+// per block), chunk offsets of a window in registers (v_readlane per row instead of an LDS table), the window's event
+// constants passed in by the caller (no per-window load of the event table), a scan body written for 128 registers
+// (four waves per SIMD instead of two) with its cold paths out of line.
+//
+// Reference functions restated here: cparsers.pyx:157-178 (_best_split_stepwise) through scan_window_bs,
+// core.py:209-223 (Segment statistics) through segstat_bs_kernel.
 //
 // Included by seg_device.hpp after the common helpers (screen arithmetic, DPP primitives, scan_exact).
 #pragma once
 
 namespace ps {
 
-constexpr int BS_WIDE = 23000;             // |k - m| must stay below this: 8 * BS_WIDE^2 < 2^32, n * BS_WIDE < 2^31
+constexpr int BS_WIDE = 16384;             // narrow digest: |k - m| must stay below this (a block's S2 < 2^31, a chunk prefix:
+                                           // |S1| < 2^24 -> 25 bits, S2 < 2^38 -> 39 bits; a window of 64 chunks: |S1| < 2^31)
 enum : unsigned { ST_WIDE_RANGE = 16u };
-constexpr int BS_CHUNK = 256;              // blocks per K0 workgroup = extent of one prefix chunk
+constexpr int BS_CHUNK = 128;              // blocks per prefix chunk (1024 samples): half a wave of K0
+constexpr int BS_CHUNK_LOG = 7;
+constexpr int BS_MAXCH = 64;               // chunks a window may touch (one lane each): windows up to 64 512 samples
 // Wide digest (DT & DT_WIDE): both moments as 64-bit integers -- (E1 lo, E1 hi, E2 lo, E2 hi) per block, the chunk
-// totals alike.  |k - m| < BSW_LIM: a block's S2 < 2^49, a chunk prefix < 2^57, a window of 90 000 samples < 2^62.5.
+// totals alike.  |k - m| < BSW_LIM: a block's S2 < 2^49, a chunk prefix < 2^56, a window of 64 512 samples < 2^62.
 // Made for events that were filtered and re-quantised on a fine grid (DataTypes.Event.parse: |count| < 2^22).
 constexpr int BSW_LIM = 1 << 23;
 template <int DT> constexpr bool bs_wide() { return (DT & DT_WIDE) != 0; }
@@ -29,21 +40,43 @@ __device__ __forceinline__ double d_of_i64(long long x)
 {
     return fma(static_cast<double>(static_cast<int>(x >> 32)), 4294967296.0, static_cast<double>(static_cast<unsigned>(x)));
 }
-
 __device__ __forceinline__ unsigned long long u64_of(unsigned lo, unsigned hi) { return (static_cast<unsigned long long>(hi) << 32) | lo; }
+// digest entry of the narrow format: hi = (E1 << 7) | (E2 >> 32), lo = E2 & 0xffffffff
+__device__ __forceinline__ int bs8_s1(uint2 v) { return static_cast<int>(v.y) >> 7; }
+__device__ __forceinline__ unsigned long long bs8_s2(uint2 v) { return u64_of(v.x, v.y & 0x7fu); }
+// 2^52 + E2 as a double, by bit pattern (E2 < 2^39): the caller adds (offset - 2^52), which is exact
+__device__ __forceinline__ double bs8_s2_biased(uint2 v) { return __hiloint2double(static_cast<int>((v.y & 0x7fu) | 0x43300000u), static_cast<int>(v.x)); }
+constexpr double BS_BIAS = 4503599627370496.0;        // 2^52
+__device__ __forceinline__ uint2 bs8_pack(int e1, unsigned long long e2)
+{
+    return make_uint2(static_cast<unsigned>(e2), (static_cast<unsigned>(e1) << 7) | static_cast<unsigned>(e2 >> 32));
+}
 
-// ---- K0 -----------------------------------------------------------------------------------------------
-// One thread per 8-sample block (global block index gb; event e owns blocks [ev_boff[e], ev_boff[e+1])).
-// bs[gb] = (E1, -, E2 as fp64): sums of the blocks of gb's chunk that precede gb (one entry past the last
-// block is written too: the end boundary of the last window).  chunk_tot[2*chunk] = (S1, -, S2 as fp64),
-// chunk_tot[2*chunk+1] = (max |k|, max |k-m|, -, -).
-// (the second moments are exact integers below 2^53 carried in fp64: the scan forms n*S2 - S1^2 there)
-// A chunk may straddle events (different m): only differences inside one event are ever formed.
-// Per-sample work is kept to the minimum the digest needs (the kernel is bound by vector-instruction issue as much
-// as by HBM: the first version spent 39 VALU instructions per sample): fp32 samples are checked for integrality in
-// float (x/q, v_rndne_f32, the difference OR-ed into one word), counts pass through min3 / max3 / add3 and one 24-bit
-// multiply-add each; the range checks (|k - m| < BS_WIDE, |k| < 2^23) are taken once per block from the block's
-// min and max.  A workgroup that lies inside one event (the common case) reads the event's tables with scalar loads.
+// ---- wave primitives of this file ---------------------------------------------------------------------
+// half-wave (32 lanes) inclusive scans: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast15 into rows 1 and 3
+#define PS_DPP_HALF_STEPS(X) X(0x111, 0xf) X(0x112, 0xf) X(0x114, 0xf) X(0x118, 0xf) X(0x142, 0xa)
+__device__ __forceinline__ int half_incl_scan_i32(int x)
+{
+#define PS_STEP(CTRL, RM) { x += dpp_mov<CTRL, RM>(0, x); }
+    PS_DPP_HALF_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+__device__ __forceinline__ long long half_incl_scan_i64(long long x)
+{
+#define PS_STEP(CTRL, RM) { const int lo_ = dpp_mov<CTRL, RM>(0, static_cast<int>(x)), hi_ = dpp_mov<CTRL, RM>(0, static_cast<int>(x >> 32)); \
+                            x += i64_of(lo_, hi_); }
+    PS_DPP_HALF_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+__device__ __forceinline__ int half_max_i32(int x)            // result in lanes 31 and 63
+{
+#define PS_STEP(CTRL, RM) { x = max(x, dpp_mov<CTRL, RM>(static_cast<int>(0x80000000), x)); }
+    PS_DPP_HALF_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
 __device__ __forceinline__ int wave_incl_scan_i32(int x)
 {
 #define PS_STEP(CTRL, RM) { x += dpp_mov<CTRL, RM>(0, x); }
@@ -73,179 +106,323 @@ __device__ __forceinline__ int wave_max_i32(int x)            // result in lane 
 #undef PS_STEP
     return x;
 }
+// uniform values into scalar registers (the compiler cannot prove uniformity of what comes out of LDS or a lane read)
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ double uni(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ long long uni(long long x)
+{
+    return i64_of(__builtin_amdgcn_readfirstlane(static_cast<int>(x)), __builtin_amdgcn_readfirstlane(static_cast<int>(x >> 32)));
+}
+// value of lane `l` (uniform index)
+__device__ __forceinline__ int lane_get(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ double lane_get(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ long long lane_get(long long x, int l)
+{
+    return i64_of(__builtin_amdgcn_readlane(static_cast<int>(x), l), __builtin_amdgcn_readlane(static_cast<int>(x >> 32), l));
+}
 
+// Arguments and results travel by value: the address of a caller's local (its `bad` word, its counters, the kernel's
+// DevCfg) would move that object to the stack for the whole kernel.  Results: low word = split, high word = status bits /
+// near-tie flag.
+struct BsCold { const void *samples; float inv_q; int off_counts; double q, q2; };
+__device__ __forceinline__ BsCold bs_cold(const DevCfg &c) { BsCold k = {c.samples, c.inv_q, c.off_counts, c.q, c.q2}; return k; }
+__device__ __forceinline__ DevCfg bs_cold_cfg(const BsCold &k)
+{
+    DevCfg c = {};
+    c.samples = k.samples; c.inv_q = k.inv_q; c.off_counts = k.off_counts; c.q = k.q; c.q2 = k.q2;
+    return c;
+}
+
+// ---- K0 -----------------------------------------------------------------------------------------------
+// Event e owns the blocks [ev_boff[e], ev_boff[e+1]) of the global block index gb (events back to back in block units;
+// a last partial block is padded with k = m).  A wave takes 256 consecutive blocks = two chunks:
+//   1. lane L loads blocks L, 64+L, 128+L, 192+L (coalesced: 2 KB per load instruction and block row) and forms their
+//      S1, S2, min, max -- per-sample work kept to what the digest needs: fp32 samples are checked for integrality in
+//      float (x/q, v_rndne_f32, the difference OR-ed into one word), counts pass through min3 / max3 / add3 and one
+//      24-bit multiply-add each; the range check (|k - m| < BS_WIDE) once per block from its min and max;
+//   2. the four records go through LDS (wave-local, no barrier) so that lane L then holds blocks 4L .. 4L+3: their
+//      prefix is three additions, and ONE half-wave scan (lanes 0..31 = chunk A, 32..63 = chunk B) per four blocks
+//      completes the chunk-exclusive prefix -- the second moments as two 16-bit halves in fused integer DPP additions;
+//   3. lane L writes its four consecutive digest entries (32 bytes) and, when statistics are wanted, the four min/max
+//      words; lanes 31 and 63 write the chunk totals (S1, max |k-m|, S2 as int64).
+// bs[gb]: prefix of the blocks of gb's chunk that precede gb (entries up to one past the last block are valid: the end
+// boundary of the last window; the arrays are padded to whole waves).  A chunk may straddle events (different m): only
+// differences inside one event are ever formed.
+#ifndef PS_K0_MINW
+#define PS_K0_MINW 5                                   // waves per SIMD K0 is compiled for (the fp32 instance takes 82 registers: eight 16-byte loads in flight per lane)
+#endif
+constexpr int K0_BPT = 4;                              // consecutive blocks per thread after the transposition
+constexpr int K0_WB = 64 * K0_BPT;                     // blocks per wave
+constexpr int K0_WAVES = 4;                            // waves per workgroup (independent of each other)
+__host__ __device__ inline long long k0_padded_blocks(long long nb_total) { return (nb_total + 1 + K0_WB - 1) / K0_WB * K0_WB; }
+
+template <int DT> struct K0Rec { int s1; unsigned s2; unsigned long long s2w; int ymin, ymax; };
+template <int DT> struct K0Gen { K0Rec<DT> r; int m; unsigned bad; };     // what the general route returns (by value: no stack objects)
+
+// sums of one block from its eight offsets y = k - m
 template <int DT>
-__global__ __launch_bounds__(256) void blocksum_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len,
-                                                       const int64_t *ev_boff, int n_ev, int64_t n_samples, int4 *bs,
-                                                       int4 *ev_info, int4 *chunk_tot, unsigned *status)
+__device__ __forceinline__ void k0_block_sums(const int (&y)[8], K0Rec<DT> &r)
 {
     constexpr bool WIDE = bs_wide<DT>();
-    __shared__ double w2[4];
-    __shared__ long long wl1[4], wl2[4];               // (wide digest)
-    __shared__ int w1[4], smax[4], symax[4];
-    const long long wg0 = blockIdx.x * 256LL;
-    const long long gb = wg0 + threadIdx.x;
-    const long long nb_total = ev_boff[n_ev];
+    r.s1 = 0; r.s2 = 0; r.s2w = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        r.s1 += y[q];
+        if constexpr (WIDE) r.s2w += static_cast<unsigned long long>(static_cast<long long>(y[q]) * static_cast<long long>(y[q]));
+        else r.s2 += static_cast<unsigned>(__mul24(y[q], y[q]));           // |y| < BS_WIDE < 2^23, else the call is redone
+    }
+    r.ymin = min(min(min(y[0], y[1]), min(y[2], y[3])), min(min(y[4], y[5]), min(y[6], y[7])));
+    r.ymax = max(max(max(y[0], y[1]), max(y[2], y[3])), max(max(y[4], y[5]), max(y[6], y[7])));
+}
+
+// eight aligned samples (raw: 32 bytes fp32 / 16 bytes int16) -> offsets from m
+template <int DT>
+__device__ __forceinline__ void k0_offsets(const DevCfg &c, const int4 *raw, int m, float mf, unsigned &nz, int (&y)[8])
+{
+    if (sdt(DT) == PS_DTYPE_F32) {
+        const f2 iq = {c.inv_q, c.inv_q};
+        const f2 mf2 = {mf, mf};
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma clang fp contract(off)                                              // (x/q rounded first, as in to_count)
+            const int w[4] = {raw[v].x, raw[v].y, raw[v].z, raw[v].w};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f2 x = {__int_as_float(w[2 * h]), __int_as_float(w[2 * h + 1])};
+                const f2 t = x * iq;
+                const f2 r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+                const f2 d = t - r;                                     // +0 exactly when t is an integer; NaN for inf/NaN
+                nz |= __float_as_uint(d.x) | __float_as_uint(d.y);
+                const f2 yf = r - mf2;                                  // exact while |r| < 2^24 (else: saturates below -> wide)
+                y[v * 4 + 2 * h] = static_cast<int>(yf.x);
+                y[v * 4 + 2 * h + 1] = static_cast<int>(yf.y);
+            }
+        }
+    } else {
+        const int w[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w};
+        const int om = c.off_counts - m;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            y[q] = ((q & 1) ? (w[q >> 1] >> 16) : static_cast<int>(static_cast<short>(w[q >> 1] & 0xffff))) + om;
+    }
+}
+
+// One block by the general route: any event layout, partial last blocks, unaligned int16 events.  Out of line: the
+// streaming route of the kernel keeps its registers to itself.
+template <int DT>
+__device__ __attribute__((noinline)) K0Gen<DT> k0_block_general(BsCold k, const int64_t *ev_start, const int64_t *ev_len, const int64_t *ev_boff,
+                                                                int64_t n_samples, long long gb, long long nb_total, int e_hint, int4 *ev_info)
+{
+    const DevCfg c = bs_cold_cfg(k);
+    K0Gen<DT> out;
+    K0Rec<DT> &r = out.r;
     unsigned bad = 0;
-    int mabs = 0, yabs = 0;                        // max |k| over the block's samples, max |k - m|
-    int s1 = 0;
-    unsigned s2 = 0;
-    unsigned long long s2w = 0;                        // (wide digest: 8 * 2^46)
-    // event of the workgroup's first block (uniform search)
+    r.s1 = 0; r.s2 = 0; r.s2w = 0; r.ymin = 0; r.ymax = 0;
+    out.m = 0; out.bad = 0;
+    if (gb >= nb_total) return out;                    // beyond the last block: empty (the end boundary's prefix is still written)
+    int e = e_hint;
+    while (ev_boff[e + 1] <= gb) ++e;                  // (empty events are stepped over)
+    const int64_t len = ev_len[e], base = ev_start[e];
+    const long long b = gb - ev_boff[e];
+    const int64_t i0 = 8 * b;
+    const int m = load_count<DT>(c, base, bad);
+    out.m = m;
+    int y[8];
+    const int cnt = static_cast<int>(len - i0 < 8 ? len - i0 : 8);
+    constexpr int ES = static_cast<int>(sizeof(typename Raw<DT>::type));
+    const char *p = static_cast<const char *>(c.samples) + (base + i0) * ES;
+    if (cnt == 8 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        constexpr int NV = 8 * ES / 16;
+        int4 raw[2];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) raw[v] = reinterpret_cast<const int4 *>(p)[v];
+        unsigned nz = 0;
+        k0_offsets<DT>(c, raw, m, static_cast<float>(m), nz, y);
+        if (nz) bad |= ST_OFF_GRID;
+        k0_block_sums<DT>(y, r);
+    } else if (sdt(DT) == PS_DTYPE_I16 && cnt == 8 && base + i0 >= 1 && base + i0 + 10 <= n_samples) {
+        // int16 block that is not 16-byte aligned (events cut out of a file trace start anywhere):
+        // dword loads, shifted by one sample when the block starts on an odd sample
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        const int *q4 = reinterpret_cast<const int *>(a & ~static_cast<uintptr_t>(3));
+        int v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] = q4[q];            // (v[4] is inside the array: one more sample follows)
+        const bool odd = (a & 2u) != 0;
+        const int om = c.off_counts - m;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int w = odd ? static_cast<int>((static_cast<unsigned>(v[q]) >> 16) | (static_cast<unsigned>(v[q + 1]) << 16)) : v[q];
+            y[2 * q] = static_cast<int>(static_cast<short>(w & 0xffff)) + om;
+            y[2 * q + 1] = (w >> 16) + om;
+        }
+        k0_block_sums<DT>(y, r);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) y[q] = q < cnt ? load_count<DT>(c, base + i0 + q, bad) - m : 0;   // padding = m: y = 0
+        k0_block_sums<DT>(y, r);
+        r.ymin = r.ymax = y[0];                    // (cnt >= 1: block b exists only if it holds a sample) over the real samples
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            if (q < cnt) { r.ymin = min(r.ymin, y[q]); r.ymax = max(r.ymax, y[q]); }
+    }
+    if (b == 0) ev_info[e] = make_int4(m, 0, static_cast<int>(ev_boff[e] & 0xffffffffLL), static_cast<int>(ev_boff[e] >> 32));
+    out.bad = bad;
+    return out;
+}
+
+template <int DT>
+__global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len,
+                                                                const int64_t *ev_boff, int n_ev, int64_t n_samples, void *bs_out,
+                                                                int4 *ev_info, int4 *chunk_tot, unsigned *status)
+{
+    constexpr bool WIDE = bs_wide<DT>();
+    constexpr int LIM = WIDE ? BSW_LIM : BS_WIDE;
+    constexpr int ES = static_cast<int>(sizeof(typename Raw<DT>::type));
+    constexpr int NV = 8 * ES / 16;                    // 16-byte vectors per block
+    __shared__ int4 tr[K0_WAVES][K0_WB];               // per wave: the records of its 256 blocks (transposition)
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(static_cast<int>(threadIdx.x >> 6));
+    const long long wb0 = (static_cast<long long>(blockIdx.x) * K0_WAVES + wave) * K0_WB;
+    const long long nb_total = ev_boff[n_ev];
+    if (wb0 > nb_total) return;                        // (waves are independent: no barrier in this kernel)
+    unsigned bad = 0;
+    // event of the wave's first block (uniform search)
     int e_first = 0;
     {
-        const long long gfirst = min(wg0, nb_total - 1);
-        int lo = 0, hi = n_ev - 1;                 // event e: ev_boff[e] <= gb < ev_boff[e+1]
+        const long long gfirst = min(wb0, nb_total - 1);
+        int lo = 0, hi = n_ev - 1;                     // event e: ev_boff[e] <= gb < ev_boff[e+1]
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (ev_boff[mid] <= gfirst) lo = mid; else hi = mid - 1;
         }
         e_first = lo;
     }
-    const bool one_event = wg0 + 255 < ev_boff[e_first + 1];     // the whole workgroup lies in event e_first (uniform)
-    if (gb < nb_total) {
-        int e = e_first;
-        int64_t len, base;
-        long long b;
-        if (one_event) {                           // uniform indices: scalar loads
-            len = ev_len[e_first]; base = ev_start[e_first]; b = gb - ev_boff[e_first];
-        } else {
-            while (ev_boff[e + 1] <= gb) ++e;      // (empty events are stepped over)
-            len = ev_len[e]; base = ev_start[e]; b = gb - ev_boff[e];
-        }
-        const int64_t i0 = 8 * b;
-        const int m = load_count<DT>(c, base, bad);
-        int y[8];
-        const int cnt = static_cast<int>(len - i0 < 8 ? len - i0 : 8);
-        constexpr int ES = static_cast<int>(sizeof(typename Raw<DT>::type));
-        const char *p = static_cast<const char *>(c.samples) + (base + i0) * ES;
-        int ymin, ymax;                            // over the block's real samples
-#define PS_MM8 { ymin = min(min(min(y[0], y[1]), min(y[2], y[3])), min(min(y[4], y[5]), min(y[6], y[7])));     \
-                 ymax = max(max(max(y[0], y[1]), max(y[2], y[3])), max(max(y[4], y[5]), max(y[6], y[7]))); }
-        if (cnt == 8 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
-            constexpr int NV = 8 * ES / 16;
-            int4 raw[NV];
+    int4 *mine = tr[wave];
+    auto put = [&](int k, const K0Rec<DT> &r) {        // record of block 64 k + lane, in load order
+        if (r.ymax >= LIM || r.ymin <= -LIM) bad |= ST_WIDE_RANGE;
+        if constexpr (WIDE) mine[64 * k + lane] = make_int4(r.s1, max(-r.ymin, r.ymax), static_cast<int>(r.s2w), static_cast<int>(r.s2w >> 32));
+        else mine[64 * k + lane] = make_int4(r.s1, static_cast<int>(r.s2), (r.ymin & 0xffff) | (r.ymax << 16), 0);
+    };
+    // fast route (uniform): the wave's 256 blocks are full blocks of one event, 16-byte aligned
+    const long long b_first = wb0 - ev_boff[e_first];
+    const int64_t len_f = ev_len[e_first], base_f = ev_start[e_first];
+    const bool fast = wb0 + K0_WB <= ev_boff[e_first + 1] && 8 * (b_first + K0_WB) <= len_f &&
+                      (((base_f + 8 * b_first) * ES) & 15) == 0 && nb_total > 0;
+    if (fast) {
+        const char *p0 = static_cast<const char *>(c.samples) + (base_f + 8 * (b_first + lane)) * ES;
+        int4 raw[K0_BPT][NV];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) raw[v] = reinterpret_cast<const int4 *>(p)[v];
+        for (int k = 0; k < K0_BPT; ++k)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) raw[k][v] = reinterpret_cast<const int4 *>(p0 + static_cast<long long>(k) * 64 * 8 * ES)[v];
+        const int m = load_count<DT>(c, base_f, bad);
+        const float mf = static_cast<float>(m);        // |m| < 2^23: exact
+        unsigned nz = 0;
+        // |count| < 2^23 for fp32 input: |k - m| < LIM is checked for every block, so only an m near the limit needs a look
+        const bool look = sdt(DT) == PS_DTYPE_F32 && (WIDE || m > 8388607 - LIM || m < -8388607 + LIM);
+#pragma unroll
+        for (int k = 0; k < K0_BPT; ++k) {
+            int y[8];
+            K0Rec<DT> r;
+            k0_offsets<DT>(c, raw[k], m, mf, nz, y);
+            k0_block_sums<DT>(y, r);
+            if (look) {
+                const int ka = m + r.ymin, kb = m + r.ymax;
+                if (max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb) >= 8388608) bad |= ST_OFF_GRID;
+            }
+            put(k, r);
+        }
+        if (nz) bad |= ST_OFF_GRID;
+        if (b_first + lane == 0) ev_info[e_first] = make_int4(m, 0, static_cast<int>(ev_boff[e_first] & 0xffffffffLL), static_cast<int>(ev_boff[e_first] >> 32));
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < K0_BPT; ++k) {
+            const K0Gen<DT> g = k0_block_general<DT>(bs_cold(c), ev_start, ev_len, ev_boff, n_samples, wb0 + 64 * k + lane, nb_total, e_first, ev_info);
+            bad |= g.bad;
             if (sdt(DT) == PS_DTYPE_F32) {
-                const f2 iq = {c.inv_q, c.inv_q};
-                const float mf = static_cast<float>(m);                    // |m| < 2^23: exact
-                const f2 mf2 = {mf, mf};
-                unsigned nz = 0;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-#pragma clang fp contract(off)                                              // (x/q rounded first, as in to_count)
-                    const int w[4] = {raw[v].x, raw[v].y, raw[v].z, raw[v].w};
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f2 x = {__int_as_float(w[2 * h]), __int_as_float(w[2 * h + 1])};
-                        const f2 t = x * iq;
-                        const f2 r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
-                        const f2 d = t - r;                                 // +0 exactly when t is an integer; NaN for inf/NaN
-                        nz |= __float_as_uint(d.x) | __float_as_uint(d.y);
-                        const f2 yf = r - mf2;                              // exact while |r| < 2^24 (else: saturates below -> wide)
-                        y[v * 4 + 2 * h] = static_cast<int>(yf.x);
-                        y[v * 4 + 2 * h + 1] = static_cast<int>(yf.y);
-                    }
-                }
-                if (nz) bad |= ST_OFF_GRID;
-                PS_MM8
-            } else {
-                const int w[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w};
-                const int om = c.off_counts - m;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    y[q] = ((q & 1) ? (w[q >> 1] >> 16) : static_cast<int>(static_cast<short>(w[q >> 1] & 0xffff))) + om;
-                PS_MM8
+                const int ka = g.m + g.r.ymin, kb = g.m + g.r.ymax;
+                if (max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb) >= 8388608) bad |= ST_OFF_GRID;     // |count| >= 2^23
             }
-        } else if (sdt(DT) == PS_DTYPE_I16 && cnt == 8 && base + i0 >= 1 && base + i0 + 10 <= n_samples) {
-            // int16 block that is not 16-byte aligned (events cut out of a file trace start anywhere):
-            // dword loads, shifted by one sample when the block starts on an odd sample
-            const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-            const int *q4 = reinterpret_cast<const int *>(a & ~static_cast<uintptr_t>(3));
-            int v[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) v[q] = q4[q];            // (v[4] is inside the array: one more sample follows)
-            const bool odd = (a & 2u) != 0;
-            const int om = c.off_counts - m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int w = odd ? static_cast<int>((static_cast<unsigned>(v[q]) >> 16) | (static_cast<unsigned>(v[q + 1]) << 16)) : v[q];
-                y[2 * q] = static_cast<int>(static_cast<short>(w & 0xffff)) + om;
-                y[2 * q + 1] = (w >> 16) + om;
-            }
-            PS_MM8
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) y[q] = q < cnt ? load_count<DT>(c, base + i0 + q, bad) - m : 0;   // padding = m: y = 0
-            ymin = ymax = y[0];                    // (cnt >= 1: block b exists only if it holds a sample)
-#pragma unroll
-            for (int q = 1; q < 8; ++q)
-                if (q < cnt) { ymin = min(ymin, y[q]); ymax = max(ymax, y[q]); }
+            put(k, g.r);
         }
-#undef PS_MM8
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            s1 += y[q];
-            if constexpr (WIDE) s2w += static_cast<unsigned long long>(static_cast<long long>(y[q]) * static_cast<long long>(y[q]));
-            else s2 += static_cast<unsigned>(__mul24(y[q], y[q]));         // |y| < BS_WIDE < 2^23, else the call is redone
-        }
-        constexpr int LIM = WIDE ? BSW_LIM : BS_WIDE;
-        if (ymax >= LIM || ymin <= -LIM) bad |= ST_WIDE_RANGE;
-        const int ka = m + ymin, kb = m + ymax;
-        mabs = max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb);
-        yabs = max(-ymin, ymax);
-        if (sdt(DT) == PS_DTYPE_F32 && mabs >= 8388608) bad |= ST_OFF_GRID;     // |count| >= 2^23
-        if (!WIDE && c.blk_mm) c.blk_mm[gb] = (ymin & 0xffff) | (ymax << 16);      // (|y| < BS_WIDE fits int16; otherwise the call is redone)
-        if (b == 0) ev_info[e] = make_int4(m, 0, static_cast<int>(ev_boff[e] & 0xffffffffLL), static_cast<int>(ev_boff[e] >> 32));
     }
-    // exclusive prefix over the workgroup: first moments in int32 (256 * 8 * BS_WIDE < 2^31), second moments as exact
-    // integers in fp64
-    mabs = wave_max_i32(mabs);
-    yabs = wave_max_i32(yabs);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the records went through LDS in load order (block 64 k + L); read back as blocks 4 L .. 4 L + 3
+    ps_sync<64>();                                     // wave-local hand-over (the waves of the workgroup are independent)
+    int4 t[K0_BPT];
+#pragma unroll
+    for (int j = 0; j < K0_BPT; ++j) t[j] = mine[K0_BPT * lane + j];
+    const long long gb4 = wb0 + K0_BPT * lane;        // first of this lane's four consecutive blocks
+    const long long chunk = (wb0 >> BS_CHUNK_LOG) + (lane >> 5);
     if constexpr (WIDE) {
-        const long long i1 = wave_incl_scan_i64(static_cast<long long>(s1));
-        const long long i2 = wave_incl_scan_i64(static_cast<long long>(s2w));
-        if (lane == 63) { wl1[wave] = i1; wl2[wave] = i2; smax[wave] = mabs; symax[wave] = yabs; }
-        __syncthreads();
-        long long o1 = 0, o2 = 0;
-        for (int w = 0; w < wave; ++w) { o1 += wl1[w]; o2 += wl2[w]; }
-        if (gb <= nb_total) {
-            const long long e1 = o1 + i1 - s1, e2 = o2 + i2 - static_cast<long long>(s2w);
-            bs[gb] = make_int4(static_cast<int>(e1), static_cast<int>(e1 >> 32), static_cast<int>(e2), static_cast<int>(e2 >> 32));
+        // in-thread prefix, then one half-wave scan of the four-block totals (64-bit)
+        long long e1[K0_BPT], e2[K0_BPT];
+        long long r1 = 0, r2 = 0;
+        int yabs = 0;
+#pragma unroll
+        for (int j = 0; j < K0_BPT; ++j) {
+            e1[j] = r1; e2[j] = r2;
+            r1 += t[j].x; r2 += i64_of(t[j].z, t[j].w);
+            yabs = max(yabs, t[j].y);
         }
-        if (threadIdx.x == 255) {
-            const long long t1 = o1 + i1, t2 = o2 + i2;
-            chunk_tot[2 * blockIdx.x] = make_int4(static_cast<int>(t1), static_cast<int>(t1 >> 32), static_cast<int>(t2), static_cast<int>(t2 >> 32));
+        const long long i1 = half_incl_scan_i64(r1), i2 = half_incl_scan_i64(r2);
+        const long long x1 = i1 - r1, x2 = i2 - r2;
+        int4 *bs = static_cast<int4 *>(bs_out) + gb4;
+#pragma unroll
+        for (int j = 0; j < K0_BPT; ++j) {
+            const long long a1 = x1 + e1[j], a2 = x2 + e2[j];
+            bs[j] = make_int4(static_cast<int>(a1), static_cast<int>(a1 >> 32), static_cast<int>(a2), static_cast<int>(a2 >> 32));
+        }
+        yabs = half_max_i32(yabs);
+        if ((lane & 31) == 31) {
+            chunk_tot[2 * chunk] = make_int4(static_cast<int>(i1), static_cast<int>(i1 >> 32), static_cast<int>(i2), static_cast<int>(i2 >> 32));
+            chunk_tot[2 * chunk + 1] = make_int4(yabs, 0, 0, 0);
         }
     } else {
-        const int i1 = wave_incl_scan_i32(s1);
-        const double i2 = wave_incl_scan_f64(static_cast<double>(s2));
-        if (lane == 63) { w1[wave] = i1; w2[wave] = i2; smax[wave] = mabs; symax[wave] = yabs; }
-        __syncthreads();
-        int o1 = 0;
-        double o2 = 0.0;
-        for (int w = 0; w < wave; ++w) { o1 += w1[w]; o2 += w2[w]; }
-        if (gb <= nb_total) {
-            const int e1 = o1 + i1 - s1;
-            const double e2 = (o2 + i2) - static_cast<double>(s2);
-            bs[gb] = make_int4(e1, 0, __double2loint(e2), __double2hiint(e2));
+        int e1[K0_BPT];
+        unsigned long long e2[K0_BPT];
+        int r1 = 0;
+        unsigned long long r2 = 0;                     // four blocks: < 2^33
+#pragma unroll
+        for (int j = 0; j < K0_BPT; ++j) {
+            e1[j] = r1; e2[j] = r2;
+            r1 += t[j].x; r2 += static_cast<unsigned>(t[j].y);
         }
-        if (threadIdx.x == 255) {
-            const double t2 = o2 + i2;
-            chunk_tot[2 * blockIdx.x] = make_int4(o1 + i1, 0, __double2loint(t2), __double2hiint(t2));
+        // min / max of the four blocks (packed int16 pairs: low half min, high half max)
+        const int mmn = min(min(static_cast<int>(static_cast<short>(t[0].z & 0xffff)), static_cast<int>(static_cast<short>(t[1].z & 0xffff))),
+                            min(static_cast<int>(static_cast<short>(t[2].z & 0xffff)), static_cast<int>(static_cast<short>(t[3].z & 0xffff))));
+        const int mmx = max(max(t[0].z >> 16, t[1].z >> 16), max(t[2].z >> 16, t[3].z >> 16));
+        int yabs = max(-mmn, mmx);
+        const int i1 = half_incl_scan_i32(r1);
+        const int r2lo = static_cast<int>(r2 & 0xffffu), r2hi = static_cast<int>(r2 >> 16);      // < 2^16, < 2^17: 32 lanes < 2^22
+        const int ilo = half_incl_scan_i32(r2lo), ihi = half_incl_scan_i32(r2hi);
+        const int x1 = i1 - r1;
+        const unsigned long long x2 = (static_cast<unsigned long long>(static_cast<unsigned>(ihi - r2hi)) << 16) + static_cast<unsigned>(ilo - r2lo);
+        uint2 ent[K0_BPT];
+#pragma unroll
+        for (int j = 0; j < K0_BPT; ++j) ent[j] = bs8_pack(x1 + e1[j], x2 + e2[j]);
+        uint4 *bs = reinterpret_cast<uint4 *>(static_cast<uint2 *>(bs_out) + gb4);
+        bs[0] = make_uint4(ent[0].x, ent[0].y, ent[1].x, ent[1].y);
+        bs[1] = make_uint4(ent[2].x, ent[2].y, ent[3].x, ent[3].y);
+        if (c.blk_mm) *reinterpret_cast<int4 *>(c.blk_mm + gb4) = make_int4(t[0].z, t[1].z, t[2].z, t[3].z);
+        yabs = half_max_i32(yabs);
+        if ((lane & 31) == 31) {
+            const unsigned long long tot2 = (static_cast<unsigned long long>(static_cast<unsigned>(ihi)) << 16) + static_cast<unsigned>(ilo);
+            chunk_tot[chunk] = make_int4(i1, yabs, static_cast<int>(tot2), static_cast<int>(tot2 >> 32));
         }
     }
-    if (threadIdx.x == 255)
-        chunk_tot[2 * blockIdx.x + 1] = make_int4(max(max(smax[0], smax[1]), max(smax[2], smax[3])),
-                                                  max(max(symax[0], symax[1]), max(symax[2], symax[3])), 0, 0);
     if (bad) atomicOr(status, bad);
 }
 
 // ---- screen arithmetic from window-relative sums ------------------------------------------------------
 struct BsEval { float g; f2 lg; f2 r; bool okL, okR; };
-__device__ __forceinline__ double ent2(const int4 &v) { return __hiloint2double(v.w, v.z); }
 
 // Screened gain of the split (nl | nr) from the exact sums about m of the left part (a1, a2) and the right
 // part (b1, b2).  D = n*S2 - S1^2 is formed in fp64 (relative error kappa_m * 2^-52 with kappa_m = n*S2/D
@@ -270,25 +447,15 @@ __device__ __forceinline__ BsEval bs_eval(double a1d, double a2, double b1d, dou
     return o;
 }
 
+
 struct BsQ { int j, a1; double a2; };                     // queued block (J-8, J): its end J, sums of [ps, J)
 struct BsC { int j, a1; double a2; float g; int pad; };   // contender: candidate, its exact sums, screened gain
-struct BsOff { int o1, pad; double o2; };                 // sums of the window's chunks before this one (+ the window constant)
-// the same three for the wide digest (64-bit integer sums; |S1| < 2^40 shares a word with the window-relative position)
+// the same for the wide digest (64-bit integer sums; |S1| < 2^40 shares a word with the window-relative position)
 struct BsQW { long long ja, a2; };                        // ja = S1 * 2^18 + (J - ps)
 struct BsCW { int j; float g; long long a1, a2; };
-struct BsOffW { long long o1, o2; };
-static_assert(sizeof(BsQW) == sizeof(BsQ) && sizeof(BsCW) == sizeof(BsC) && sizeof(BsOffW) == sizeof(BsOff), "LDS layout shared by both digests");
-template <bool WIDE> struct BsTypes { typedef int s1_t; typedef double s2_t; typedef BsQ Q; typedef BsC C; typedef BsOff Off; };
-template <> struct BsTypes<true> { typedef long long s1_t; typedef long long s2_t; typedef BsQW Q; typedef BsCW C; typedef BsOffW Off; };
-// moments of a digest entry; conversions to the fp64 the screen computes in
-template <bool WIDE> __device__ __forceinline__ typename BsTypes<WIDE>::s1_t bs_s1(const int4 &v)
-{
-    if constexpr (WIDE) return i64_of(v.x, v.y); else return v.x;
-}
-template <bool WIDE> __device__ __forceinline__ typename BsTypes<WIDE>::s2_t bs_s2(const int4 &v)
-{
-    if constexpr (WIDE) return i64_of(v.z, v.w); else return __hiloint2double(v.w, v.z);
-}
+static_assert(sizeof(BsQW) == sizeof(BsQ) && sizeof(BsCW) == sizeof(BsC), "LDS layout shared by both digests");
+template <bool WIDE> struct BsTypes { typedef int s1_t; typedef double s2_t; typedef BsQ Q; typedef BsC C; typedef uint2 E; typedef double o2_t; };
+template <> struct BsTypes<true> { typedef long long s1_t; typedef long long s2_t; typedef BsQW Q; typedef BsCW C; typedef int4 E; typedef long long o2_t; };
 __device__ __forceinline__ double bs_d(int x) { return static_cast<double>(x); }
 __device__ __forceinline__ double bs_d(double x) { return x; }
 __device__ __forceinline__ double bs_d(long long x) { return d_of_i64(x); }
@@ -298,15 +465,21 @@ __device__ __forceinline__ int bs_q_j(const BsQ &q, int ps) { return q.j; }
 __device__ __forceinline__ int bs_q_j(const BsQW &q, int ps) { return ps + static_cast<int>(q.ja & 262143LL); }
 __device__ __forceinline__ int bs_q_a1(const BsQ &q) { return q.a1; }
 __device__ __forceinline__ long long bs_q_a1(const BsQW &q) { return q.ja >> 18; }
+// exact sums of [ps, J) at a digest entry: entry + the offset of its chunk.  Narrow digest: the second moment comes
+// out of the entry as the double 2^52 + E2 (bit pattern), the chunk offset carries -2^52: one exact fp64 addition.
+__device__ __forceinline__ int bs_a1(uint2 e, int o1) { return bs8_s1(e) + o1; }
+__device__ __forceinline__ double bs_a2(uint2 e, double k2) { return bs8_s2_biased(e) + k2; }
+__device__ __forceinline__ long long bs_a1(const int4 &e, long long o1) { return i64_of(e.x, e.y) + o1; }
+__device__ __forceinline__ long long bs_a2(const int4 &e, long long o2) { return i64_of(e.z, e.w) + o2; }
 constexpr int BS_NC = 64;                                 // contenders kept per window
 #ifndef PS_BS_G
-#define PS_BS_G 5
+#define PS_BS_G 2
 #endif
-constexpr int BS_G = PS_BS_G;                             // rows per group (loads in flight)
+constexpr int BS_G = PS_BS_G;                             // rows per group (loads in flight: two groups)
 constexpr int BS_QN = 64 * BS_G + 64;                     // queued blocks; a drain is forced when a group may not fit
 constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
-static_assert(sizeof(QEnt) * SharedT<64>::QN >= sizeof(BsQ) * BS_QN + sizeof(BsC) * BS_NC + 64 * 32 + 64 * sizeof(BsOff),
-              "SharedT<64>::q too small");             // (64 * 32: staged blocks of the wide digest, 8 int32 each)
+constexpr int BS_LDS_BYTES = static_cast<int>(sizeof(BsQ)) * BS_QN + static_cast<int>(sizeof(BsC)) * BS_NC + 64 * 32;
+static_assert(sizeof(QEnt) * SharedT<64>::QN >= BS_LDS_BYTES, "SharedT<64>::q too small");   // (64 * 32: staged blocks of the wide digest, 8 int32 each)
 
 // Exact (reference-order, fp64) gain of one candidate from its exact integer sums about m.
 __device__ __forceinline__ double bs_exact_gain(const DevCfg &c, int m, int a1, double a2, int T1, double T2, int nl, int n,
@@ -337,117 +510,234 @@ __device__ __forceinline__ float from_lane_below(float x) { return __int_as_floa
 // Value of lane+1 (wave_shl:1); lane 63 keeps its own.
 __device__ __forceinline__ int from_lane_above(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ float from_lane_above(float x) { return __int_as_float(from_lane_above(__float_as_int(x))); }
+// sum over lanes 8 j .. 8 j + 7 of each group of eight, in lane 8 j + 7 (three row_shr steps)
+__device__ __forceinline__ int oct_sum(int x)
+{
+    x += dpp_mov<0x111, 0xf>(0, x); x += dpp_mov<0x112, 0xf>(0, x); x += dpp_mov<0x114, 0xf>(0, x);
+    return x;
+}
+__device__ __forceinline__ long long oct_sum(long long x)
+{
+#define PS_STEP(CTRL) { const int lo_ = dpp_mov<CTRL, 0xf>(0, static_cast<int>(x)), hi_ = dpp_mov<CTRL, 0xf>(0, static_cast<int>(x >> 32)); x += i64_of(lo_, hi_); }
+    PS_STEP(0x111) PS_STEP(0x112) PS_STEP(0x114)
+#undef PS_STEP
+    return x;
+}
 
-// One wave scans the window [ps, pe) of event `ev` (samples at c.samples[base + .]).
+// ---- cold paths of the scan, out of line (they hold the fp64 logarithms and divisions: inlined they would set the
+//      register count of the whole kernel) --------------------------------------------------------------------------
+template <int DT>
+__device__ __attribute__((noinline)) long long bs_scan_exact(BsCold k, int64_t g0, int ps, int n, int cand_lo, int cand_hi,
+                                                             double thresh, SharedT<64> *sh)
+{
+    const DevCfg c = bs_cold_cfg(k);
+    unsigned bad = 0;
+    const int r = scan_exact<64, DT>(c, nullptr, g0, ps, n, cand_lo, cand_hi, thresh, nullptr, *sh, bad, nullptr);
+    return (static_cast<long long>(bad) << 32) | static_cast<unsigned>(r);
+}
+
+// The contenders (at most 64, one per lane) decided with the reference's fp64 arithmetic; first maximum wins.
+template <int DT>
+__device__ __attribute__((noinline)) long long bs_decide(BsCold k, int m, const void *cont_v, int ccount, int ps, int n,
+                                                         typename BsTypes<bs_wide<DT>()>::s1_t T1, typename BsTypes<bs_wide<DT>()>::s2_t T2,
+                                                         double thresh)
+{
+    const DevCfg cfg = bs_cold_cfg(k);
+    const DevCfg *c = &cfg;
+    int near = 0;
+    constexpr bool WIDE = bs_wide<DT>();
+    typedef typename BsTypes<WIDE>::C BsC_t;
+    const BsC_t *cont = static_cast<const BsC_t *>(cont_v);
+    const int lane = threadIdx.x & 63;
+    const double T1d = bs_d(T1), T2d = bs_d(T2), dn = static_cast<double>(n);
+    double var_summed;
+    if constexpr (WIDE) var_summed = dn * log(ref_var(T1d, T2d, n, c->q, c->q2));
+    else var_summed = dn * log(ref_var(T1d + dn * static_cast<double>(m),
+                                       T2d + 2.0 * static_cast<double>(m) * T1d + dn * static_cast<double>(m) * static_cast<double>(m), n, c->q, c->q2));
+    double eg = thresh;
+    int ei = -1;
+    double gx = -INFINITY;
+    if (lane < ccount) {
+        const BsC_t e = cont[lane];
+        if constexpr (WIDE) {
+            const int nl = e.j - ps;
+            gx = ref_gain(var_summed, nl, ref_var(d_of_i64(e.a1), d_of_i64(e.a2), nl, c->q, c->q2),
+                          n - nl, ref_var(d_of_i64(T1 - e.a1), d_of_i64(T2 - e.a2), n - nl, c->q, c->q2));
+        } else {
+            gx = bs_exact_gain(*c, m, e.a1, e.a2, T1, T2, e.j - ps, n, var_summed);
+        }
+        if (gx > eg) { eg = gx; ei = e.j; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double og = __shfl_xor(eg, d);
+        const int oi = __shfl_xor(ei, d);
+        if (beats(og, oi, eg, ei)) { eg = og; ei = oi; }
+    }
+    // Near-tie accounting: the device logarithm is not glibc's bit for bit, gains carry ~1e-11 of absolute
+    // error.  A decision whose margin -- winner against the best other contender, or against the threshold -- lies inside
+    // 1e-9 * max(1, |gain|) could have gone the other way in the reference: counted, reported by ps_get_timings.
+    if (ei >= 0) {
+        double other = (lane < ccount && cont[lane].j != ei) ? gx : -INFINITY;      // NaN gains never win and never tie
+        if (!(other == other)) other = -INFINITY;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) other = fmax(other, __shfl_xor(other, d));
+        const double tol = 1.0e-9 * fmax(1.0, fabs(eg));
+        near = (eg - other < tol || eg - thresh < tol) ? 1 : 0;
+    } else {
+        double best = (lane < ccount && gx == gx) ? gx : -INFINITY;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) best = fmax(best, __shfl_xor(best, d));
+        const double tol = 1.0e-9 * fmax(1.0, fabs(thresh));
+        near = thresh - best < tol ? 1 : 0;
+    }
+    return (static_cast<long long>(near) << 32) | static_cast<unsigned>(ei);
+}
+
+// One wave scans the window [ps, pe) of an event (samples at c.samples[base + .], event constants `er`).
 //
-// Phase 0 (every window): in row r lane L takes block boundary t = 63 r + L (J = g0 + 8t; lane 0 repeats
-// the previous row's last boundary so that every block finds its left neighbour one lane below): sums of
-// [ps, J) from the K0 prefix, boundary candidate evaluated, the block (J-8, J) bounded with the lane
-// below's left-side values and queued in LDS if it survives (slots from a ballot, no atomics); the queue
-// is drained -- interior candidates evaluated from raw samples -- when it may overflow and at the end.
-// Top-2 over the wave decides.
-// Phase 1 (ambiguous windows only, ~1 %): the same sweep with the final maximum known collects the
-// contenders (screened gain within 3 delta of the decision level) and the reference's fp64 arithmetic
-// picks among them.  A whole-window fp64 scan remains for guard failures and contender overflow.
+// Setup (one memory round trip): the ragged head / tail samples, the totals of the <= 64 chunks the window touches (one
+// lane each), the digest entries at the window's first and last boundary, one sampled boundary per lane and the first
+// rows -- all issued together.  A scan of the chunk totals gives every chunk's offset, kept in the registers of lane c:
+// a(t) = E[t] + off[chunk(t)] are the exact sums of [ps, g0 + 8 t) about m.
+// Phase 0 (every window): in row r lane L takes block boundary t = 63 r + L (J = g0 + 8t; lane 0 repeats the previous
+// row's last boundary so that every block finds its left neighbour one lane below); a row touches at most two chunks,
+// whose offsets come from two v_readlane.  The boundary candidate is evaluated, the block (J-8, J) bounded with the
+// lane below's left-side values and queued in LDS if it survives (slots from a ballot, no atomics); the queue is
+// drained -- interior candidates evaluated from raw samples -- when it may overflow and at the end.  The wave maximum
+// decides the common case (no split); top-2 only when something reaches the threshold band.
+// Phase 1 (ambiguous windows only, ~1 %): the same sweep with the final maximum known collects the contenders
+// (screened gain within 3 delta of the decision level) and the reference's fp64 arithmetic picks among them
+// (bs_decide).  A whole-window fp64 scan remains for guard failures and contender overflow.
 template <int DT, bool ROWSKIP = true>
-__device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
+__device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                               double thresh, SharedT<64> &sh, unsigned &bad, Work &wk)
 {
     constexpr bool WIDE = bs_wide<DT>();
     typedef typename BsTypes<WIDE>::s1_t s1_t;         // first / second moments about m: int32 / fp64 (exact integers), or
     typedef typename BsTypes<WIDE>::s2_t s2_t;         // both int64 with the wide digest
+    typedef typename BsTypes<WIDE>::o2_t o2_t;         // second-moment offset of a chunk: fp64 minus 2^52 / int64
     typedef typename BsTypes<WIDE>::Q BsQ_t;
     typedef typename BsTypes<WIDE>::C BsC_t;
-    typedef typename BsTypes<WIDE>::Off BsOff_t;
+    typedef typename BsTypes<WIDE>::E ent_t;           // digest entry: 8 / 16 bytes
     const int lane = threadIdx.x & 63;                 // (one wave; possibly one of several in its workgroup)
     const int n = pe - ps;
     const int g0 = (ps + 7) & ~7, g1 = pe & ~7;
     const int nblk = (g1 - g0) >> 3;
-    if (nblk < 4 || n > 90000 || c.mode == MODE_EXACT || cand_lo < g0 || cand_hi > g1) {
-        // tiny window, or candidates in the ragged head/tail (min_width < 8): exact scan straight from HBM
-        if (lane == 0) wk.exact += 1;
-        return scan_exact<64, DT>(c, nullptr, base + ps, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);
+    const long long gb0 = er.boff + (g0 >> 3);
+    const int gbl = static_cast<int>(gb0 & (BS_CHUNK - 1));            // chunk of boundary t: (gbl + t) >> 7
+    const int nch = ((gbl + nblk) >> BS_CHUNK_LOG) + 1;                // chunks touched
+    if (nblk < 4 || nch > BS_MAXCH || c.mode == MODE_EXACT || cand_lo < g0 || cand_hi > g1) {
+        // tiny or huge window, or candidates in the ragged head/tail (min_width < 8): exact scan straight from HBM
+        wk.exact += 1;                                 // (counters are wave-uniform: scalar registers; lane 0 reports them)
+        const long long ex = bs_scan_exact<DT>(bs_cold(c), base + ps, ps, n, cand_lo, cand_hi, thresh, &sh);
+        bad |= static_cast<unsigned>(ex >> 32);
+        return uni(static_cast<int>(ex));
     }
-    const int4 info = c.ev_info[ev];
-    const int m = info.x;
-    const long long gb0 = ((static_cast<long long>(static_cast<unsigned>(info.w)) << 32) | static_cast<unsigned>(info.z)) + (g0 >> 3);
-    const int4 *bsw = c.bsum + gb0;                                    // bsw[t]: chunk prefix at boundary t = 0..nblk
-    const int c0 = static_cast<int>(gb0 >> 8), nch = static_cast<int>((gb0 + nblk) >> 8) - c0 + 1;     // chunks touched (<= 45)
-    const int gbl = static_cast<int>(gb0 & 255);                       // chunk of boundary t: (gbl + t) >> 8
-    PS_STAMP_AT(wk, 5);                                // (diagnostic) entry, event info
+    const int m = er.m;
+    const ent_t *bsw = static_cast<const ent_t *>(c.bsum) + gb0;      // bsw[t]: chunk prefix at boundary t = 0..nblk
+    const long long c0 = gb0 >> BS_CHUNK_LOG;
+    const int rows = (nblk + BS_STRIDE - 1) / BS_STRIDE;               // nblk + 1 boundaries, 63 new ones per row
+    auto row_load = [&](int r) { return bsw[min(max(r, 0) * BS_STRIDE + lane, nblk)]; };
     // everything the window needs before its first boundary, issued together
     const int nh = g0 - ps, nt = pe - g1;              // ragged head [ps, g0) and tail [g1, pe): <= 7 raw samples each
     int yht = 0;
     if (lane < nh) yht = load_count<DT>(c, base + ps + lane, bad) - m;
     if (lane >= 32 && lane - 32 < nt) yht = load_count<DT>(c, base + g1 + (lane - 32), bad) - m;
-    int4 ct = make_int4(0, 0, 0, 0), cm = make_int4(0, 0, 0, 0);
-    if (lane < nch) { ct = c.chunk_tot[2 * (c0 + lane)]; cm = c.chunk_tot[2 * (c0 + lane) + 1]; }
-    const int4 e0 = bsw[0], eN = bsw[nblk];
-    const int nbnd = nblk + 1;
-    const int rows = (nbnd - 1 + BS_STRIDE - 1) / BS_STRIDE;           // nbnd >= 5
-    const int4 row0 = bsw[min(lane, nblk)];
+    int4 ct = make_int4(0, 0, 0, 0);
+    int yab = 0;
+    if (lane < nch) {
+        if constexpr (WIDE) { ct = c.chunk_tot[2 * (c0 + lane)]; yab = c.chunk_tot[2 * (c0 + lane) + 1].x; }
+        else { ct = c.chunk_tot[c0 + lane]; yab = ct.y; }
+    }
+    const ent_t e0 = bsw[0], eN = bsw[nblk];
     const int tS = min(nblk, lane * rows);             // one sampled boundary per lane, spread over the window
-    const int4 smp = bsw[tS];
-    // head/tail sums (one scan: lanes 0..31 head, 32..63 tail), chunk offsets (exclusive scan of the totals)
-    double hs1 = static_cast<double>(yht), hs2 = static_cast<double>(yht) * static_cast<double>(yht);
-    wave_incl_scan2(hs1, hs2);
-    const double H1d = __shfl(hs1, 31), H2d = __shfl(hs2, 31);
-    const double TL1d = __shfl(hs1, 63) - H1d, TL2d = __shfl(hs2, 63) - H2d;
-    const s1_t cs1 = bs_s1<WIDE>(ct);
-    const s2_t cs2 = bs_s2<WIDE>(ct);
-    s1_t cx1;                                          // sums of the chunks before this lane's
-    s2_t cx2;
+    const ent_t smp = bsw[tS];
+    ent_t ga[BS_G], gb[BS_G];                          // two groups of rows: the next group's loads are in flight while this one is evaluated
+#pragma unroll
+    for (int i = 0; i < BS_G; ++i) ga[i] = row_load(i);
+    // head / tail sums (lanes 0..7 head, 32..39 tail)
+    s1_t H1, TL1;
+    s2_t H2, TL2;
     if constexpr (WIDE) {
-        cx1 = wave_incl_scan_i64(cs1) - cs1;
-        cx2 = wave_incl_scan_i64(cs2) - cs2;
+        const long long h1 = oct_sum(static_cast<long long>(yht)), h2 = oct_sum(static_cast<long long>(yht) * static_cast<long long>(yht));
+        H1 = lane_get(h1, 7); H2 = lane_get(h2, 7); TL1 = lane_get(h1, 39); TL2 = lane_get(h2, 39);
     } else {
-        double ci1 = static_cast<double>(cs1), ci2 = cs2;
-        wave_incl_scan2(ci1, ci2);
-        cx1 = static_cast<int>(ci1 - static_cast<double>(cs1));
-        cx2 = ci2 - cs2;
+        const int h1 = oct_sum(yht), h2 = oct_sum(yht * yht);      // 7 * 2^28 < 2^31
+        H1 = lane_get(h1, 7); H2 = static_cast<double>(lane_get(h2, 7)); TL1 = lane_get(h1, 39); TL2 = static_cast<double>(lane_get(h2, 39));
     }
-    int mabs = cm.x, nymax = -cm.y;                     // max |k| and max |k-m| over the chunks touched
-    wave_minmax(nymax, mabs);                          // (the min slot carries -max |k-m|)
-    mabs = __shfl(mabs, 63);
-    const float ymaxf = static_cast<float>(-__shfl(nymax, 63));
-    BsQ_t *queue = reinterpret_cast<BsQ_t *>(sh.q);
-    BsC_t *cont = reinterpret_cast<BsC_t *>(queue + BS_QN);
-    int4 *ybuf = reinterpret_cast<int4 *>(cont + BS_NC);               // 64 staged blocks: 8 int16 offsets (wide digest: 8 int32)
-    BsOff_t *coff = reinterpret_cast<BsOff_t *>(ybuf + 128);
-    // a(t) = E[t] + off[chunk(t)] : sums of [ps, g0 + 8t) about m  (off includes the head and -E[0])
-    // (head and tail: at most 7 samples each, their sums are small exact integers in fp64)
-    const s1_t K1 = static_cast<s1_t>(H1d) - bs_s1<WIDE>(e0);
-    const s2_t K2 = static_cast<s2_t>(H2d) - bs_s2<WIDE>(e0);
-    ps_sync<64>();                                  // previous user of sh.q (this wave) is done
+    // chunk offsets: exclusive scan of the chunk totals over the lanes (rows of 16 suffice for windows up to 15 000 samples)
+    const bool many = nch > 16;                        // (uniform)
+    s1_t off1;                                         // lane c: sums of [ps, first boundary of chunk c) minus that chunk's prefix base
+    o2_t off2;
+    s1_t T1;
+    s2_t T2;
+    int yabs = yab;
     {
-        BsOff_t o;
-        if constexpr (!WIDE) o.pad = 0;
-        o.o1 = cx1 + K1; o.o2 = cx2 + K2;
-        coff[lane] = o;
+#define PS_ROW_STEPS(X) X(0x111, 0xf) X(0x112, 0xf) X(0x114, 0xf) X(0x118, 0xf)
+#define PS_BC_STEPS(X) X(0x142, 0xa) X(0x143, 0xc)
+#define PS_MSTEP(CTRL, RM) { yabs = max(yabs, dpp_mov<CTRL, RM>(0, yabs)); }
+        PS_ROW_STEPS(PS_MSTEP)
+        if (many) { PS_BC_STEPS(PS_MSTEP) }
+#undef PS_MSTEP
+        yabs = lane_get(yabs, many ? 63 : 15);
+        if constexpr (WIDE) {
+            const long long cs1 = i64_of(ct.x, ct.y), cs2 = i64_of(ct.z, ct.w);
+            long long i1 = cs1, i2 = cs2;
+#define PS_STEP(CTRL, RM) { const int l1_ = dpp_mov<CTRL, RM>(0, static_cast<int>(i1)), h1_ = dpp_mov<CTRL, RM>(0, static_cast<int>(i1 >> 32)); \
+                            const int l2_ = dpp_mov<CTRL, RM>(0, static_cast<int>(i2)), h2_ = dpp_mov<CTRL, RM>(0, static_cast<int>(i2 >> 32)); \
+                            i1 += i64_of(l1_, h1_); i2 += i64_of(l2_, h2_); }
+            PS_ROW_STEPS(PS_STEP)
+            if (many) { PS_BC_STEPS(PS_STEP) }
+#undef PS_STEP
+            off1 = (i1 - cs1) + (H1 - i64_of(e0.x, e0.y));
+            off2 = (i2 - cs2) + (H2 - i64_of(e0.z, e0.w));
+            T1 = i64_of(eN.x, eN.y) + lane_get(off1, nch - 1) + TL1;
+            T2 = i64_of(eN.z, eN.w) + lane_get(off2, nch - 1) + TL2;
+        } else {
+            const int cs1 = ct.x;
+            const double cs2 = bs_d(i64_of(ct.z, ct.w));                   // < 2^38: exact
+            int i1 = cs1;
+            double i2 = cs2;
+#define PS_STEP(CTRL, RM) { i1 += dpp_mov<CTRL, RM>(0, i1); i2 += dpp_movd<CTRL, RM>(i2); }
+            PS_ROW_STEPS(PS_STEP)
+            if (many) { PS_BC_STEPS(PS_STEP) }
+#undef PS_STEP
+            off1 = (i1 - cs1) + (H1 - bs8_s1(e0));
+            const double o2 = (i2 - cs2) + (H2 - static_cast<double>(bs8_s2(e0)));   // exact integers below 2^45
+            off2 = o2 - BS_BIAS;
+            T1 = bs8_s1(eN) + lane_get(off1, nch - 1) + TL1;
+            T2 = (bs8_s2_biased(eN) + lane_get(off2, nch - 1)) + TL2;
+        }
+#undef PS_ROW_STEPS
+#undef PS_BC_STEPS
     }
-    ps_sync<64>();
-    const BsOff_t oN = coff[nch - 1];
-    const s1_t T1 = bs_s1<WIDE>(eN) + oN.o1 + static_cast<s1_t>(TL1d);
-    const s2_t T2 = bs_s2<WIDE>(eN) + oN.o2 + static_cast<s2_t>(TL2d);     // window totals about m
-    const double T1d = bs_d(T1), T2d = bs_d(T2);
+    const double T1d = uni(bs_d(T1)), T2d = uni(bs_d(T2));                // window totals about m
     const double dn = static_cast<double>(n);
     const double Dtot = dn * T2d - T1d * T1d;
     if (!(Dtot > 0.0)) {
-        if (lane == 0) wk.exact += 1;
-        return scan_exact<64, DT>(c, nullptr, base + ps, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);
+        wk.exact += 1;                                 // (counters are wave-uniform: scalar registers; lane 0 reports them)
+        const long long ex = bs_scan_exact<DT>(bs_cold(c), base + ps, ps, n, cand_lo, cand_hi, thresh, &sh);
+        bad |= static_cast<unsigned>(ex >> 32);
+        return uni(static_cast<int>(ex));
     }
-    const float rn = __builtin_amdgcn_rcpf(static_cast<float>(n));
-    const float c0f = __builtin_amdgcn_logf(static_cast<float>(Dtot) * rn * rn);
+    const float nf = static_cast<float>(n);
+    const float rn = __builtin_amdgcn_rcpf(nf);
+    const float c0f = uni(__builtin_amdgcn_logf(static_cast<float>(Dtot) * rn * rn));
     const f2 cc = {c0f, c0f};
     const float dlt = screen_delta_log2(n);
     const float thr_log2 = static_cast<float>(thresh * 1.4426950408889634);
-    const float dthr = dlt + 3.0e-6f * static_cast<float>(n) + 1.0e-6f * fabsf(thr_log2);
-    const float nf = static_cast<float>(n);
+    const float dthr = dlt + 3.0e-6f * nf + 1.0e-6f * fabsf(thr_log2);
     const float LOG2E = 1.4426950408889634f;
-    // variance floor: the reference's own fp64 rounding (mabs^2 * 2^-52 * n) and the fp64 D above (kappa_m <= 2^26)
-    // (wide digest: S2 is rounded to fp64 once, kappa_m <= 2^22 keeps D to 2^-30)
-    const float vfloor = fmaxf(static_cast<float>(mabs) * static_cast<float>(mabs) * 1.0e-9f, ymaxf * ymaxf * (WIDE ? 2.4e-7f : 1.5e-8f));
+    // variance floor: the reference's own fp64 rounding (max|k|^2 * 2^-52 * n; max|k| <= |m| + max|k-m|) and the fp64 D
+    // above (kappa_m <= 2^26; wide digest: S2 is rounded to fp64 once, kappa_m <= 2^22 keeps D to 2^-30)
+    const float ymaxf = static_cast<float>(yabs);
+    const float mabsf = fabsf(static_cast<float>(m)) + ymaxf;
+    const float vfloor = uni(fmaxf(mabsf * mabsf * 1.0e-9f, ymaxf * ymaxf * (WIDE ? 2.4e-7f : 1.5e-8f)));
     const unsigned crange = static_cast<unsigned>(cand_hi - cand_lo);
+    BsQ_t *queue = reinterpret_cast<BsQ_t *>(sh.q);
+    BsC_t *cont = reinterpret_cast<BsC_t *>(queue + BS_QN);
+    int4 *ybuf = reinterpret_cast<int4 *>(cont + BS_NC);               // 64 staged blocks: 8 int16 offsets (wide digest: 8 int32)
 
     int result = -2;
     bool anyflag = false;
@@ -457,9 +747,9 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     {
         // pruning level from the sampled boundary candidates
         const int J = g0 + 8 * tS;
-        const BsOff_t off = coff[(gbl + tS) >> 8];
-        const s1_t a1 = bs_s1<WIDE>(smp) + off.o1;
-        const s2_t a2 = bs_s2<WIDE>(smp) + off.o2;
+        const int cs = (gbl + tS) >> BS_CHUNK_LOG;
+        const s1_t a1 = bs_a1(smp, static_cast<s1_t>(__shfl(off1, cs)));
+        const s2_t a2 = bs_a2(smp, static_cast<o2_t>(__shfl(off2, cs)));
         const BsEval e = bs_eval(bs_d(a1), bs_d(a2), bs_d(static_cast<s1_t>(T1 - a1)), bs_d(static_cast<s2_t>(T2 - a2)),
                                  max(J - ps, 1), max(pe - J, 1), cc, vfloor);
         const bool inr = static_cast<unsigned>(J - cand_lo) <= crange;
@@ -468,15 +758,14 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
 #define PS_STEP(CTRL, RM) { bm = fmaxf(bm, dpp_movf<CTRL, RM>(-INFINITY, bm)); }
         PS_DPP_STEPS(PS_STEP)
 #undef PS_STEP
-        bm = __shfl(bm, 63);
+        bm = __int_as_float(lane_get(__float_as_int(bm), 63));
         Tprune = fmaxf(thr_log2 - dthr, bm - 2.0f * dlt) - 2.0f * dlt;
         // A window that holds a split (a sampled gain above the threshold band; rows <= 64: windows up to 32 000
         // samples): the same monotone bound as for an 8-sample block, applied to the whole stretch [J, Jb) up to the
         // NEXT lane's sample (left side from this sample, right side from that one; loose by about Jb - J nats, nothing
         // next to the thousands of nats of a real step).  Nearly every stretch then lies below the pruning level, and
         // the sweep skips the rows that lie in such stretches altogether, loads included: a candidate there is provably
-        // more than 2 delta below the winner.  Windows without such a sample (all subtree windows, half of the spine's)
-        // skip this and sweep every row: for them the bookkeeping would only cost (measured: +1.6 us per window).
+        // more than 2 delta below the winner.  Windows without such a sample sweep every row.
         hitlike = ROWSKIP && c.prune && rows <= 64 && bm > thr_log2 + dthr;
         if (hitlike) {
             const int Jb = from_lane_above(J);
@@ -492,7 +781,6 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
             }
         }
     }
-    PS_STAMP_AT(wk, 0);                                // loads, totals, wave scans, pruning level
     int ccount = 0;
 #define PS_COLLECT(COND, G, JJ, A1, A2)                                                                       \
     {                                                                                                         \
@@ -508,7 +796,13 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
             ccount += __popcll(cm_);                                                                          \
         }                                                                                                     \
     }
+    const int nl0 = nh + 8 * lane;                     // samples left of this lane's boundary in row 0
+    ps_sync<64>();                                     // previous user of sh.q (this wave) is done
+#ifdef PS_X_NOPHASE1
+    for (int phase = 0; phase < 1; ++phase) {
+#else
     for (int phase = 0; phase < 2; ++phase) {
+#endif
         Top2 top = {-INFINITY, -INFINITY, -1};
         unsigned flag = 0;
         int qcount = 0;
@@ -531,9 +825,11 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
             return r;
         };
         auto drain = [&]() {
+#ifdef PS_X_NODRAIN
+            qcount = 0; return;
+#endif
             // drain: interior candidates of the queued blocks
             ps_sync<64>();
-            PS_STAMP_AT(wk, 1);                    // boundary sweep
             for (int r = 0; r < qcount; r += 64) {
                 // (a) one queued block per lane: its 8 samples, as int16 offsets from m, go to LDS
                 const int nb = min(64, qcount - r);
@@ -593,21 +889,26 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
                 ps_sync<64>();
             }
             qcount = 0;
-            PS_STAMP_AT(wk, 2);                        // drain
         };
-        // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t)
-        auto do_row = [&](int r, const int4 &cur, const BsOff_t &off) {
+        // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t); the row's boundaries lie in at most two chunks
+        auto do_row = [&](int r, const ent_t &cur) {
             const bool first_row = r == 0;
-            const int J = g0 + 8 * (BS_STRIDE * r + lane), nl = J - ps;
+            const int tb = gbl + BS_STRIDE * r;                            // (uniform) chunk-relative index of the row's first boundary
+            const int cA = min(tb >> BS_CHUNK_LOG, nch - 1), cB = min(cA + 1, nch - 1);
+            const int lsw = ((tb >> BS_CHUNK_LOG) + 1) * BS_CHUNK - tb;    // first lane in the second chunk (>= 64: none)
+            const bool second = lane >= lsw;
+            const s1_t o1 = second ? lane_get(off1, cB) : lane_get(off1, cA);
+            const o2_t o2 = second ? lane_get(off2, cB) : lane_get(off2, cA);
+            const int nl = nl0 + 8 * BS_STRIDE * r, J = ps + nl;
             const float nlf = static_cast<float>(nl);
             const double nld = static_cast<double>(nl);
-            const s1_t a1 = bs_s1<WIDE>(cur) + off.o1;
-            const s2_t a2 = bs_s2<WIDE>(cur) + off.o2;
+            const s1_t a1 = bs_a1(cur, o1);
+            const s2_t a2 = bs_a2(cur, o2);
             // screened gain of the boundary (bs_eval, with the running nl and the right side from the totals)
             const double a1d = bs_d(a1), b1d = T1d - a1d;                  // (exact: |S1| < 2^53)
             double a2d, b2d;
             if constexpr (WIDE) { a2d = d_of_i64(a2); b2d = d_of_i64(T2 - a2); }
-            else { a2d = a2; b2d = T2 - a2; }
+            else { a2d = a2; b2d = T2d - a2; }
             const double DL = fma(nld, a2d, -(a1d * a1d));
             const double DR = fma(dn - nld, b2d, -(b1d * b1d));
             const float nrf = nf - nlf;
@@ -651,32 +952,24 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
             }
             if (phase) PS_COLLECT(ge >= Tc, ge, J, a1, a2)
         };
-        // rows in groups of BS_G, double-buffered: the next group's loads are in flight while this one is evaluated
-        int4 ga[BS_G], gb[BS_G];
-        BsOff_t offs[BS_G];                            // the group's chunk offsets: one LDS round trip per group, not per row
-        auto row_load = [&](int r) { return r == 0 ? row0 : bsw[min(max(r, 0) * BS_STRIDE + lane, nblk)]; };
-        auto row_off = [&](int r) { return coff[min((gbl + max(r, 0) * BS_STRIDE + lane) >> 8, nch - 1)]; };
         if (!hitlike) {
-            // every row, five at a time in straight-line code (rows past the end are inert): the compiler interleaves the
-            // rows of a group, which is worth 20 % of a window -- no branch may stand between them
+            // every row, BS_G at a time in straight-line code (rows past the end are inert)
+            if (phase) {
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) ga[i] = row_load(i);
+                for (int i = 0; i < BS_G; ++i) ga[i] = row_load(i);
+            }
             for (int r0 = 0; r0 < rows; r0 += 2 * BS_G) {
                 if (qcount > BS_QN - 64 * BS_G) drain();
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(r0 + i);
-#pragma unroll
                 for (int i = 0; i < BS_G; ++i) gb[i] = row_load(r0 + BS_G + i);
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) do_row(r0 + i, ga[i], offs[i]);
+                for (int i = 0; i < BS_G; ++i) do_row(r0 + i, ga[i]);
                 if (r0 + BS_G >= rows) break;
                 if (qcount > BS_QN - 64 * BS_G) drain();
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(r0 + BS_G + i);
-#pragma unroll
                 for (int i = 0; i < BS_G; ++i) ga[i] = row_load(r0 + 2 * BS_G + i);
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) do_row(r0 + BS_G + i, gb[i], offs[i]);
+                for (int i = 0; i < BS_G; ++i) do_row(r0 + BS_G + i, gb[i]);
             }
         } else {
             // live rows only (a window that holds a split: typically 2 .. 4 of 20); an empty slot of a group loads row 0
@@ -690,43 +983,46 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
                 if (ra[0] < 0) break;
                 if (qcount > BS_QN - 64 * BS_G) drain();
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(ra[i]);
-#pragma unroll
                 for (int i = 0; i < BS_G; ++i) rb[i] = take_row();
 #pragma unroll
                 for (int i = 0; i < BS_G; ++i) gb[i] = row_load(rb[i]);
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) if (ra[i] >= 0) do_row(ra[i], ga[i], offs[i]);
+                for (int i = 0; i < BS_G; ++i) if (ra[i] >= 0) do_row(ra[i], ga[i]);
                 if (rb[0] < 0) break;
                 if (qcount > BS_QN - 64 * BS_G) drain();
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) offs[i] = row_off(rb[i]);
 #pragma unroll
                 for (int i = 0; i < BS_G; ++i) ra[i] = take_row();
 #pragma unroll
                 for (int i = 0; i < BS_G; ++i) ga[i] = row_load(ra[i]);
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) if (rb[i] >= 0) do_row(rb[i], gb[i], offs[i]);
+                for (int i = 0; i < BS_G; ++i) if (rb[i] >= 0) do_row(rb[i], gb[i]);
             }
         }
         drain();
         if (phase == 1) break;
-        // wave top-2 (DPP) and flags (ballot)
-#define PS_STEP(CTRL, RM) { const float ob = dpp_movf<CTRL, RM>(-INFINITY, top.b), os = dpp_movf<CTRL, RM>(-INFINITY, top.s); \
-                            const int oi = dpp_mov<CTRL, RM>(-1, top.i); top2_merge(top, ob, os, oi); }
+        // the wave maximum decides the common case; top-2 (DPP) only when something reaches the threshold band
+        anyflag = __ballot(flag != 0) != 0ull;
+        float mx = top.b;
+#define PS_STEP(CTRL, RM) { mx = fmaxf(mx, dpp_movf<CTRL, RM>(-INFINITY, mx)); }
         PS_DPP_STEPS(PS_STEP)
 #undef PS_STEP
-        const float ab = __shfl(top.b, 63), as = __shfl(top.s, 63);
-        const int ai = __shfl(top.i, 63);
-        anyflag = __ballot(flag != 0) != 0ull;
-        if (!anyflag) {
-            if (ab < thr_log2 - dthr) result = -1;
-            else if (ab > thr_log2 + dthr && as < ab - 2.0f * dlt) result = ps + ai;
+        const float ab = __int_as_float(lane_get(__float_as_int(mx), 63));
+        float as = -INFINITY;
+        int ai = -1;
+        if (!anyflag && ab < thr_log2 - dthr) {
+            result = -1;
+        } else if (!anyflag) {
+#define PS_STEP(CTRL, RM) { const float ob = dpp_movf<CTRL, RM>(-INFINITY, top.b), os = dpp_movf<CTRL, RM>(-INFINITY, top.s); \
+                            const int oi = dpp_mov<CTRL, RM>(-1, top.i); top2_merge(top, ob, os, oi); }
+            PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+            as = __int_as_float(lane_get(__float_as_int(top.s), 63));
+            ai = lane_get(top.i, 63);
+            if (ab > thr_log2 + dthr && as < ab - 2.0f * dlt) result = ps + ai;
         }
 #ifdef PS_NOEXACT
         if (result == -2) result = ab < thr_log2 ? -1 : ps + ai;       // timing experiment only: never the product
 #endif
-        PS_STAMP_AT(wk, 3);                            // top-2 reduce + decision
         if (result != -2 || anyflag) break;
         // Ambiguous for the screen (inside the threshold band, or a near tie): collect the contenders.
         // The screen is within delta of the reference gain, so the reference's choice has a screened
@@ -740,50 +1036,22 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
     // Wide digest: the data are a re-quantised float64 current, which the reference's own fp64 sums do not represent
     // exactly either; the contenders are decided in the same fp64 formulas from the exact 64-bit sums ABOUT m (each
     // rounded to fp64 once: closer to the true value than any order of summation).
-    const bool sums_exact = WIDE || static_cast<double>(n) * static_cast<double>(mabs) * static_cast<double>(mabs) < 9007199254740992.0;
+    const bool sums_exact = WIDE || static_cast<double>(n) * static_cast<double>(mabsf) * static_cast<double>(mabsf) < 9007199254740992.0;
     if (result == -2 && !anyflag && ccount <= BS_NC && sums_exact) {
         ps_sync<64>();                              // contender stores visible to the other lanes
-        double var_summed;
-        if constexpr (WIDE) var_summed = static_cast<double>(n) * log(ref_var(T1d, T2d, n, c.q, c.q2));
-        else var_summed = static_cast<double>(n) *
-            log(ref_var(T1d + dn * static_cast<double>(m),
-                        T2d + 2.0 * static_cast<double>(m) * T1d + dn * static_cast<double>(m) * static_cast<double>(m), n, c.q, c.q2));
-        double eg = thresh;
-        int ei = -1;
-        if (lane < ccount) {
-            const BsC_t e = cont[lane];
-            double gx;
-            if constexpr (WIDE) {
-                const int nl = e.j - ps;
-                gx = ref_gain(var_summed, nl, ref_var(d_of_i64(e.a1), d_of_i64(e.a2), nl, c.q, c.q2),
-                              n - nl, ref_var(d_of_i64(T1 - e.a1), d_of_i64(T2 - e.a2), n - nl, c.q, c.q2));
-            } else {
-                gx = bs_exact_gain(c, m, e.a1, e.a2, T1, T2, e.j - ps, n, var_summed);
-            }
-            if (gx > eg) { eg = gx; ei = e.j; }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double og = __shfl_xor(eg, d);
-            const int oi = __shfl_xor(ei, d);
-            if (beats(og, oi, eg, ei)) { eg = og; ei = oi; }
-        }
-        result = ei;
-        if (lane == 0) wk.exact += 1;
+        const long long dr = bs_decide<DT>(bs_cold(c), m, cont, ccount, ps, n, T1, T2, thresh);
+        result = uni(static_cast<int>(dr));
+        wk.exact += 1; wk.near += uni(static_cast<int>(dr >> 32));
     }
-    PS_STAMP_AT(wk, 4);                                // contenders + fp64 decision
-#ifdef PS_STAMP
-    if (lane == 0 && anyflag) wk.ph[10] += 1;
-    if (lane == 0 && !anyflag && result == -2) wk.ph[11] += 1;
-#endif
     if (c.mode == MODE_VERIFY || result == -2) {
-        if (lane == 0) wk.exact += (1LL << 32);                        // high word: full exact scans
-        const int ex = scan_exact<64, DT>(c, nullptr, base + ps, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);
+        wk.exact += (1LL << 32);                       // high word: full exact scans
+        const long long exr = bs_scan_exact<DT>(bs_cold(c), base + ps, ps, n, cand_lo, cand_hi, thresh, &sh);
+        bad |= static_cast<unsigned>(exr >> 32);
+        const int ex = uni(static_cast<int>(exr));
         if (result != -2 && ex != result) {
             bad |= ST_VERIFY_MISMATCH;
-            if (lane == 0 && wk.dbg[1] == 0) { wk.dbg[0] = ps; wk.dbg[1] = pe; wk.dbg[2] = result; wk.dbg[3] = ex; }
+            if (wk.dbg[1] == 0) { wk.dbg[0] = ps; wk.dbg[1] = pe; wk.dbg[2] = result; wk.dbg[3] = ex; }
         }
-        PS_STAMP_AT(wk, 6);
         return ex;
     }
     return result;
@@ -794,7 +1062,7 @@ __device__ int scan_window_bs(const DevCfg &c, int ev, int64_t base, int ps, int
 // S1, S2 of the full blocks inside the segment from the chunk prefix and the chunk totals, min/max from the per-block
 // table, the ragged ends (<= 7 samples each) from the samples.  mean = (m + S1/n) q, std = sqrt(S2/n - (S1/n)^2) q
 // (population; formed about m, so nothing cancels), min/max exact.  n_seg = bounds_off[n_ev] + n_ev is read on the
-// device; `stats_cap` bounds the writes.
+// device; `stats_cap` bounds the writes.  (Narrow digest only: the wide one keeps no min/max table.)
 template <int DT>
 __global__ __launch_bounds__(64) void segstat_bs_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev,
                                                         const int32_t *bounds, const int64_t *bounds_off, ps_segstat *stats,
@@ -804,6 +1072,7 @@ __global__ __launch_bounds__(64) void segstat_bs_kernel(DevCfg c, const int64_t 
     // a failed stitch or a refused digest leaves no valid boundaries: the host redoes the call on another path
     if ((hdr && hdr->fail) || (*status & ~ST_VERIFY_MISMATCH) != 0u) return;
     const int64_t n_seg = min(bounds_off[n_ev] + n_ev, stats_cap);
+    const uint2 *bs = static_cast<const uint2 *>(c.bsum);
     unsigned bad = 0;
     for (int64_t g = blockIdx.x; g < n_seg; g += gridDim.x) {
         int lo = 0, hi = n_ev - 1;                 // event e: bounds_off[e] + e <= g < bounds_off[e+1] + e + 1
@@ -841,19 +1110,19 @@ __global__ __launch_bounds__(64) void segstat_bs_kernel(DevCfg c, const int64_t 
             if (lane >= 32 && lane - 32 < b - 8 * b1) { y = load_count<DT>(c, base + 8 * b1 + (lane - 32), bad) - m; have = true; }
             if (have) { s1 = static_cast<double>(y); s2 = static_cast<double>(y) * static_cast<double>(y); mn = y; mx = y; }
             // chunk totals between the two boundaries, min/max of the full blocks
-            const long long c0 = gb0 >> 8, c1 = gb1 >> 8;
+            const long long c0 = gb0 >> BS_CHUNK_LOG, c1 = gb1 >> BS_CHUNK_LOG;
             for (long long cc = c0 + lane; cc < c1; cc += 64) {
-                const int4 t = c.chunk_tot[2 * cc];
-                s1 += static_cast<double>(t.x); s2 += ent2(t);
+                const int4 t = c.chunk_tot[cc];
+                s1 += static_cast<double>(t.x); s2 += bs_d(i64_of(t.z, t.w));
             }
             for (long long gb = gb0 + lane; gb < gb1; gb += 64) {
                 const int w = c.blk_mm[gb];
                 mn = min(mn, static_cast<int>(static_cast<short>(w & 0xffff))); mx = max(mx, w >> 16);
             }
             if (lane == 0) {
-                const int4 p0 = c.bsum[gb0], p1 = c.bsum[gb1];
-                s1 += static_cast<double>(p1.x) - static_cast<double>(p0.x);
-                s2 += ent2(p1) - ent2(p0);
+                const uint2 p0 = bs[gb0], p1 = bs[gb1];
+                s1 += static_cast<double>(bs8_s1(p1)) - static_cast<double>(bs8_s1(p0));
+                s2 += static_cast<double>(bs8_s2(p1)) - static_cast<double>(bs8_s2(p0));
             }
         }
 #pragma unroll

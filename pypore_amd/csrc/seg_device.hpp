@@ -52,14 +52,17 @@ struct DevCfg {
     int mode;               // MODE_*
     int prune;              // 1: block-bound pruning in the screen (default), 0: evaluate every candidate
     int lds_cap;            // samples that fit the dynamic LDS window buffer
-    const int4 *bsum;       // per 8-sample block: chunk-exclusive prefix of (sum (k-m), sum (k-m)^2), all events; nullptr: LDS-window scan
+    const void *bsum;       // per 8-sample block: chunk-exclusive prefix of (sum (k-m), sum (k-m)^2), all events -- 8 bytes (25 + 39
+                            // bits), wide digest 16 bytes (two int64), seg_bs.hpp; nullptr: LDS-window scan
     const int4 *ev_info;    // per event: (m, -, block offset lo, block offset hi)
-    const int4 *chunk_tot;  // per 256 blocks (K0 workgroup): (S1, -, S2 fp64), (max |k|, max |k-m|, -, -)
+    const int4 *chunk_tot;  // per chunk of 128 blocks: (S1, max |k-m|, S2 as int64); wide digest: two entries (S1, S2 as int64), (max |k-m|, -, -, -)
     int *blk_mm;            // per block: min / max of k-m as two int16 (written by K0 when statistics are wanted) or nullptr
     int bs_wide;            // (host side) the digest is the 64-bit one: kernels compiled for DT | DT_WIDE
     unsigned long long *dbg;  // diagnostics scratch (12 words) or nullptr
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
+
+struct EvRef { int m; long long boff; };   // what a block-sum window scan needs of its event: centre m (the first count), first block
 
 struct SpineJob {           // speculative spine of one tile: rec(start, end) without left subtrees
     int64_t base;           // offset of the event in the sample array
@@ -72,7 +75,6 @@ struct SpineJob {           // speculative spine of one tile: rec(start, end) wi
     int32_t tile_len;       // tile t of the event starts at t * tile_len
     int32_t ev;             // event index
     int64_t vbase;          // sum of the lengths of the preceding events (layout of the tree output regions)
-    int64_t spec_off;       // start of the tile's region in the speculative subtree output area
 };
 
 struct TreeJob {            // full in-order traversal of rec(start, end), first window index j0
@@ -80,7 +82,8 @@ struct TreeJob {            // full in-order traversal of rec(start, end), first
     int32_t start, end, j0;
     int32_t out_cap;
     int64_t out_off;        // into the private boundary scratch (int32) and the spill stack (int2)
-    int32_t ev, pad_;
+    int32_t m, pad_;        // the event's centre (first count) and first block (K0 digest; 0 on the LDS-window path)
+    int64_t boff;
 };
 
 typedef short lds_t;               // window samples in LDS: ADC counts as int16 (windows that do not fit go the exact HBM path)
@@ -92,7 +95,7 @@ struct QEnt { int j, jend, p1, r1; unsigned p2, r2; int cL, cR; };
 template <int NT> struct SharedT {
     static constexpr int NWV = NT / 64;
     static constexpr int OB = NT == 64 ? BR_MAX : OBUF;      // buffered outputs (a bridge buffers its whole chain)
-    static constexpr int QN = NT == 64 ? 336 : QMAX;         // queued blocks (NT == 64: the block-sum scan's LDS, seg_bs.hpp)
+    static constexpr int QN = NT == 64 ? 208 : QMAX;         // queued blocks (NT == 64: the block-sum scan's LDS, seg_bs.hpp: 6 656 bytes)
     static constexpr int LN = NT == 64 ? 128 : LST_MAX;      // cached downstream anchors
     static constexpr int SN = NT == 64 ? 64 : LDS_STACK;     // DFS stack entries before spilling
     double wsum1[NWV], wsum2[NWV];
@@ -116,19 +119,21 @@ template <int NT> struct SharedT {
 typedef SharedT<1024> Shared;  // (size reference for the host-side LDS budget: the largest variant)
 
 #ifndef PS_BS_MINW
-#define PS_BS_MINW 2          // waves per SIMD the single-wave (block-sum) kernels are compiled for
+#define PS_BS_MINW 4          // waves per SIMD the single-wave (block-sum) kernels are compiled for
 #endif
-// Registers of the block-sum scan kernels: 232, so that two of their waves leave 48 of a SIMD's 512 to a wave of another
-// call's streaming kernels (K0 needs 40) -- several calls are in flight (engine.StreamPool) and K0, which is bound by
-// HBM, then runs UNDER the scans, which are bound by instruction issue.  (The attribute counts architectural VGPRs, half
-// of the unified file on this part: 116 -> 232.  A kernel whose launch bounds allow less -- the NT >= 256 instances,
-// 128 -- ignores it.)
+// Registers of the block-sum scan kernels.  Round 3: 128 (four waves per SIMD; the scan body of seg_bs.hpp is written for
+// it: small row groups, chunk offsets in lane registers, cold fp64 paths out of line) -- a window spends a third of its
+// time in dependent memory round trips (setup, drain, decision), which two waves per SIMD could not cover.  Round 2 ran
+// them at 232 (two waves plus room for a wave of another call's K0).  The attribute counts architectural VGPRs, half of
+// the unified file on this part: 64 -> 128.  A kernel whose launch bounds allow less -- the NT >= 256 instances, 128 --
+// ignores it.
 #ifndef PS_SCAN_VGPRS
-#define PS_SCAN_VGPRS 116
+#define PS_SCAN_VGPRS 64
 #endif
 #define PS_SCAN_REGS __attribute__((amdgpu_num_vgpr(PS_SCAN_VGPRS)))
 struct Work {
     long long windows, cands, exact;
+    long long near;          // contender decisions whose margin lies inside the device-vs-glibc logarithm noise (seg_bs.hpp: bs_decide)
     long long dbg[4];        // verify mode: first disagreement (ps, pe, screen result, exact result)
 #ifdef PS_STAMP
     long long t0, ph[12], tbeg;
@@ -138,10 +143,10 @@ struct Work {
 // deltas per phase of the window scan; never compiled into the product library.
 #ifdef PS_STAMP
 #define PS_STAMP_AT(wk, i) do { if (threadIdx.x == 0) { long long t_ = clock64(); (wk).ph[i] += t_ - (wk).t0; (wk).t0 = t_; } } while (0)
-#define PS_WORK_INIT {0, 0, 0, {0, 0, 0, 0}, clock64(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clock64()}
+#define PS_WORK_INIT {0, 0, 0, 0, {0, 0, 0, 0}, clock64(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clock64()}
 #else
 #define PS_STAMP_AT(wk, i) do { } while (0)
-#define PS_WORK_INIT {0, 0, 0, {0, 0, 0, 0}}
+#define PS_WORK_INIT {0, 0, 0, 0, {0, 0, 0, 0}}
 #endif
 
 // ---- sample access --------------------------------------------------------------------------
@@ -896,7 +901,7 @@ namespace ps {
 template <int NT, int DT, bool VALIDATE, bool ROWSKIP = true>
 __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                            double thresh, double *scores, SharedT<NT> &sh, unsigned &bad, Work &wk,
-                           double *best_gain_out = nullptr, int pf_end = 0, int ev = 0)
+                           double *best_gain_out = nullptr, int pf_end = 0, const EvRef &er = EvRef{0, 0})
 {
     constexpr int NW = NT / 64;
     const int n = pe - ps;
@@ -908,10 +913,10 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     }
     if constexpr (NT == 64) {                          // single-wave workgroup: block-sum scan (seg_bs.hpp)
         if (c.bsum != nullptr && scores == nullptr && best_gain_out == nullptr)
-            return scan_window_bs<DT, ROWSKIP>(c, ev, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
+            return scan_window_bs<DT, ROWSKIP>(c, er, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
     }
     if (n > c.lds_cap) {                               // window larger than LDS: exact path from HBM
-        if (threadIdx.x == 0) wk.exact += 1;
+        wk.exact += 1;
         return scan_exact<NT, DT>(c, nullptr, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
     }
     // 1. stage: 16-byte loads (4 fp32 / 8 int16 per lane), all of a thread's loads issued before
@@ -1009,7 +1014,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
         const bool try_screen = c.mode != MODE_EXACT && scores == nullptr && best_gain_out == nullptr;
         const int wdone = try_screen ? scan_screen_wide<NT, DT>(c, g0, ps, n, cand_lo, cand_hi, thresh, kmin, kmax, sh, &wsplit, bad) : 0;
         if (wdone && c.mode == MODE_FAST) return wsplit;
-        if (threadIdx.x == 0) wk.exact += 1;
+        wk.exact += 1;
         const int ex = scan_exact<NT, DT>(c, nullptr, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
         if (wdone && c.mode == MODE_VERIFY && ex != wsplit) bad |= ST_VERIFY_MISMATCH;
         return ex;
@@ -1026,12 +1031,12 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
         else if (c.mode == MODE_VERIFY) {
             result = scan_exact<NT, DT>(c, ysw, g0, ps, n, cand_lo, cand_hi, thresh, nullptr, sh, bad, nullptr);
             if (done && result != split) bad |= ST_VERIFY_MISMATCH;
-            if (!done && threadIdx.x == 0) wk.exact += 1;
+            if (!done) wk.exact += 1;
             decided = true;
         }
     }
     if (!decided) {
-        if (threadIdx.x == 0) wk.exact += 1;
+        wk.exact += 1;
         result = scan_exact<NT, DT>(c, ysw, g0, ps, n, cand_lo, cand_hi, thresh, scores, sh, bad, best_gain_out);
         PS_STAMP_AT(wk, 6);                            // exact rescans
     }
@@ -1044,7 +1049,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 // parent frame, DESIGN.md "memoised left child").
 template <int NT, int DT, bool VALIDATE, bool BSONLY = false, bool ROWSKIP = true>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
-                          SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, int ev = 0,
+                          SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, const EvRef &er = EvRef{0, 0},
                           long long stop_lim = 0x7fffffffffffffffLL, int budget = 0x7fffffff)
 {
     const long long lim = static_cast<long long>(end) - 2LL * c.mw;
@@ -1062,16 +1067,16 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
         if (pe > end) pe = end;                                         // :193
         int s = -1;
         if (pe - ps > 2LL * c.mw) {                                     // :164
-            if constexpr (BSONLY) {
+            if constexpr (BSONLY || NT == 64) {            // (the single-wave kernels exist for the block-sum scan only)
                 static_assert(NT == 64, "block-sum scan: one wave per window");
-                if ((threadIdx.x & 63u) == 0) { wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1; }
-                s = scan_window_bs<DT, ROWSKIP>(c, ev, base, static_cast<int>(ps), static_cast<int>(pe),
+                wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1;       // (wave-uniform counters)
+                s = scan_window_bs<DT, ROWSKIP>(c, er, base, static_cast<int>(ps), static_cast<int>(pe),
                                                 static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
             } else {
                 s = scan_window<NT, DT, VALIDATE, ROWSKIP>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
                                     static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw,
                                     c.min_gain, nullptr, sh, bad, wk, nullptr,
-                                    static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim), ev);
+                                    static_cast<int>(pe + c.W < pf_lim ? pe + c.W : pf_lim), er);
             }
         }
         if (s >= 0) { kind = KIND_HIT; return s; }                      // :195-196
@@ -1080,6 +1085,19 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
     long long a = static_cast<long long>(start) + c.maxw, b = static_cast<long long>(end) - c.mw;
     kind = KIND_LATE;                                                   // :201
     return static_cast<int>(a < b ? a : b);
+}
+
+// event constants of a tile job: one load per job (not per window), kept in scalar registers
+__device__ __forceinline__ EvRef ev_ref_of(const DevCfg &c, int ev)
+{
+    EvRef r = {0, 0};
+    if (c.bsum != nullptr) {
+        const int4 info = c.ev_info[ev];
+        r.m = __builtin_amdgcn_readfirstlane(info.x);
+        r.boff = (static_cast<long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(info.w))) << 32) |
+                 static_cast<unsigned>(__builtin_amdgcn_readfirstlane(info.z));
+    }
+    return r;
 }
 
 __device__ __forceinline__ int left_child_j0(int start, int split, int W, int half)
@@ -1097,6 +1115,7 @@ __device__ __forceinline__ void flush(unsigned bad, const Work &wk, unsigned *st
         if (wk.exact) atomicAdd(&work[2], static_cast<unsigned long long>(wk.exact));
         if (wk.dbg[1]) { work[8] = wk.dbg[0]; work[9] = wk.dbg[1]; work[10] = wk.dbg[2]; work[11] = wk.dbg[3]; }
 #ifndef PS_STAMP
+        if (wk.near) atomicAdd(&work[4], static_cast<unsigned long long>(wk.near));                      // near-tie decisions
         if (which >= 0) atomicAdd(&work[17 + 3 * which], static_cast<unsigned long long>(wk.windows));   // windows per kernel
 #endif
 #ifdef PS_STAMP
@@ -1125,6 +1144,7 @@ __device__ __forceinline__ void flush_wave(unsigned bad, const Work &wk, unsigne
     if ((threadIdx.x & 63u) == 0 && wk.windows) {
         atomicAdd(&work[0], static_cast<unsigned long long>(wk.windows));
 #ifndef PS_STAMP
+        if (wk.near) atomicAdd(&work[4], static_cast<unsigned long long>(wk.near));
         if (which >= 0) atomicAdd(&work[17 + 3 * which], static_cast<unsigned long long>(wk.windows));
 #endif
         atomicAdd(&work[1], static_cast<unsigned long long>(wk.cands));
@@ -1163,12 +1183,13 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
     // the launch cost of a workgroup per tile would rival the scans.
     for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
         const SpineJob job = jobs[jb];
+        const EvRef er = ev_ref_of(c, job.ev);
         int2 *out = scratch + job.out_off;
         int a = job.start, cnt = 0, ended = 0, flushed = 0, open_j = 0;
         for (;;) {
             int kind;
             // (device stitch only: the host stitch expects every list to reach its tile end)
-            int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev,
+            int s = find_split<NT, DT, true>(c, ys, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, er,
                                              dense == nullptr ? static_cast<long long>(job.stop) + 2LL * c.W : 0x7fffffffffffffffLL);
             if (kind == KIND_NONE) { ended = 1; break; }
             if (kind == KIND_STOP) { open_j = s; break; }   // open end: the list stops short of the tile end (not "ended")
@@ -1244,6 +1265,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
         }
         int a = m.x > 0 ? lists[job.out_off + m.x - 1].x : job.start;
         int cnt = 0, st = BR_FAIL, jt = -1, ji = 0, cached = -1, ccnt = 0;
+        const EvRef er = ev_ref_of(c, job.ev);
         for (int step = 0; step <= BR_MAX; ++step) {
             int u = a / job.tile_len;
             if (u > job.ntiles - 1) u = job.ntiles - 1;
@@ -1275,7 +1297,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
             int kind;
             // (the samples a bridge reads were validated by the downstream tiles' own spine scans; the first call skips
             // the windows the tile's own chain already scanned without a hit before it gave up)
-            const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, step == 0 ? m.z : 0, kind, sh, bad, wk, job.end, job.ev,
+            const int s = find_split<NT, DT, false>(c, ys, job.base, a, job.end, step == 0 ? m.z : 0, kind, sh, bad, wk, job.end, er,
                                                     0x7fffffffffffffffLL, (NT == 64 && c.bsum != nullptr) ? BR_PATIENCE : 0x7fffffff);
             if (kind == KIND_NONE) { st = BR_ENDED; break; }
             if (kind == KIND_STOP) { st = BR_DEFER; jt = s; break; }     // a long stretch: the look-ahead kernel takes over at window s
@@ -1299,7 +1321,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
 // the longest seam sets the kernel's duration.  Semantics: find_split (cparsers.pyx:186-201) window by window.
 constexpr int BR_LA = 4;
 template <int DT>
-__global__ __launch_bounds__(64 * BR_LA, 2) PS_SCAN_REGS void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+__global__ __launch_bounds__(64 * BR_LA, (PS_BS_MINW > 3 ? 3 : PS_BS_MINW)) PS_SCAN_REGS void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                                   const int4 *meta, int2 *bridges, int4 *bmeta,
                                                                   unsigned *status, unsigned long long *work, int n_jobs)
 {
@@ -1323,6 +1345,7 @@ __global__ __launch_bounds__(64 * BR_LA, 2) PS_SCAN_REGS void bridge_la_kernel(D
         __syncthreads();
         int a = cnt > 0 ? obuf[cnt - 1].x : (m.x > 0 ? lists[job.out_off + m.x - 1].x : job.start);
         int st = BR_FAIL, jt = -1, ji = 0, cached = -1, ccnt = 0;
+        const EvRef er = ev_ref_of(c, job.ev);
         long long jres = bm.y;                         // window of the current find_split to resume at
         for (int step = cnt; step <= BR_MAX; ++step) {
             int u = a / job.tile_len;
@@ -1367,8 +1390,8 @@ __global__ __launch_bounds__(64 * BR_LA, 2) PS_SCAN_REGS void bridge_la_kernel(D
                     long long pe = ps + c.W;
                     if (pe > end) pe = end;
                     if (pe - ps > 2LL * c.mw) {
-                        if ((threadIdx.x & 63) == 0) { wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1; }
-                        val = scan_window_bs<DT>(c, job.ev, job.base, static_cast<int>(ps), static_cast<int>(pe),
+                        wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1;
+                        val = scan_window_bs<DT>(c, er, job.base, static_cast<int>(ps), static_cast<int>(pe),
                                                  static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
                         if (val >= 0) oc = O_HIT;
                     }
@@ -1399,6 +1422,9 @@ __global__ __launch_bounds__(64 * BR_LA, 2) PS_SCAN_REGS void bridge_la_kernel(D
     flush_wave(bad, wk, status, work, 1);              // counters: every wave counted its own scans
 }
 
+#ifndef PS_TREE_ROWSKIP
+#define PS_TREE_ROWSKIP false
+#endif
 // ---- phase 3: in-order traversal of rec(start, end) -----------------------------------------------
 // One job, by the NT threads that share `sh` (a workgroup, or one wave of a multi-wave workgroup when NT == 64).
 template <int NT, int DT, bool BSONLY = false>
@@ -1409,6 +1435,7 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
     int32_t *out = scratch + job.out_off;
     int2 *sp_glob = spill + job.out_off;
     int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0, flushed = 0;
+    const EvRef er = {job.m, job.boff};
     int *obuf = reinterpret_cast<int *>(sh.obuf);
     constexpr int OB = 2 * SharedT<NT>::OB;
     auto emit = [&](int v) {
@@ -1427,7 +1454,7 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
         int kind;
         // (no row skipping in subtree windows: they rarely hold a split, the extra registers cost 2-3 %; filtered events on
         //  the 64-bit digest, where they mostly do, neither gain nor lose -- measured)
-        int s = find_split<NT, DT, false, BSONLY, false>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, job.ev);
+        int s = find_split<NT, DT, false, BSONLY, PS_TREE_ROWSKIP>(c, ys, job.base, start, end, j0, kind, sh, bad, wk, job.end, er);
         if (kind == KIND_NONE) {
             if (sp == 0) break;
             --sp;
@@ -1469,164 +1496,6 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
     return cnt;
 }
 
-// ---- phase 1 + speculative phase 3 in one kernel (block-sum scan) ---------------------------------------------
-// The tile chains of the spine kernel differ in length (3 .. 15 windows for the bench trace), so 40 % of the wave
-// slots sit empty while the longest chain finishes, and the subtree kernel repeats the pattern.  Here a wave that has
-// finished its chains turns to subtree jobs: every chain publishes the pairs (a_{i-1}, a_i) of ITS OWN list in a queue
-// in HBM as soon as it ends, and idle waves draw from the queue -- rec(a_{i-1}, a_i) depends on nothing but its range,
-// and about four pairs in five turn out to lie on the true spine (the others, upstream of the point where the true
-// chain enters the tile, are wasted work in slots that were idle anyway).  The stitch accepts a speculative result
-// when its record (pred, anchor, epoch) matches the true pair; everything else (bridge anchors, a tile's first
-// anchor) is left to the subtree kernel proper.
-//
-// Queue: entry t = four 64-bit words (epoch << 32 | value) for pred, anchor, tile and the anchor's list index.  Every
-// word is written with one agent-scope atomic store and carries the call's epoch, so an entry is complete exactly when
-// all four words show the epoch: no ordering between the stores is needed, hence NO release / acquire fences -- on this
-// part an agent-scope acquire is a `buffer_inv sc1`, which drops every line the XCD's L2 holds of the digest the scans
-// live on (the first version did that once per job and ran twice as long).  Stale entries of earlier calls never match.
-// Producers reserve a range with one atomic on `qctl` (low word: tail, high word: producers that have finished
-// publishing); consumers take tickets from `qhead` and wait for THEIR entry, or leave when every producer is done and
-// the ticket lies beyond the final tail.  All waves of the grid are resident (one workgroup per slot) and producers
-// never wait: no deadlock.
-struct SpecRec { int32_t pred, anchor, cnt, epoch; };   // per list slot: what a speculative subtree job computed
-
-__device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int ld_agent_i32(const int *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int DT>
-__global__ __launch_bounds__(64, PS_BS_MINW) PS_SCAN_REGS void spine_spec_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch, int4 *meta,
-                                                                    unsigned long long *queue, long long qcap, unsigned long long *qctl,
-                                                                    unsigned long long *qhead, int32_t *tscratch, int2 *tspill,
-                                                                    long long spec_base, SpecRec *rec, int epoch, int flags,
-                                                                    unsigned *status, unsigned long long *work, int n_jobs)
-{
-    __shared__ SharedT<64> sh;
-    if ((*status & ST_WIDE_RANGE) != 0u) return;       // K0 refused the data: the host redoes the call
-    const int lane = threadIdx.x;
-    unsigned bad = 0;
-    Work wk = PS_WORK_INIT;
-    // flags: 1 = chains at high priority, 2 = stop drawing subtree jobs once every chain has ended (the rest goes to the
-    // subtree kernel, which balances better than a draining queue)
-    if (flags & 1) __builtin_amdgcn_s_setprio(3);      // chains are the critical path; subtree jobs take what is left
-    // ---- producer: the chains of this wave's tiles (spine_kernel, list mode) ----
-    for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
-        const SpineJob job = jobs[jb];
-        int2 *out = scratch + job.out_off;
-        int a = job.start, cnt = 0, ended = 0, flushed = 0, open_j = 0;
-        for (;;) {
-            int kind;
-            int s = find_split<64, DT, true, true>(c, nullptr, job.base, a, job.end, 0, kind, sh, bad, wk, job.end, job.ev,
-                                                   static_cast<long long>(job.stop) + 2LL * c.W);
-            if (kind == KIND_NONE) { ended = 1; break; }
-            if (kind == KIND_STOP) { open_j = s; break; }
-            if (cnt - flushed == SharedT<64>::OB) {    // rare: spill the LDS buffer to the list
-                ps_sync<64>();
-                for (int i = lane; i < SharedT<64>::OB; i += 64)
-                    if (flushed + i < job.out_cap) out[flushed + i] = sh.obuf[i];
-                flushed += SharedT<64>::OB;
-                ps_sync<64>();
-            }
-            if (cnt >= job.out_cap) bad |= ST_OUT_OVERFLOW;
-            if (lane == 0) sh.obuf[cnt - flushed] = make_int2(s, kind);
-            ++cnt;
-            a = s;
-            if (a >= job.stop) break;
-        }
-        if (cnt > job.out_cap) cnt = job.out_cap;
-        ps_sync<64>();
-        for (int i = flushed + lane; i < cnt; i += 64) out[i] = sh.obuf[i - flushed];
-        if (lane == 0) meta[jb] = make_int4(cnt, ended, open_j, 0);
-        // publish the pairs with a left subtree: (tile start | a_{i-1}, a_i), i >= 1 -- and i = 0 for an event's first
-        // tile, whose start is a true anchor.  (Only the part of the list still in LDS: a list that was spilled is
-        // densely stepped data, whose pairs the subtree kernel takes.)
-        if (flushed == 0 && cnt > 0) {
-            const int i0 = jb == job.first_tile ? 0 : 1;
-            int np = 0;
-            for (int i = i0 + lane; i < cnt; i += 64) { const int k = sh.obuf[i].y; np += (k == KIND_HIT || k == KIND_LATE) ? 1 : 0; }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) np += __shfl_xor(np, d);
-            if (np > 0) {
-                unsigned long long pos = 0;
-                if (lane == 0) pos = atomicAdd(qctl, static_cast<unsigned long long>(np)) & 0xffffffffULL;
-                pos = __shfl(pos, 0);
-                int w = 0;                             // lane 0 writes the few entries (np is 3 .. 6)
-                if (lane == 0) {
-                    const unsigned long long tag = static_cast<unsigned long long>(static_cast<unsigned>(epoch)) << 32;
-                    for (int i = i0; i < cnt; ++i) {
-                        const int2 e = sh.obuf[i];
-                        if (e.y != KIND_HIT && e.y != KIND_LATE) continue;
-                        const long long qi = static_cast<long long>(pos) + w;
-                        if (qi < qcap) {
-                            unsigned long long *q = queue + 4 * qi;
-                            const unsigned pred = static_cast<unsigned>(i > 0 ? sh.obuf[i - 1].x : job.start);
-                            __hip_atomic_store(q + 0, tag | pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(q + 1, tag | static_cast<unsigned>(e.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(q + 2, tag | static_cast<unsigned>(jb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(q + 3, tag | static_cast<unsigned>(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        ++w;
-                    }
-                }
-            }
-        }
-        ps_sync<64>();                                 // obuf is reused by the next tile
-    }
-    if (lane == 0) atomicAdd(qctl, 1ULL << 32);        // this producer is done (its reservations precede this in the same word)
-    // ---- consumer: speculative subtree jobs from the queue ----
-    if (flags & 1) __builtin_amdgcn_s_setprio(0);
-    const unsigned nprod = gridDim.x;
-    for (;;) {
-        if ((flags & 2) && static_cast<unsigned>(ld_agent_u64(qctl) >> 32) == nprod) break;
-        unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(qhead, 1ULL);
-        t = __shfl(t, 0);
-        int4 e = make_int4(0, 0, 0, 0);                // (pred, anchor, tile, list index)
-        bool have = false;
-        const unsigned uep = static_cast<unsigned>(epoch);
-        for (;;) {                                     // wait for entry t, or for the end of the queue
-            if (static_cast<long long>(t) < qcap) {
-                const unsigned long long *q = queue + 4 * t;
-                const unsigned long long w3 = ld_agent_u64(q + 3);
-                if (static_cast<unsigned>(w3 >> 32) == uep) {
-                    const unsigned long long w0 = ld_agent_u64(q + 0), w1 = ld_agent_u64(q + 1), w2 = ld_agent_u64(q + 2);
-                    if (static_cast<unsigned>(w0 >> 32) == uep && static_cast<unsigned>(w1 >> 32) == uep && static_cast<unsigned>(w2 >> 32) == uep) {
-                        e = make_int4(static_cast<int>(w0 & 0xffffffffULL), static_cast<int>(w1 & 0xffffffffULL),
-                                      static_cast<int>(w2 & 0xffffffffULL), static_cast<int>(w3 & 0xffffffffULL));
-                        have = true;
-                        break;
-                    }
-                }
-            }
-            const unsigned long long ctl = ld_agent_u64(qctl);
-            if (static_cast<unsigned>(ctl >> 32) == nprod && t >= (ctl & 0xffffffffULL)) break;
-            __builtin_amdgcn_s_sleep(64);
-        }
-        if (!have) break;
-        const SpineJob job = jobs[e.z];
-        TreeJob tj;
-        tj.base = job.base; tj.start = e.x; tj.end = e.y;
-        tj.j0 = left_child_j0(e.x, e.y, c.W, c.half);
-        tj.out_cap = (e.y - e.x) / c.mw + 1;
-        // region of the pair inside the tile's speculative area: (pred - tile start)/min_width + list index is monotone
-        // and non-overlapping ((a+b)/m >= a/m + b/m)
-        const int li = e.w;
-        tj.out_off = spec_base + job.spec_off + (e.x - job.start) / c.mw + li;
-        tj.ev = job.ev; tj.pad_ = 0;
-        const int n = tree_job<64, DT, true>(c, nullptr, tj, 0, tscratch, tspill, nullptr, sh, bad, wk);
-        if (lane == 0) {
-            SpecRec r; r.pred = e.x; r.anchor = e.y; r.cnt = n; r.epoch = epoch;
-            rec[job.out_off + li] = r;
-        }
-    }
-    flush(bad, wk, status, work, 0);
-}
-
 template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
@@ -1659,7 +1528,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
                               // (4 streams: 0.354 -> 0.347 ms per step; single-wave workgroups 0.345)
 constexpr int TREE_W = PS_TREE_W;
 template <int DT>
-__global__ __launch_bounds__(64 * TREE_W, 2) PS_SCAN_REGS void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+__global__ __launch_bounds__(64 * TREE_W, PS_BS_MINW) PS_SCAN_REGS void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr,
                                                   unsigned long long *tail_ctr, int tail_pct)
@@ -1924,8 +1793,7 @@ __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
 __global__ __launch_bounds__(256) void assemble_items_kernel(
     const SpineJob *jobs, int n_tiles, const int4 *meta, const int2 *lists, const int2 *bridges,
     const int *entry, const long long *sp_off, long long n_items_host, int mw, int W,
-    TreeJob *tjobs, Item *items, int32_t *counts, const AsmHeader *hdr,
-    const SpecRec *spec_rec, int epoch, long long spec_base)
+    TreeJob *tjobs, Item *items, int32_t *counts, const AsmHeader *hdr, const int4 *ev_info)
 {
     const long long n_items = dev_count(hdr, n_items_host);
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n_items; i += gridDim.x * 256LL) {
@@ -1940,11 +1808,9 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     const SpineJob jb2 = jobs[g];
     int2 el;
     int pred;
-    long long slot = -1;                               // list slot of the anchor (speculative subtree records)
     if (k < cnt - en) {
         el = lists[jb2.out_off + en + k];
         pred = (en + k) > 0 ? lists[jb2.out_off + en + k - 1].x : jb2.start;
-        slot = jb2.out_off + en + k;
     } else {
         const int kb = k - (cnt - en);
         el = bridges[static_cast<long long>(g) * BR_MAX + kb];
@@ -1963,19 +1829,14 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     tj.j0 = left_child_j0(pred, el.x, W, W / 2);
     tj.out_cap = has ? (el.x - pred) / mw + 1 : 0;       // 0 marks "no left subtree": the tree kernel skips it
     tj.out_off = (jb2.vbase + pred) / mw + i;
-    tj.ev = jb2.ev; tj.pad_ = 0;
-    int done_cnt = 0;
-    if (has && spec_rec != nullptr && slot >= 0) {
-        // the subtree of exactly this pair was computed speculatively by the spine kernel in this call: take it
-        const SpecRec r = spec_rec[slot];
-        if (r.epoch == epoch && r.pred == pred && r.anchor == el.x) {
-            tj.out_cap = 0;
-            tj.out_off = spec_base + jb2.spec_off + (pred - jb2.start) / mw + (en + k);
-            done_cnt = r.cnt;
-        }
-    }
+    tj.pad_ = 0;
+    if (ev_info) {
+        const int4 info = ev_info[jb2.ev];
+        tj.m = info.x;
+        tj.boff = (static_cast<long long>(static_cast<unsigned>(info.w)) << 32) | static_cast<unsigned>(info.z);
+    } else { tj.m = 0; tj.boff = 0; }
     tjobs[i] = tj;
-    counts[i] = done_cnt;
+    counts[i] = 0;
     }
 }
 
