@@ -91,13 +91,14 @@ struct ps_ctx {
     double wide_quantum = 0;  // quantum of the last call K0 refused (counts too wide) ...
     int wide_skip = 0;        // ... and the number of calls with that quantum that still start where that call ended:
     int wide_mode = 0;        // ... 2 = block-sum scan on the 64-bit digest, 0 = LDS-window scan
-    int tree_mw = 1;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list
+    int tree_mw = 0;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list (round 3: single-wave workgroups are faster at four waves per SIMD and need no spills)
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     int wide_bs = 1;          // 1: counts too wide for the 32-bit digest are retried on the 64-bit digest, 0: straight to the LDS-window scan
     int bridge_single = 1 << 30;   // anchors a single-wave bridge adds before it hands the seam to the look-ahead kernel (measured: handing over early is slower)
     int tree_tail_pct = 0;    // tree_mw_kernel: share of the job list drawn dynamically (counter in HBM) at the end
+    int slots_pct = 100;      // share of the resident wave slots the scan kernels are launched on (the rest is left to other calls' kernels)
     // host-side caches: occupancy per kernel, dynamic-LDS attribute last set, the tile tables of the last call
     struct OccKey { const void *fn; int nt; size_t lds; unsigned slots; };
     std::vector<OccKey> occ_cache;
@@ -204,7 +205,9 @@ template <typename K> unsigned resident_slots(ps_ctx *ctx, K kernel, int nt, siz
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, lds) != hipSuccess || per_cu <= 0)
         per_cu = 1;
-    const unsigned slots = static_cast<unsigned>(per_cu) * static_cast<unsigned>(ctx->n_cu);
+    unsigned slots = static_cast<unsigned>(per_cu) * static_cast<unsigned>(ctx->n_cu);
+    if (std::getenv("PORESEG_DEBUG")) fprintf(stderr, "[poreseg] occupancy: %d workgroups of %d threads per CU (dynamic LDS %zu), %d CUs\n", per_cu, nt, lds, ctx->n_cu);
+    if (nt <= 256) slots = std::max(1u, static_cast<unsigned>(static_cast<unsigned long long>(slots) * static_cast<unsigned>(ctx->slots_pct) / 100u));
     ctx->occ_cache.push_back({fn, nt, lds, slots});
     return slots;
 }
@@ -457,18 +460,15 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
 #endif
 #ifdef PS_STAMP
     {
-        static const char *nm[12] = {"stage_tail", "minmax", "chunksum", "scan", "eval", "top2", "exact", "outside", "ld_issue", "ld_wait", "-", "-"};
+        static const char *nm[12] = {"level", "sweep", "drain", "decide", "contend", "setup", "exact", "outside", "-", "-", "-", "-"};
         unsigned long long tot = 0;
-        for (int i = 0; i < 9; ++i) tot += hs.stamp[i];
-        fprintf(stderr, "[poreseg stamps] thread-0 cycles summed over workgroups (spine+tree):");
-        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
+        for (int i = 0; i < 8; ++i) tot += hs.stamp[i];
+        fprintf(stderr, "[poreseg stamps] lane-0 cycles summed over waves (spine+bridge+tree):");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
         fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
-        fprintf(stderr, "[poreseg stamps] (block-sum scan: top2=entry, ld_issue=block-sum loads+adds, stage_tail=wave scans+setup, minmax=boundary sweep, chunksum=drain, scan=reduce+decide, eval=contenders)\n");
         for (int k = 0; k < 3; ++k)
             fprintf(stderr, "[poreseg stamps] %s: longest workgroup %llu cycles, windows %llu, sum of lifetimes %llu cycles\n",
                     k == 0 ? "spine" : k == 1 ? "bridge" : "tree", hs.life[3 * k], hs.life[3 * k + 1], hs.life[3 * k + 2]);
-        fprintf(stderr, "[poreseg stamps] block-sum scan fallbacks: queue overflow %llu, screen guard %llu, contender overflow %llu\n",
-                hs.stamp[9], hs.stamp[10], hs.stamp[11]);
     }
 #endif
     const int64_t total = h_bounds_off[n_ev];
@@ -802,6 +802,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_SLOTS_PCT")) ctx->slots_pct = std::max(1, std::min(100, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);

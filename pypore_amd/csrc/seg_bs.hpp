@@ -471,12 +471,20 @@ __device__ __forceinline__ int bs_a1(uint2 e, int o1) { return bs8_s1(e) + o1; }
 __device__ __forceinline__ double bs_a2(uint2 e, double k2) { return bs8_s2_biased(e) + k2; }
 __device__ __forceinline__ long long bs_a1(const int4 &e, long long o1) { return i64_of(e.x, e.y) + o1; }
 __device__ __forceinline__ long long bs_a2(const int4 &e, long long o2) { return i64_of(e.z, e.w) + o2; }
+// count of one sample WITHOUT the grid check: every sample of an event was validated by K0 before a scan reads it
+template <int DT>
+__device__ __forceinline__ int bs_count(const DevCfg &c, int64_t gi)
+{
+    if (sdt(DT) == PS_DTYPE_F32) return __float2int_rn(static_cast<const float *>(c.samples)[gi] * c.inv_q);
+    return static_cast<int>(static_cast<const int16_t *>(c.samples)[gi]) + c.off_counts;
+}
 constexpr int BS_NC = 64;                                 // contenders kept per window
-#ifndef PS_BS_G
-#define PS_BS_G 2
+#ifndef PS_BS_D
+#define PS_BS_D 4
 #endif
-constexpr int BS_G = PS_BS_G;                             // rows per group (loads in flight: two groups)
-constexpr int BS_QN = 64 * BS_G + 64;                     // queued blocks; a drain is forced when a group may not fit
+constexpr int BS_D = PS_BS_D;                             // rows in flight: a ring of digest entries in registers (8 bytes each), row r + BS_D
+                                                          // is requested when row r has been evaluated -- the prefetch distance of a lone chain
+constexpr int BS_QN = 192;                                // queued blocks; a drain is forced when the next row may not fit
 constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
 constexpr int BS_LDS_BYTES = static_cast<int>(sizeof(BsQ)) * BS_QN + static_cast<int>(sizeof(BsC)) * BS_NC + 64 * 32;
 static_assert(sizeof(QEnt) * SharedT<64>::QN >= BS_LDS_BYTES, "SharedT<64>::q too small");   // (64 * 32: staged blocks of the wide digest, 8 int32 each)
@@ -634,6 +642,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         bad |= static_cast<unsigned>(ex >> 32);
         return uni(static_cast<int>(ex));
     }
+    PS_STAMP_AT(wk, 7);                                // (diagnostic build) time between scans: recursion control, stack
     const int m = er.m;
     const ent_t *bsw = static_cast<const ent_t *>(c.bsum) + gb0;      // bsw[t]: chunk prefix at boundary t = 0..nblk
     const long long c0 = gb0 >> BS_CHUNK_LOG;
@@ -642,8 +651,10 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     // everything the window needs before its first boundary, issued together
     const int nh = g0 - ps, nt = pe - g1;              // ragged head [ps, g0) and tail [g1, pe): <= 7 raw samples each
     int yht = 0;
-    if (lane < nh) yht = load_count<DT>(c, base + ps + lane, bad) - m;
-    if (lane >= 32 && lane - 32 < nt) yht = load_count<DT>(c, base + g1 + (lane - 32), bad) - m;
+#ifndef PS_X_NOHT                                        // (timing experiments only: wrong results)
+    if (lane < nh) yht = bs_count<DT>(c, base + ps + lane) - m;
+    if (lane >= 32 && lane - 32 < nt) yht = bs_count<DT>(c, base + g1 + (lane - 32)) - m;
+#endif
     int4 ct = make_int4(0, 0, 0, 0);
     int yab = 0;
     if (lane < nch) {
@@ -651,11 +662,13 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         else { ct = c.chunk_tot[c0 + lane]; yab = ct.y; }
     }
     const ent_t e0 = bsw[0], eN = bsw[nblk];
-    const int tS = min(nblk, lane * rows);             // one sampled boundary per lane, spread over the window
+    // one sampled boundary per lane, spread over the window (also in subtree windows, which rarely hold a split: without
+    // the raised pruning level the few that do queue hundreds of blocks -- measured, subtree kernel 0.175 -> 0.21 ms)
+    const int tS = min(nblk, lane * rows);
     const ent_t smp = bsw[tS];
-    ent_t ga[BS_G], gb[BS_G];                          // two groups of rows: the next group's loads are in flight while this one is evaluated
+    ent_t ring[BS_D];                                  // rows in flight
 #pragma unroll
-    for (int i = 0; i < BS_G; ++i) ga[i] = row_load(i);
+    for (int i = 0; i < BS_D; ++i) ring[i] = row_load(i);
     // head / tail sums (lanes 0..7 head, 32..39 tail)
     s1_t H1, TL1;
     s2_t H2, TL2;
@@ -712,6 +725,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #undef PS_ROW_STEPS
 #undef PS_BC_STEPS
     }
+    PS_STAMP_AT(wk, 5);                                // setup loads + head / tail / chunk scans
     const double T1d = uni(bs_d(T1)), T2d = uni(bs_d(T2));                // window totals about m
     const double dn = static_cast<double>(n);
     const double Dtot = dn * T2d - T1d * T1d;
@@ -745,7 +759,9 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     float cbound = INFINITY;                           // bound of the stretch between this lane's sample and the next lane's
     bool hitlike = false;                              // (uniform) a sampled candidate lies above the threshold band
     {
-        // pruning level from the sampled boundary candidates
+        // pruning level from the sampled boundary candidates (one per lane, spread evenly over the window: 64 scattered
+        // cache lines -- sampling the chunk starts instead, whose sums need no load, was measured: coarser samples skip
+        // fewer rows and queue more blocks, spine 0.193 -> 0.225 ms)
         const int J = g0 + 8 * tS;
         const int cs = (gbl + tS) >> BS_CHUNK_LOG;
         const s1_t a1 = bs_a1(smp, static_cast<s1_t>(__shfl(off1, cs)));
@@ -781,6 +797,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             }
         }
     }
+    PS_STAMP_AT(wk, 0);                                // totals, pruning level from the sampled boundaries
     int ccount = 0;
 #define PS_COLLECT(COND, G, JJ, A1, A2)                                                                       \
     {                                                                                                         \
@@ -830,6 +847,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #endif
             // drain: interior candidates of the queued blocks
             ps_sync<64>();
+            PS_STAMP_AT(wk, 1);                        // boundary sweep
             for (int r = 0; r < qcount; r += 64) {
                 // (a) one queued block per lane: its 8 samples, as int16 offsets from m, go to LDS
                 const int nb = min(64, qcount - r);
@@ -837,7 +855,11 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                     const int64_t gq = base + bs_q_j(queue[r + lane], ps) - 8;
                     int y[8];
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) y[w] = load_count<DT>(c, gq + w, bad) - m;
+#ifdef PS_X_NODRAINLD
+                    for (int w = 0; w < 8; ++w) y[w] = static_cast<int>(gq & 3) + w;
+#else
+                    for (int w = 0; w < 8; ++w) y[w] = bs_count<DT>(c, gq + w) - m;
+#endif
                     if constexpr (WIDE) {
                         ybuf[2 * lane] = make_int4(y[0], y[1], y[2], y[3]);
                         ybuf[2 * lane + 1] = make_int4(y[4], y[5], y[6], y[7]);
@@ -889,6 +911,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 ps_sync<64>();
             }
             qcount = 0;
+            PS_STAMP_AT(wk, 2);                        // drain
         };
         // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t); the row's boundaries lie in at most two chunks
         auto do_row = [&](int r, const ent_t &cur) {
@@ -897,8 +920,10 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const int cA = min(tb >> BS_CHUNK_LOG, nch - 1), cB = min(cA + 1, nch - 1);
             const int lsw = ((tb >> BS_CHUNK_LOG) + 1) * BS_CHUNK - tb;    // first lane in the second chunk (>= 64: none)
             const bool second = lane >= lsw;
-            const s1_t o1 = second ? lane_get(off1, cB) : lane_get(off1, cA);
-            const o2_t o2 = second ? lane_get(off2, cB) : lane_get(off2, cA);
+            const s1_t o1A = lane_get(off1, cA), o1B = lane_get(off1, cB);   // (both read unconditionally: a select, not a branch)
+            const o2_t o2A = lane_get(off2, cA), o2B = lane_get(off2, cB);
+            const s1_t o1 = second ? o1B : o1A;
+            const o2_t o2 = second ? o2B : o2A;
             const int nl = nl0 + 8 * BS_STRIDE * r, J = ps + nl;
             const float nlf = static_cast<float>(nl);
             const double nld = static_cast<double>(nl);
@@ -952,50 +977,41 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             }
             if (phase) PS_COLLECT(ge >= Tc, ge, J, a1, a2)
         };
+        // One row at a time (no interleaving of rows: the four waves of the SIMD cover each other's latencies, and a row
+        // evaluated alone keeps the kernel at 128 registers); its slot of the ring is refilled as soon as it is free.
         if (!hitlike) {
-            // every row, BS_G at a time in straight-line code (rows past the end are inert)
             if (phase) {
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) ga[i] = row_load(i);
+                for (int i = 0; i < BS_D; ++i) ring[i] = row_load(i);
             }
-            for (int r0 = 0; r0 < rows; r0 += 2 * BS_G) {
-                if (qcount > BS_QN - 64 * BS_G) drain();
+            for (int r0 = 0; r0 < rows; r0 += BS_D) {
 #pragma unroll
-                for (int i = 0; i < BS_G; ++i) gb[i] = row_load(r0 + BS_G + i);
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) do_row(r0 + i, ga[i]);
-                if (r0 + BS_G >= rows) break;
-                if (qcount > BS_QN - 64 * BS_G) drain();
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) ga[i] = row_load(r0 + 2 * BS_G + i);
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) do_row(r0 + BS_G + i, gb[i]);
+                for (int i = 0; i < BS_D; ++i) {
+                    if (r0 + i < rows) {
+                        if (qcount > BS_QN - 64) drain();
+                        do_row(r0 + i, ring[i]);
+                    }
+                    // (unconditional, clamped past the end: a load under a condition makes the compiler's count of the loads
+                    //  in flight imprecise, and every row then waits for the newest request instead of its own)
+                    ring[i] = row_load(r0 + i + BS_D);
+                }
             }
         } else {
-            // live rows only (a window that holds a split: typically 2 .. 4 of 20); an empty slot of a group loads row 0
-            // again, so that no branch stands between the loads
-            int ra[BS_G], rb[BS_G];                    // (uniform) row indices of the two groups, -1: none
+            // live rows only (a window that holds a split: typically 2 .. 4 of 20)
+            int rr[BS_D];                              // (uniform) row of every slot, -1: none
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) ra[i] = take_row();
+            for (int i = 0; i < BS_D; ++i) { rr[i] = take_row(); ring[i] = row_load(rr[i]); }
+            for (bool any = true; any;) {
+                any = false;
 #pragma unroll
-            for (int i = 0; i < BS_G; ++i) ga[i] = row_load(ra[i]);
-            for (;;) {
-                if (ra[0] < 0) break;
-                if (qcount > BS_QN - 64 * BS_G) drain();
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) rb[i] = take_row();
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) gb[i] = row_load(rb[i]);
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) if (ra[i] >= 0) do_row(ra[i], ga[i]);
-                if (rb[0] < 0) break;
-                if (qcount > BS_QN - 64 * BS_G) drain();
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) ra[i] = take_row();
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) ga[i] = row_load(ra[i]);
-#pragma unroll
-                for (int i = 0; i < BS_G; ++i) if (rb[i] >= 0) do_row(rb[i], gb[i]);
+                for (int i = 0; i < BS_D; ++i) {
+                    if (rr[i] >= 0) {
+                        if (qcount > BS_QN - 64) drain();
+                        do_row(rr[i], ring[i]);
+                        any = true;
+                    }
+                    if (any) { rr[i] = take_row(); ring[i] = row_load(rr[i]); }
+                }
             }
         }
         drain();
@@ -1023,6 +1039,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #ifdef PS_NOEXACT
         if (result == -2) result = ab < thr_log2 ? -1 : ps + ai;       // timing experiment only: never the product
 #endif
+        PS_STAMP_AT(wk, 3);                            // wave maximum / top-2, decision
         if (result != -2 || anyflag) break;
         // Ambiguous for the screen (inside the threshold band, or a near tie): collect the contenders.
         // The screen is within delta of the reference gain, so the reference's choice has a screened
@@ -1043,6 +1060,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         result = uni(static_cast<int>(dr));
         wk.exact += 1; wk.near += uni(static_cast<int>(dr >> 32));
     }
+    PS_STAMP_AT(wk, 4);                                // contenders + fp64 decision
     if (c.mode == MODE_VERIFY || result == -2) {
         wk.exact += (1LL << 32);                       // high word: full exact scans
         const long long exr = bs_scan_exact<DT>(bs_cold(c), base + ps, ps, n, cand_lo, cand_hi, thresh, &sh);

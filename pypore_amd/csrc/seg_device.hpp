@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(64 * BR_LA, (PS_BS_MINW > 3 ? 3 : PS_BS_MINW)) PS_S
     __shared__ int2 obuf[BR_MAX];
     __shared__ int2 res[BR_LA];                        // per wave: (outcome, value)
     if ((*status & ST_WIDE_RANGE) != 0u) return;       // K0 refused the data: the host redoes the call
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     SharedT<64> &sh = shw[wave];
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
@@ -1460,7 +1460,8 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
             --sp;
             if (tid == 0) sh.pop = sp < SharedT<NT>::SN ? sh.stack[sp] : sp_glob[sp - SharedT<NT>::SN];
             ps_sync<NT>();
-            const int2 top = sh.pop;
+            int2 top = sh.pop;
+            if constexpr (NT == 64) { top.x = __builtin_amdgcn_readfirstlane(top.x); top.y = __builtin_amdgcn_readfirstlane(top.y); }   // (uniform: scalar registers)
             ps_sync<NT>();
             emit(top.x);
             start = top.x; end = top.y; j0 = 0;
@@ -1535,7 +1536,7 @@ __global__ __launch_bounds__(64 * TREE_W, PS_BS_MINW) PS_SCAN_REGS void tree_mw_
 {
     extern __shared__ int ys[];                        // TREE_W x SharedT<64> (beyond the static 64 KB for 8 waves)
     __shared__ int next_k;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));     // (scalar: the wave's LDS block gets a scalar base)
     SharedT<64> &sh = reinterpret_cast<SharedT<64> *>(ys)[wave];
     const long long n_jobs = dev_count(hdr, n_jobs_host);
     // tail_pct > 0 (option tree_tail_pct, default 0): the last tail_pct per cent of the job list are drawn one by one
