@@ -140,17 +140,23 @@ def main():
     # ------------------------------------------------------------------------------------------------ workloads
     if wl in ("trace", "file"):
         if wl == "trace":
-            d = synth.dwell_table(seed, n, *args.dwell) if args.dwell else synth.dwell_table(seed, n)
-            ends = np.cumsum(d)
-            lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
-            trace = ctx.synth_trace(n, seed, ends, lv, dtype=torch.float32)
+            # Independent batches are independent DATA: stream t segments its own trace (generator seed + 1000 t; stream 0
+            # of rank 0 is golden case G7, seed 2024).  T x 0.4 GB of samples resident in HBM.
+            traces = []
+            for t_ in range(T):
+                sd = seed + 1000 * t_
+                d = synth.dwell_table(sd, n, *args.dwell) if args.dwell else synth.dwell_table(sd, n)
+                ends = np.cumsum(d)
+                lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+                traces.append(ctx.synth_trace(n, sd, ends, lv, dtype=torch.float32))
+            trace = traces[0]
             ev_off = np.array([0, n], dtype=np.int64)
             outs = [torch.empty(n // mw + 1, dtype=torch.int32, device=device) for _ in range(T)]   # reused result buffers
 
             def step(k=None, cx=None, t=0):
                 # k: index of a timed batch when the job gathers its boundaries at the end (N > 1): they are written
                 # straight into row k of the send buffer
-                b, o, st = (cx or ctx).segment_batch(trace, ev_off, params, synth.QUANTUM, want_stats=args.stats,
+                b, o, st = (cx or ctx).segment_batch(traces[t], ev_off, params, synth.QUANTUM, want_stats=args.stats,
                                                      out=acc[k] if k is not None and acc is not None else outs[t])
                 if k is not None and acc is not None:
                     acc_counts[k] = b.numel()
@@ -202,13 +208,27 @@ def main():
             b, o, st, sp = ctx.segment_batch(t, off, params, synth.QUANTUM, want_stats=False, want_spine=True, out=out)
             return b, sp
 
+        def regen_segment(lo2, hi2):
+            # a seam without a common anchor inside the halo (long dwells): the stretch is generated and segmented afresh
+            t2 = ctx.synth_trace(hi2 - lo2, seed, ends, lv, dtype=torch.float32, start=lo2)
+            return segment_piece(t2, np.array([0, hi2 - lo2], dtype=np.int64))
+
         if use_dist:
+            def repair(r_up, lo2, hi2):
+                if rank == r_up:
+                    rb, rf = regen_segment(lo2, hi2)
+                else:
+                    rb = torch.zeros(0, dtype=torch.int32, device=device)
+                    rf = torch.zeros(0, dtype=torch.uint8, device=device)
+                gb, gf = pdist.gather_varlen(rb), pdist.gather_varlen(rf)
+                return gb[r_up].cpu().numpy(), gf[r_up].cpu().numpy()
+
             def step(k=None):
                 b, sp = segment_piece(trace, piece_off, out1)
                 allb = pdist.gather_varlen(b)
                 allf = pdist.gather_varlen(sp)
                 pieces = [(ranges[r][0], ranges[r][1], allb[r].cpu().numpy(), allf[r].cpu().numpy()) for r in range(world)]
-                return pdist.stitch_pieces(pieces, n, W, mw)
+                return pdist.stitch_pieces(pieces, n, W, mw, repair=repair, halo=halo)
         else:
             def step(k=None):
                 b, sp = segment_piece(trace, piece_off, out1)
@@ -333,11 +353,37 @@ def main():
     # ------------------------------------------------------------------------------------------------ parity evidence
     if wl in ("trace", "file"):
         bounds = result
+        if wl == "trace" and rank == 0:
+            import hashlib
+            # (a) the results the T streams produced in flight == the same traces segmented one call at a time on context 0
+            last = {}
+            for k_, r_ in enumerate(results):
+                last[k_ % T] = r_.clone() if T > 1 else r_
+            same = True
+            per_stream = []
+            for t_ in sorted(last):
+                one, _, _ = ctx.segment_batch(traces[t_], ev_off, params, synth.QUANTUM, want_stats=False)
+                same = same and bool(torch.equal(one, last[t_]))
+                per_stream.append(int(one.numel()))
+            check["all_streams_equal_single_stream"] = same
+            check["boundaries_per_stream"] = per_stream
+            bounds = last[0]
+            # (b) stream 0's trace is golden case G7 (tests/golden/manifest.json: SHA-256 of the reference's boundaries)
+            if n == 100_000_000 and not args.dwell and seed == 2024:
+                try:
+                    with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
+                        g7 = [c for c in json.load(f)["cases"] if c["name"] == "G7_1e8"][0]
+                    b0 = last[0].cpu().numpy().astype(np.int32)
+                    check["g7_sha256_equal"] = bool(hashlib.sha256(b0.tobytes()).hexdigest() == g7["sha256"] and len(b0) == g7["n_bounds"])
+                except (OSError, IndexError, KeyError):
+                    check["g7_sha256_equal"] = None
+            assert check["all_streams_equal_single_stream"] and check.get("g7_sha256_equal", True) is not False, check
         if use_dist:
             all_counts = recv_counts.view(world, steps).cpu().numpy()
             n_bounds = [int(c) for c in all_counts[:, -1]]            # the last batch's boundaries, all ranks
             mine_row = recv.view(world, steps, -1)[rank, steps - 1, :n_bounds[rank]]
-            assert torch.equal(mine_row, bounds), "boundary gather returned something else for this rank"
+            # (the last batch ran on stream (steps - 1) % T, i.e. on that stream's trace)
+            assert torch.equal(mine_row, results[-1][:n_bounds[rank]]), "boundary gather returned something else for this rank"
         else:
             n_bounds = [int(bounds.numel())]
     elif wl == "sharded-trace":
@@ -351,8 +397,10 @@ def main():
                 for (plo, phi) in pr:
                     b, sp = segment_piece(trace[plo:phi], np.array([0, phi - plo], dtype=np.int64))
                     pieces.append((plo, phi, b.cpu().numpy(), sp.cpu().numpy()))
-                ref = pdist.stitch_pieces(pieces, n, W, mw)
+                ref = pdist.stitch_pieces(pieces, n, W, mw, halo=halo,
+                                          repair=lambda r_, lo2, hi2: tuple(x_.cpu().numpy() for x_ in regen_segment(lo2, hi2)))
                 check["whole_trace_equals_8_stitched_pieces"] = bool(np.array_equal(ref, got))
+                check["seam_repairs"] = int(pdist.stitch_pieces.last_repairs)
             else:
                 b, sp = segment_piece(trace, piece_off)
                 mine_g = b.cpu().numpy().astype(np.int64) + lo
@@ -377,7 +425,7 @@ def main():
                 traffic = json.load(f)                   # {"source": ..., "total": bytes, "per_kernel": {...}}
         workload_text = {
             "trace": "one %.0e-sample fp32 trace per GPU (5-level step signal, dwell U[1000,20000), sigma 1 pA, 2^-5 pA grid), "
-                     "single SpeedyStatSplit.parse over the whole trace" % n,
+                     "single SpeedyStatSplit.parse over the whole trace; every stream segments its own trace (seeds 2024 + 1000 t)" % n,
             "file": "BASELINE config 3: one %.0e-sample int16 .abf-shaped trace per GPU @100 kHz (110 pA open channel, blockade "
                     "events 1.5-10 s with dwells U[1000,20000)); lambda_event_parser(threshold=90) -> per-event "
                     "SpeedyStatSplit, end to end on the GPU" % n,
@@ -440,7 +488,8 @@ def main():
             "host": {"omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "torch_threads": torch.get_num_threads(),
                      "affinity_cpus": len(os.sched_getaffinity(0)), "under_torchrun": "TORCHELASTIC_RUN_ID" in os.environ},
             "fallbacks": {"host_stitch": int(tm["repairs"] >= 1000000), "seam_repairs": int(tm["repairs"] % 1000000),
-                          "wide_range_redo": int(tm.get("wide_redo", 0)), "full_exact_scans": int(tm["full_exact_scans"])},
+                          "wide_range_redo": int(tm.get("wide_redo", 0)), "full_exact_scans": int(tm["full_exact_scans"]),
+                          "near_ties": int(tm.get("near_ties", 0))},
         }
         # ---- PCIe-inclusive rate (report H2D-inclusive separately; never `value`) ------------------
         if wl == "trace" and not args.no_h2d and world == 1:

@@ -189,7 +189,8 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
  * *centre_out, rounded to multiples of *step_out -- centre = the mean rounded to the grid, step = the finest power of two
  * that keeps every count below 2^22 (what DataTypes.Event.parse does on the host for a single event).  Segment d_out with
  * quantum = *step_out; the gains are shift invariant, so the boundaries are those of the rounded current.  Synchronises
- * the context's stream once (the statistics come back to the host). */
+ * the context's stream twice: for the statistics (they come back to the host) and before returning (d_out is complete
+ * and d_in no longer read when the call returns). */
 int ps_requantise(ps_ctx *ctx, const double *d_in, int64_t n, float *d_out, double *centre_out, double *step_out);
 
 /* Replaces cSegmentAligner(model_means, model_stds, model_durs, skip_penalty, backslip_penalty).align(seq_means,
@@ -225,7 +226,10 @@ int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_mod
  * positions covered, [2] tiles, [3] tree jobs, [4] seam repairs, [5] windows decided in fp64 (among
  * contenders or by a whole-window scan), [6] of which whole-window scans, [7] 1 = the call was redone on the 64-bit
  * digest, 2 = on the LDS-window kernels (counts too wide for the block sums), [8] [9] [10] window scans of the spine /
- * bridge / subtree kernels. */
+ * bridge / subtree kernels, [11] near ties: windows decided among fp64 contenders whose margin -- winner against the best
+ * other candidate, or against min_gain -- is below 1e-9 * max(1, |gain|).  The device logarithm is not glibc's bit for bit
+ * (gains differ by ~1e-11), so the reference could have decided such a window the other way; exact ties are decided like
+ * the reference (first maximum wins, cparsers.pyx:175-177) and counted too. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);
 
 /* Synthetic step-signal generator (bit-identical to pypore_amd/synth.py):

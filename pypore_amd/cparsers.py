@@ -14,7 +14,10 @@ class FastStatSplit(object):
     def __init__(self, min_width=100, max_width=1000000, window_width=10000,
                  min_gain_per_sample=None, false_positive_rate=None,
                  prior_segments_per_second=None, sampling_freq=1.e5, cutoff_freq=None,
-                 quantum=None, device=None, offset=None):
+                 quantum=None, device=None, offset=None, off_grid="raise"):
+        if off_grid not in ("raise", "requantise"):
+            raise ValueError("off_grid must be 'raise' or 'requantise'")
+        self.off_grid = off_grid
         self.min_width = int(min_width)
         self.max_width = int(max_width)
         self.window_width = int(window_width)
@@ -53,12 +56,42 @@ class FastStatSplit(object):
                 q = min(p.quantum for p in parts)
             return parts, q
 
-        def run(idx):
-            parts, q = upload(idx, False)
+        def requantised(i):
+            """off_grid="requantise": float input that lies on no ADC grid (the reference takes any float64 buffer,
+            cparsers.pyx:53,103-111 -- filtered or resampled on the host, np.random.normal test data) is centred and
+            rounded on the device to the finest power-of-two grid that keeps its counts below 2**22 (ps_requantise, what
+            Event.parse does for a filtered event) and segmented on the 64-bit digest.  The segments hold views of the
+            ORIGINAL values and take their statistics from those."""
+            cur = np.ascontiguousarray(currents[i], dtype=np.float64)
+            if cur.ndim != 1:
+                raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % cur.ndim)
+            n = cur.size
+            if n == 0:
+                out[i] = [Segment(current=currents[i][0:0], start=0, duration=0, end=0)]
+                return
+            dev = torch.device("cuda", torch.cuda.current_device() if self.device is None else int(self.device))
+            z, _, step = ctx.requantise(torch.from_numpy(cur).to(dev))
+            bounds, boff, _ = ctx.segment_batch(z, np.array([0, n], dtype=np.int64), self._params, step, want_stats=False)
+            edges = np.concatenate(([0], bounds.cpu().numpy(), [n])).tolist()
+            src = currents[i]
+            out[i] = [Segment(current=src[a:z_], start=a, duration=z_ - a, end=z_) for a, z_ in zip(edges, edges[1:])]
+
+        def run(idx, full_detect=False):
+            try:
+                parts, q = upload(idx, full_detect)
+            except ValueError:
+                if self.off_grid != "requantise" or self.quantum is not None:
+                    raise
+                if len(idx) > 1:                    # find the event(s) without a grid
+                    for i in idx:
+                        run([i], full_detect)
+                else:
+                    requantised(idx[0])
+                return
             kinds = {(p.tensor.dtype, p.quantum if p.tensor.dtype == torch.int16 else None) for p in parts}
             if len(kinds) > 1:                      # (float input that resolved to different grids: one call each)
                 for i in idx:
-                    run([i])
+                    run([i], full_detect)
                 return
             if parts[0].tensor.dtype == torch.int16:
                 q = parts[0].quantum
@@ -68,13 +101,16 @@ class FastStatSplit(object):
                 samples = parts[0].tensor if len(parts) == 1 else torch.cat([p.tensor for p in parts])
                 bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
             except ValueError:
-                if self.quantum is not None:
+                if self.quantum is not None or full_detect:
+                    if self.off_grid == "requantise" and self.quantum is None and len(idx) == 1:
+                        requantised(idx[0])
+                        return
                     raise
                 # the grid was detected on a subset of the samples and the device found a sample off it: search all
-                # samples for the grid once (still ValueError if there is none)
-                parts, q = upload(idx, True)
-                samples = parts[0].tensor if len(parts) == 1 else torch.cat([p.tensor for p in parts])
-                bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
+                # samples for the grid once (still ValueError if there is none) -- through run(), so that events which
+                # then resolve to different representations are split again
+                run(idx, True)
+                return
             b = bounds.cpu().numpy()
             st = stats.cpu().numpy()
             for e, i in enumerate(idx):

@@ -1505,6 +1505,8 @@ int ps_requantise(ps_ctx *ctx, const double *d_in, int64_t n, float *d_out, doub
     const unsigned rg = static_cast<unsigned>(std::min<int64_t>(65535, (n + 4 * RQ_NT - 1) / (4 * RQ_NT)));
     hipLaunchKernelGGL(requant_round_kernel, dim3(rg), dim3(RQ_NT), 0, ctx->stream, d_in, static_cast<long long>(n), centre, 1.0 / step, step, d_out);
     HIP_TRY(ctx, hipGetLastError());
+    // (the context's stream does not block on torch's: the caller may read d_out, or free d_in, as soon as this returns)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *centre_out = centre; *step_out = step;
     return PS_OK;
 }

@@ -144,32 +144,73 @@ def shard_ranges(n, world_size, halo):
     return [(starts[r], min(n, starts[r + 1] + (halo if r < world_size - 1 else 0))) for r in range(world_size)]
 
 
-def stitch_pieces(pieces, n, window_width, min_width):
+def stitch_pieces(pieces, n, window_width, min_width, repair=None, halo=None):
     """pieces: per rank (lo, hi, bounds_local int32, is_spine uint8), rank order.  Returns the global
-    breakpoint array.  Raises RuntimeError when a seam finds no common trusted spine anchor
-    (halo too short for this signal)."""
+    breakpoint array.
+
+    Two consecutive pieces are joined at the first spine anchor both found, the upstream one by windows that cannot
+    have touched its end.  A seam without such an anchor inside the halo (dwells longer than the halo, a flat stretch)
+    is REPAIRED when `repair` is given ("extend and re-run that seam only"): rec(a, N) depends only on
+    (a, N, data) (cparsers.pyx:180-203), so the chain is re-run from the last trusted upstream anchor a0 over
+    [a0, next piece start + 2 halo), `repair(r, lo, hi) -> (bounds_local, is_spine)` segmenting [lo, hi) as a stand-alone
+    trace on behalf of upstream piece r; the extension doubles until it shares an anchor with a downstream piece (pieces
+    it covers entirely are dropped) or reaches the end of the trace.  Without `repair` such a seam raises RuntimeError."""
+    if halo is None:
+        halo = 8 * window_width
     out = []
     enter = -1                                   # global position after which the current piece is valid
-    for r, (lo, hi, b, f) in enumerate(pieces):
-        g = np.asarray(b, dtype=np.int64) + lo
-        f = np.asarray(f, dtype=bool)
-        last = r == len(pieces) - 1
-        if last:
+    cur = None                                   # the upstream piece as (lo, hi, global bounds, spine flags)
+    r = 0
+    nxt = 0                                      # index of the next piece to take from `pieces`
+    n_pieces = len(pieces)
+    repairs = 0
+    while True:
+        if cur is None:
+            lo, hi, b, f = pieces[nxt]
+            cur = (lo, hi, np.asarray(b, dtype=np.int64) + lo, np.asarray(f, dtype=bool))
+            r = nxt
+            nxt += 1
+        lo, hi, g, f = cur
+        if nxt >= n_pieces or hi >= n and nxt >= n_pieces:
             out.append(g[g > enter])
             break
-        nlo, nhi, nb, nf = pieces[r + 1]
+        if hi >= n:                              # the (repaired) upstream piece runs to the end of the trace: done
+            out.append(g[g > enter])
+            break
+        nlo, nhi, nb, nf = pieces[nxt]
+        if nhi <= hi and nhi < n:                # downstream piece lies inside the upstream one: nothing new in it
+            nxt += 1
+            continue
         ng = np.asarray(nb, dtype=np.int64) + nlo
         nspine = set(ng[np.asarray(nf, dtype=bool)].tolist())
         # spine anchors of this piece found by windows that cannot have touched its end
-        trust_limit = hi - 2 * window_width - 2 * min_width if hi < n else n
-        cand = g[f & (g >= nlo) & (g > enter) & (g <= trust_limit)]
+        trust_limit = hi - 2 * window_width - 2 * min_width
+        trusted = f & (g > enter) & (g <= trust_limit)
+        cand = g[trusted & (g >= nlo)]
         join = next((int(a) for a in cand if int(a) in nspine), None)
-        if join is None:
+        if join is not None:
+            out.append(g[(g > enter) & (g <= join)])
+            enter = join
+            cur = None
+            continue
+        if repair is None:
             raise RuntimeError("sharded trace: pieces %d and %d share no spine anchor inside the halo "
-                               "(increase halo)" % (r, r + 1))
-        out.append(g[(g > enter) & (g <= join)])
-        enter = join
+                               "(increase halo)" % (r, nxt))
+        # no common anchor: re-run the chain from the last trusted upstream anchor over a longer stretch
+        ta = g[trusted]
+        a0 = int(ta[-1]) if ta.size else (enter if enter >= 0 else lo)
+        ext = 2 * halo * (1 << min(repairs, 20))
+        new_hi = int(min(n, max(hi, nlo) + ext))
+        out.append(g[(g > enter) & (g <= a0)])
+        enter = max(enter, a0)
+        rb, rf = repair(r, a0, new_hi)
+        cur = (a0, new_hi, np.asarray(rb, dtype=np.int64) + a0, np.asarray(rf, dtype=bool))
+        repairs += 1
+    stitch_pieces.last_repairs = repairs
     return np.concatenate(out).astype(np.int64) if out else np.zeros(0, np.int64)
+
+
+stitch_pieces.last_repairs = 0
 
 
 def segment_trace_sharded(n, segment_piece_fn, window_width, min_width, halo=None, device=None, group=None):
@@ -177,7 +218,9 @@ def segment_trace_sharded(n, segment_piece_fn, window_width, min_width, halo=Non
 
     segment_piece_fn(lo, hi) -> (bounds_local int32, is_spine uint8): the local segmenter applied to
     samples [lo, hi) as a stand-alone trace (ps_segment_batch_ex with d_is_spine on this rank's GPU).
-    Every rank returns the full global breakpoint array.  Collectives: the boundary gather only."""
+    Every rank returns the full global breakpoint array.  Collectives: the boundary gather, and for every seam that
+    finds no common anchor inside the halo one more gather of the stretch the UPSTREAM rank re-segments (all ranks
+    walk the same gathered data, so they agree on which seam failed without an extra round)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if halo is None:
@@ -186,7 +229,22 @@ def segment_trace_sharded(n, segment_piece_fn, window_width, min_width, halo=Non
     lo, hi = ranges[rank]
     b, f = segment_piece_fn(lo, hi)
     dev = device if device is not None else torch.device("cpu")
-    allb = gather_varlen(torch.from_numpy(np.ascontiguousarray(b, dtype=np.int32)).to(dev), group)
-    allf = gather_varlen(torch.from_numpy(np.ascontiguousarray(f, dtype=np.uint8)).to(dev), group)
+
+    def gather2(bb, ff):
+        allb = gather_varlen(torch.from_numpy(np.ascontiguousarray(bb, dtype=np.int32)).to(dev), group)
+        allf = gather_varlen(torch.from_numpy(np.ascontiguousarray(ff, dtype=np.uint8)).to(dev), group)
+        return allb, allf
+
+    allb, allf = gather2(b, f)
     pieces = [(ranges[r][0], ranges[r][1], allb[r].cpu().numpy(), allf[r].cpu().numpy()) for r in range(world)]
-    return stitch_pieces(pieces, n, window_width, min_width)
+
+    def repair(r_up, lo2, hi2):
+        # the upstream rank re-segments [lo2, hi2); everybody takes part in the gather of that one stretch
+        if rank == r_up:
+            rb, rf = segment_piece_fn(lo2, hi2)
+        else:
+            rb, rf = np.zeros(0, np.int32), np.zeros(0, np.uint8)
+        gb, gf = gather2(rb, rf)
+        return gb[r_up].cpu().numpy(), gf[r_up].cpu().numpy()
+
+    return stitch_pieces(pieces, n, window_width, min_width, repair=repair, halo=halo)

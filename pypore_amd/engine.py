@@ -59,7 +59,16 @@ class Context(object):
         return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4], bridge_ms=ms[5], blocksum_ms=ms[6], seq_ms=ms[7],
                     windows=cnt[0], candidates=cnt[1], tiles=cnt[2], tree_jobs=cnt[3], repairs=cnt[4],
                     exact_rescans=cnt[5], full_exact_scans=cnt[6], wide_redo=cnt[7],
-                    windows_spine=cnt[8], windows_bridge=cnt[9], windows_tree=cnt[10])
+                    windows_spine=cnt[8], windows_bridge=cnt[9], windows_tree=cnt[10], near_ties=cnt[11])
+
+    def near_ties(self):
+        """Windows of the most recent segment call that were decided among fp64 contenders with a margin inside the
+        noise of the device logarithm against glibc's (1e-9 relative): the reference could have decided
+        them the other way.  0 in every golden vector except the constructed exact tie."""
+        if not hasattr(self, "_tmc"):
+            self._tmc = ((ctypes.c_double * 8)(), (ctypes.c_int64 * 12)())
+        self.L.ps_get_timings(self.handle, self._tmc[0], 8, self._tmc[1], 12)
+        return int(self._tmc[1][11])
 
     # ---- the hot path ---------------------------------------------------------------------------
     def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None,
@@ -100,6 +109,12 @@ class Context(object):
                                         ctypes.c_void_p(stats.data_ptr()) if want_stats else None,
                                         ctypes.c_void_p(spine.data_ptr()) if want_spine else None)
         _lib.check(rc, self.handle)
+        if NEAR_TIE_WARNING:
+            nt = self.near_ties()
+            if nt:
+                import warnings
+                warnings.warn("%d window(s) were decided by a margin below 1e-9 relative (near tie): the reference's libm could "
+                              "round such a decision the other way" % nt, NearTieWarning, stacklevel=2)
         total = int(boff[-1])
         if want_spine:
             return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None), spine[:total]
@@ -247,6 +262,13 @@ class Context(object):
                                          level_counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), seg_end.size),
                    self.handle)
         return out
+
+
+class NearTieWarning(UserWarning):
+    """A segment call decided at least one window by a margin inside the logarithm's rounding noise (Context.near_ties)."""
+
+
+NEAR_TIE_WARNING = True      # set False to skip the counter read after every call (one ps_get_timings, ~1 us)
 
 
 class StreamPool(object):

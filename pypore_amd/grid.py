@@ -19,6 +19,10 @@ class GridArray(np.ndarray):
     def __new__(cls, current, counts, quantum, offset=0.0):
         obj = np.asarray(current).view(cls)
         obj.counts, obj.quantum, obj.offset = counts, float(quantum), float(offset)
+        # The float64 values and the counts must stay in step: in-place edits (a -= baseline, a[i:j] = x, a.sort())
+        # return the same object without passing __array_finalize__ and would leave the counts stale, so the array is
+        # read-only -- such an edit raises ValueError; `np.array(a)` / `a.copy()` give a writable plain array.
+        obj.setflags(write=False)
         return obj
 
     def __array_finalize__(self, obj):
@@ -31,6 +35,10 @@ class GridArray(np.ndarray):
         if isinstance(out, GridArray) and isinstance(index, slice) and self.counts is not None:
             out.counts = self.counts[index]
         return out
+
+    def copy(self, order='C'):
+        """A writable plain float64 array (the counts do not follow edits)."""
+        return np.array(self, dtype=np.float64, order=order, subok=False)
 
     @classmethod
     def from_counts(cls, counts, quantum, offset=0.0):
@@ -72,7 +80,11 @@ def affine_grid(x, sample=65536, tol=1e-6):
         if np.max(np.abs(k - kr)) <= tol:
             if np.max(np.abs(kr)) >= 2 ** 31:
                 break
-            return q, float(u[0]), kr.astype(np.int64)
+            # re-centre: the counts are anchored at the subset minimum (0 .. max - min), and a trace that touches both
+            # int16 rails would leave the int16 range although it is exactly int16 -- shift by the mid-range count
+            ki = kr.astype(np.int64)
+            c = (int(ki.min()) + int(ki.max()) + 1) // 2
+            return q, float(u[0]) + c * q, ki - c
         frac = np.abs(k - kr)
         q = float(np.min(frac[frac > tol])) * q              # a remainder that is itself on the grid, or garbage
     raise ValueError("samples are not on an ADC grid (counts * quantum + offset); pass quantum= and offset=")

@@ -117,12 +117,14 @@ class SpeedyStatSplit(parser):
     """The drop-in segmenter: stores the reference's eight parameters under the reference's names and runs
     FastStatSplit -- here the HIP kernels -- on parse().  Extra keywords (kept out of the JSON): `quantum` / `offset`
     describe the ADC grid of float input (pA per count, pA at count 0; found automatically when omitted), `device`
-    picks the GPU."""
+    picks the GPU, `off_grid` says what happens to float input that lies on NO grid (the reference takes any float64
+    buffer, cparsers.pyx:53): "raise" (default) ValueError -- nothing is rounded silently --, "requantise" rounds it
+    on the device to the finest power-of-two grid that keeps the counts below 2**22."""
 
     def __init__(self, min_width=100, max_width=1000000, window_width=10000,
                  min_gain_per_sample=None, false_positive_rate=None,
                  prior_segments_per_second=None, sampling_freq=1.e5, cutoff_freq=None,
-                 quantum=None, device=None, offset=None):
+                 quantum=None, device=None, offset=None, off_grid="raise"):
         self.min_width = min_width
         self.max_width = max_width
         self.min_gain_per_sample = min_gain_per_sample
@@ -131,7 +133,9 @@ class SpeedyStatSplit(parser):
         self.false_positive_rate = false_positive_rate
         self.sampling_freq = sampling_freq
         self.cutoff_freq = cutoff_freq
-        self._grid = dict(quantum=quantum, device=device, offset=offset)
+        if off_grid not in ("raise", "requantise"):
+            raise ValueError("off_grid must be 'raise' or 'requantise'")
+        self._grid = dict(quantum=quantum, device=device, offset=offset, off_grid=off_grid)
 
     def _fast(self, cutoff=True):
         return FastStatSplit(self.min_width, self.max_width, self.window_width, self.min_gain_per_sample,

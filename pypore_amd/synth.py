@@ -33,13 +33,18 @@ def splitmix64(z):
     return z
 
 
-def noise_counts(seed, start, n):
-    """Integer noise (sigma ~= 32 counts) for sample indices [start, start+n)."""
+def noise_sum(seed, start, n):
+    """Sum of the four 16-bit lanes of the sample hash for indices [start, start+n): Irwin-Hall(4), 0 .. 262140."""
     idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
     with np.errstate(over="ignore"):
         h = splitmix64(np.uint64(seed) + idx * GOLDEN)
-    s = ((h & np.uint64(0xFFFF)) + ((h >> np.uint64(16)) & np.uint64(0xFFFF))
-         + ((h >> np.uint64(32)) & np.uint64(0xFFFF)) + (h >> np.uint64(48))).astype(np.int64)
+    return ((h & np.uint64(0xFFFF)) + ((h >> np.uint64(16)) & np.uint64(0xFFFF))
+            + ((h >> np.uint64(32)) & np.uint64(0xFFFF)) + (h >> np.uint64(48))).astype(np.int64)
+
+
+def noise_counts(seed, start, n):
+    """Integer noise (sigma ~= 32 counts) for sample indices [start, start+n)."""
+    s = noise_sum(seed, start, n)
     return ((s - 131070) * NOISE_MUL + (1 << (NOISE_SHIFT - 1))) >> NOISE_SHIFT
 
 
@@ -79,6 +84,30 @@ def random_dwell_counts(n, seed, lo=1000, hi=20000, chunk=1 << 24):
         seg = np.searchsorted(ends, np.arange(s, e, dtype=np.int64), side="right")
         out[s:e] = LEVEL_COUNTS[seg % 5] + noise_counts(seed, s, e - s)
     return out
+
+
+def offgrid_trace(n, seed, sigma=1.0, lo=1000, hi=20000):
+    """float64 pA on NO ADC grid (what a host-side filter, a resampler or np.random.normal test data produce): the
+    level cycle of the step signals plus two independent, nearly Gaussian noise streams at incommensurate scales.  Only
+    integer hashing and single correctly-rounded float64 operations: bit-reproducible on any IEEE machine."""
+    d = dwell_table(seed, n, lo, hi)
+    ends = np.cumsum(d)
+    seg = np.searchsorted(ends, np.arange(n, dtype=np.int64), side="right")
+    level = (LEVEL_COUNTS[seg % 5].astype(np.float64)) * QUANTUM
+    a = noise_sum(seed, 0, n).astype(np.float64)                # Irwin-Hall(4) of 16-bit lanes, mean 131070, sd 37837.23
+    b = noise_sum(seed ^ 0x5DEECE66D, 0, n).astype(np.float64)
+    x = (a - 131070.0) / 37837.227
+    x = x + ((b - 131070.0) / 37837.227) * 0.0031415926535897933
+    return level + x * float(sigma)
+
+
+def palindrome_counts(n, a, seed):
+    """Levels A | B | A with steps at a and n - a and palindromic noise (sample i == sample n-1-i): the two steps are
+    exactly tied candidates of a window that spans the event."""
+    i = np.arange(n, dtype=np.int64)
+    level = np.where((i >= a) & (i < n - a), LEVEL_COUNTS[1], LEVEL_COUNTS[0])
+    noise = noise_counts(seed, 0, (n + 1) // 2)
+    return (level + noise[np.minimum(i, n - 1 - i)]).astype(np.int32)
 
 
 def counts_to_pa(counts, dtype=np.float32):

@@ -50,3 +50,23 @@ def input_counts(case):
 
 def input_pa(case, dtype=np.float64):
     return synth.counts_to_pa(input_counts(case), dtype)
+
+
+_npz_off = None
+_manifest_off = None
+
+
+def offgrid_npz():
+    global _npz_off
+    if _npz_off is None:
+        _npz_off = np.load(os.path.join(HERE, "golden", "golden_offgrid.npz"))
+    return _npz_off
+
+
+def offgrid_cases(op):
+    """Cases of tests/golden/manifest_offgrid.json (make_golden_offgrid.py): op 'parse_offgrid' or 'score_samples'."""
+    global _manifest_off
+    if _manifest_off is None:
+        with open(os.path.join(HERE, "golden", "manifest_offgrid.json")) as f:
+            _manifest_off = json.load(f)
+    return [c for c in _manifest_off["cases"] if c["op"] == op]

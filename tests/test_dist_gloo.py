@@ -127,6 +127,52 @@ def test_sharded_trace_too_short_halo_fails_loudly():
         stitch_pieces(pieces, n, 10000, 100)
 
 
+def _long_dwell_trace(n, seed):
+    from pypore_amd import synth
+    return synth.counts_to_pa(synth.random_dwell_counts(n, seed, 100000, 1000000), np.float64)
+
+
+def _flat_stretch_trace():
+    """steps | 3e6 samples of one level (only the forced splits at max_width cut it) | steps"""
+    from pypore_amd import synth
+    a = synth.random_dwell_counts(700_000, 71)
+    flat = synth.LEVEL_COUNTS[2] + synth.noise_counts(72, 0, 3_000_000)
+    b = synth.random_dwell_counts(800_000, 73)
+    return synth.counts_to_pa(np.concatenate([a, flat, b]), np.float64)
+
+
+@pytest.mark.parametrize("case,world,halo", [("short_halo", 3, 21000), ("long_dwell", 8, 80000), ("long_dwell", 4, 80000),
+                                             ("flat", 8, 80000), ("flat", 2, 80000)])
+def test_sharded_trace_seam_repair_equals_whole_trace(case, world, halo):
+    """a seam that finds no common spine anchor inside the halo is extended and re-run (that seam only),
+    and the stitched result still equals the whole-trace result -- dwells of 1e5..1e6 samples, a flat stretch of 3e6."""
+    import oracle
+    from pypore_amd import synth
+    from pypore_amd.dist import shard_ranges, stitch_pieces
+    if case == "short_halo":
+        x = synth.counts_to_pa(synth.random_dwell_counts(600_000, 62, 30000, 90000), np.float64)
+    elif case == "long_dwell":
+        x = _long_dwell_trace(6_000_000, 64)
+    else:
+        x = _flat_stretch_trace()
+    n = x.size
+    ref = oracle.parse(x, prior_segments_per_second=10.)
+    pieces = []
+    for lo, hi in shard_ranges(n, world, halo):
+        b, f = oracle.parse_flags(x[lo:hi], prior_segments_per_second=10.)
+        pieces.append((lo, hi, b, f))
+    calls = []
+
+    def repair(r, lo, hi):
+        calls.append((r, lo, hi))
+        return oracle.parse_flags(x[lo:hi], prior_segments_per_second=10.)
+
+    got = stitch_pieces(pieces, n, 10000, 100, repair=repair, halo=halo)
+    np.testing.assert_array_equal(got, ref)
+    assert len(calls) >= 1                       # (these cases cannot be joined inside the halo)
+    assert all(hi - lo < n for _, lo, hi in calls[:1]) or world == 2     # a repair re-runs a stretch, not the trace
+
+
 def _worker_trace(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -143,7 +189,20 @@ def _worker_trace(rank, world, port, q):
             return oracle.parse_flags(x[lo:hi], prior_segments_per_second=10.)
 
         got = pdist.segment_trace_sharded(n, seg, 10000, 100, halo=80000)
-        q.put((rank, bool(np.array_equal(got, oracle.parse(x, prior_segments_per_second=10.)))))
+        ok = bool(np.array_equal(got, oracle.parse(x, prior_segments_per_second=10.)))
+        # dwells far longer than the halo: the seam is repaired by the upstream rank, one more gather of that stretch
+        n2 = 3_000_000
+        x2 = synth.counts_to_pa(synth.random_dwell_counts(n2, 64, 100000, 1000000), np.float64)
+        calls = []
+
+        def seg2(lo, hi):
+            calls.append((lo, hi))
+            return oracle.parse_flags(x2[lo:hi], prior_segments_per_second=10.)
+
+        got2 = pdist.segment_trace_sharded(n2, seg2, 10000, 100, halo=80000)
+        ok = ok and bool(np.array_equal(got2, oracle.parse(x2, prior_segments_per_second=10.)))
+        ok = ok and (len(calls) >= 2 if rank == 0 else len(calls) == 1)      # rank 0 is the upstream side of the one seam
+        q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from golden_util import case_ids, cases, input_counts, input_pa, npz
+from golden_util import case_ids, cases, input_counts, input_pa, npz, offgrid_cases, offgrid_npz
 from pypore_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -105,15 +105,70 @@ def test_per_candidate_gains(case, ctx):
     assert int(np.argmax(s)) == int(np.argmax(g))
 
 
-def test_score_samples_recursive_scan_order(ctx):
+@pytest.mark.parametrize("case", offgrid_cases("score_samples"), ids=lambda c: c["name"])
+def test_score_samples_full_list(case, ctx):
+    """score_samples(current) (cparsers.pyx:205-275): one dense gain array per window scan, in the recursion's order --
+    count, order, zero pattern and every value (1e-7 absolute: same fp64 operation order, the device log differs from
+    glibc's by <= 1 ulp) against the list recorded from the compiled reference."""
     from pypore_amd.cparsers import FastStatSplit
-    x = synth.config1()
-    f = FastStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM)
+    gen = case["gen"]
+    x = synth.config1() if gen["kind"] == "config1" else synth.counts_to_pa(
+        synth.random_dwell_counts(gen["n"], gen["seed"], gen["lo"], gen["hi"]), np.float64)
+    f = FastStatSplit(quantum=synth.QUANTUM, **case["params"])
     scans = f.score_samples(x)
-    # reference: one array per window scan: full window, then the recursion
-    assert len(scans) >= 5 and all(len(s) == len(x) for s in scans)
-    _, ref0 = oracle.score_window(x, 100, f.min_gain)
-    np.testing.assert_allclose(scans[0], ref0, rtol=0, atol=1e-7)
+    assert len(scans) == case["n_scans"]
+    z = offgrid_npz()
+    for k, (sc, (a, b)) in enumerate(zip(scans, case["spans"])):
+        sc = np.asarray(sc)
+        assert sc.shape == (len(x),)
+        ref = np.zeros(len(x))
+        ref[a:b] = z["%s/scan%03d" % (case["name"], k)]
+        np.testing.assert_array_equal(sc == 0, ref == 0, err_msg="scan %d" % k)
+        np.testing.assert_allclose(sc, ref, rtol=0, atol=1e-7, err_msg="scan %d" % k)
+
+
+def test_exact_tie_first_maximum_wins_and_is_counted(ctx):
+    """A palindromic noisy event A | B | A: the gains at its two steps are exactly equal in the reference's arithmetic; the
+    first one wins (cparsers.pyx:175-177).  The device decides it among fp64 contenders the same way, reports the window
+    in the near-tie counter (ps_get_timings counters[11]) and the Python layer warns."""
+    import warnings
+    from pypore_amd import engine
+    from pypore_amd.parsers import SpeedyStatSplit
+    (case,) = offgrid_cases("tie")
+    assert case["gain_at_a"] == case["gain_at_mirror"] and case["argmax"] == case["gen"]["a"]     # the reference's own numbers
+    x = synth.counts_to_pa(synth.palindrome_counts(**case["gen"]), np.float64)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        segs = SpeedyStatSplit(quantum=synth.QUANTUM, **case["params"]).parse(x)
+    got = np.array([s_.start for s_ in segs[1:]], dtype=np.int32)
+    np.testing.assert_array_equal(got, offgrid_npz()[case["name"] + "/bounds"])
+    np.testing.assert_array_equal(got, oracle.parse(x, **case["params"]))
+    assert engine.context().near_ties() >= 1
+    assert any(issubclass(i.category, engine.NearTieWarning) for i in w)
+    # an ordinary trace reports none
+    SpeedyStatSplit(quantum=synth.QUANTUM, prior_segments_per_second=10.).parse(synth.config1())
+    assert engine.context().near_ties() == 0
+
+
+@pytest.mark.parametrize("case", offgrid_cases("parse_offgrid"), ids=lambda c: c["name"])
+def test_offgrid_float64_requantise_route(case, ctx):
+    """Float64 input on no ADC grid (the reference takes any double buffer, cparsers.pyx:53,103-111): the default raises
+    ValueError (nothing is rounded silently); off_grid="requantise" rounds on the device to a 2**-k grid with counts below
+    2**22 and segments on the 64-bit digest -- every boundary the compiled reference finds on the UNROUNDED values, and the
+    segments' statistics (taken from the original values) to 1e-12."""
+    from pypore_amd.parsers import SpeedyStatSplit
+    x = synth.offgrid_trace(**case["gen"])
+    assert [repr(float(v)) for v in x[:4]] == case["x_head"] and repr(float(np.sum(x))) == case["x_sum"]
+    if case["n"] <= 100000:
+        with pytest.raises(ValueError):
+            SpeedyStatSplit(**case["params"]).parse(x)
+    segs = SpeedyStatSplit(off_grid="requantise", **case["params"]).parse(x)
+    got = np.array([s.start for s in segs[1:]], dtype=np.int32)
+    ref = offgrid_npz()[case["name"] + "/bounds"]
+    np.testing.assert_array_equal(got, ref)
+    assert segs[3 % len(segs)].current.base is x or np.shares_memory(segs[3 % len(segs)].current, x)      # views of the caller's array
+    np.testing.assert_allclose([s.mean for s in segs], offgrid_npz()[case["name"] + "/mean"], rtol=1e-12)
+    np.testing.assert_allclose([s.std for s in segs], offgrid_npz()[case["name"] + "/std"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("case", cases("best_single_split"), ids=case_ids("best_single_split"))
@@ -250,6 +305,44 @@ def test_spine_flags_and_sharded_trace_on_device(ctx):
                                          want_stats=False, want_spine=True)
         pieces.append((lo, hi, pb.cpu().numpy(), pf.cpu().numpy()))
     np.testing.assert_array_equal(stitch_pieces(pieces, n, 10000, 100), npz()["G9_rd_2M/bounds"])
+
+
+@pytest.mark.parametrize("case", ["long_dwell", "flat"])
+def test_sharded_trace_seam_repair_on_device(ctx, case):
+    """pieces whose seams find no common spine anchor inside the halo (dwells of 1e5..1e6 samples; a flat stretch
+    of 3e6 samples) are joined by re-running the chain from the last trusted upstream anchor over a longer stretch.
+    8 pieces on one GPU == the whole trace on the GPU == the oracle."""
+    import torch
+    from pypore_amd import _lib
+    from pypore_amd.dist import shard_ranges, stitch_pieces
+    if case == "long_dwell":
+        counts = synth.random_dwell_counts(6_000_000, 64, 100000, 1000000)
+    else:
+        counts = np.concatenate([synth.random_dwell_counts(700_000, 71), synth.LEVEL_COUNTS[2] + synth.noise_counts(72, 0, 3_000_000),
+                                 synth.random_dwell_counts(800_000, 73)])
+    x = synth.counts_to_pa(counts, np.float32)
+    n = len(x)
+    params = _lib.split_params(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    t = torch.from_numpy(x).cuda()
+
+    def seg(lo, hi):
+        pb, _, _, pf = ctx.segment_batch(t[lo:hi].contiguous(), np.array([0, hi - lo]), params, synth.QUANTUM,
+                                         want_stats=False, want_spine=True)
+        return pb.cpu().numpy(), pf.cpu().numpy()
+
+    whole, _ = seg(0, n)
+    ref = oracle.parse(x.astype(np.float64), prior_segments_per_second=10.)
+    np.testing.assert_array_equal(whole, ref)
+    calls = []
+
+    def repair(r, lo, hi):
+        calls.append((r, lo, hi))
+        return seg(lo, hi)
+
+    pieces = [(lo, hi) + seg(lo, hi) for lo, hi in shard_ranges(n, 8, 80000)]
+    got = stitch_pieces(pieces, n, 10000, 100, repair=repair, halo=80000)
+    np.testing.assert_array_equal(got, ref)
+    assert calls
 
 
 def test_counts_beyond_int16_take_the_exact_path(ctx):

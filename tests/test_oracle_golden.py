@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from golden_util import case_ids, cases, input_pa, npz
+from golden_util import offgrid_cases, offgrid_npz, case_ids, cases, input_pa, npz
 
 
 @pytest.mark.parametrize("case", cases("parse"), ids=case_ids("parse"))
@@ -66,6 +66,20 @@ def test_min_gain_known_values():
         oracle.min_gain(min_width=100, window_width=199)
     with pytest.raises(AssertionError):
         oracle.min_gain(cutoff_freq=60000.)
+
+
+@pytest.mark.parametrize("case", [c for c in offgrid_cases("parse_offgrid") if c["n"] <= 1000000], ids=lambda c: c["name"])
+def test_oracle_on_offgrid_float64(case):
+    """The restatement consumes any float64 buffer like the reference (sequential cumsum, cparsers.pyx:110-111):
+    boundaries, means and stds recorded from the compiled reference on un-quantised noise step traces."""
+    from pypore_amd import synth
+    x = synth.offgrid_trace(**case["gen"])
+    assert [repr(float(v)) for v in x[:4]] == case["x_head"] and repr(float(np.sum(x))) == case["x_sum"]   # same input
+    b = oracle.parse(x, **case["params"])
+    np.testing.assert_array_equal(b, offgrid_npz()[case["name"] + "/bounds"])
+    st = oracle.segment_stats(x, b)
+    np.testing.assert_allclose(st[:, 0], offgrid_npz()[case["name"] + "/mean"], rtol=1e-12)
+    np.testing.assert_allclose(st[:, 1], offgrid_npz()[case["name"] + "/std"], rtol=1e-9)
 
 
 @pytest.mark.slow
