@@ -66,8 +66,11 @@ class Event(Segment):
     # ---- Event.filter (DataTypes.py:258-274) ----------------------------------------------------------------
     def filter(self, order=1, cutoff=2000., quantum=None):
         """Bessel low-pass, cutoff relative to the Nyquist frequency of the file's sampling rate, run forward and
-        backward (scipy.signal.filtfilt semantics) on the device; `current` becomes the float64 result.  Orders
-        other than the reference's default 1 raise ValueError.  The result no longer lies on the ADC grid: see parse."""
+        backward (scipy.signal.filtfilt semantics) on the device; `current` becomes the float64 result.  Orders 1..4
+        run on the device (1, the reference's default, by scans; 2..4 by segments with halos); higher orders raise
+        ValueError.  The result no longer lies on the ADC grid: see parse.  The INPUT must lie on an ADC grid (what a
+        file reader returns): filtering an already filtered current again raises ValueError where the reference would
+        filter it again."""
         if type(self) is not Event:
             raise TypeError("Cannot filter a metaevent. Must have the current.")
         from . import engine

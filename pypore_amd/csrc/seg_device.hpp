@@ -131,6 +131,13 @@ typedef SharedT<1024> Shared;  // (size reference for the host-side LDS budget: 
 #define PS_SCAN_VGPRS 64
 #endif
 #define PS_SCAN_REGS __attribute__((amdgpu_num_vgpr(PS_SCAN_VGPRS)))
+// The seam bridges are a few hundred windows in chains of two or three: latency is all that matters to them, occupancy
+// nothing -- they are compiled for two waves per SIMD and keep everything in registers (at 128 registers: 256 bytes of
+// scratch per lane, 0.056 -> 0.071 ms).
+#ifndef PS_BRIDGE_MINW
+#define PS_BRIDGE_MINW 2
+#endif
+#define PS_BRIDGE_REGS __attribute__((amdgpu_num_vgpr(256 / PS_BRIDGE_MINW - 12)))
 struct Work {
     long long windows, cands, exact;
     long long near;          // contender decisions whose margin lies inside the device-vs-glibc logarithm noise (seg_bs.hpp: bs_decide)
@@ -1238,7 +1245,7 @@ constexpr int BR_PATIENCE = 3;     // windows without a hit a single-wave bridge
                                    // the seam to the look-ahead kernel (bmeta = (count, next window, -, BR_DEFER))
 
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BRIDGE_MINW : 4)) PS_BRIDGE_REGS void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                        const int4 *meta, int2 *bridges, int4 *bmeta,
                                                        unsigned *status, unsigned long long *work, int n_jobs, int max_single)
 {
@@ -1321,7 +1328,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
 // the longest seam sets the kernel's duration.  Semantics: find_split (cparsers.pyx:186-201) window by window.
 constexpr int BR_LA = 4;
 template <int DT>
-__global__ __launch_bounds__(64 * BR_LA, (PS_BS_MINW > 3 ? 3 : PS_BS_MINW)) PS_SCAN_REGS void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
+__global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                                   const int4 *meta, int2 *bridges, int4 *bmeta,
                                                                   unsigned *status, unsigned long long *work, int n_jobs)
 {

@@ -191,7 +191,7 @@ class Context(object):
         return i.value, scores[:samples.numel()]
 
     def filter_bessel(self, samples, quantum, cutoff=2000., sampling_freq=1.e5, order=1, offset_counts=0):
-        """ps_filter_bessel: Event.filter (DataTypes.py:258-274) -- order-1 Bessel low-pass, forward and backward
+        """ps_filter_bessel: Event.filter (DataTypes.py:258-274) -- Bessel low-pass of order 1..4, forward and backward
         (scipy filtfilt semantics); returns the filtered current in pA as a float64 CUDA tensor."""
         assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
         fmt = self._fmt(samples, quantum, offset_counts)
