@@ -473,10 +473,15 @@ __device__ __forceinline__ long long bs_a1(const int4 &e, long long o1) { return
 __device__ __forceinline__ long long bs_a2(const int4 &e, long long o2) { return i64_of(e.z, e.w) + o2; }
 // count of one sample WITHOUT the grid check: every sample of an event was validated by K0 before a scan reads it
 template <int DT>
+__device__ __forceinline__ int bs_count_of(const DevCfg &c, typename Raw<DT>::type raw)
+{
+    if (sdt(DT) == PS_DTYPE_F32) return __float2int_rn(static_cast<float>(raw) * c.inv_q);
+    return static_cast<int>(raw) + c.off_counts;
+}
+template <int DT>
 __device__ __forceinline__ int bs_count(const DevCfg &c, int64_t gi)
 {
-    if (sdt(DT) == PS_DTYPE_F32) return __float2int_rn(static_cast<const float *>(c.samples)[gi] * c.inv_q);
-    return static_cast<int>(static_cast<const int16_t *>(c.samples)[gi]) + c.off_counts;
+    return bs_count_of<DT>(c, static_cast<const typename Raw<DT>::type *>(c.samples)[gi]);
 }
 constexpr int BS_NC = 64;                                 // contenders kept per window
 #ifndef PS_BS_D
@@ -650,17 +655,16 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     auto row_load = [&](int r) { return bsw[min(max(r, 0) * BS_STRIDE + lane, nblk)]; };
     // everything the window needs before its first boundary, issued together
     const int nh = g0 - ps, nt = pe - g1;              // ragged head [ps, g0) and tail [g1, pe): <= 7 raw samples each
-    int yht = 0;
-#ifndef PS_X_NOHT                                        // (timing experiments only: wrong results)
-    if (lane < nh) yht = bs_count<DT>(c, base + ps + lane) - m;
-    if (lane >= 32 && lane - 32 < nt) yht = bs_count<DT>(c, base + g1 + (lane - 32)) - m;
-#endif
-    int4 ct = make_int4(0, 0, 0, 0);
-    int yab = 0;
-    if (lane < nch) {
-        if constexpr (WIDE) { ct = c.chunk_tot[2 * (c0 + lane)]; yab = c.chunk_tot[2 * (c0 + lane) + 1].x; }
-        else { ct = c.chunk_tot[c0 + lane]; yab = ct.y; }
-    }
+    // (loaded by every lane from a clamped index and converted after all of the setup's loads are out: under a lane
+    //  condition the compiler finishes the conversion inside the branch and waits for the sample right there -- two
+    //  exposed round trips to HBM in front of the other loads, which is what rounds 1 and 2 did)
+    const int ht_idx = lane < 32 ? ps + min(lane, max(nh - 1, 0)) : min(g1 + min(lane - 32, max(nt - 1, 0)), pe - 1);
+    const typename Raw<DT>::type ht_raw = static_cast<const typename Raw<DT>::type *>(c.samples)[base + ht_idx];
+    // (chunk totals likewise: every lane loads a clamped entry, lanes beyond the window's chunks are masked afterwards)
+    const long long cidx = c0 + min(lane, nch - 1);
+    int4 ct, cm = make_int4(0, 0, 0, 0);
+    if constexpr (WIDE) { ct = c.chunk_tot[2 * cidx]; cm = c.chunk_tot[2 * cidx + 1]; }
+    else ct = c.chunk_tot[cidx];
     const ent_t e0 = bsw[0], eN = bsw[nblk];
     // one sampled boundary per lane, spread over the window (also in subtree windows, which rarely hold a split: without
     // the raised pruning level the few that do queue hundreds of blocks -- measured, subtree kernel 0.175 -> 0.21 ms)
@@ -669,7 +673,11 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     ent_t ring[BS_D];                                  // rows in flight
 #pragma unroll
     for (int i = 0; i < BS_D; ++i) ring[i] = row_load(i);
+    if (lane >= nch) ct = make_int4(0, 0, 0, 0);
+    const int yab = lane < nch ? (WIDE ? cm.x : ct.y) : 0;
     // head / tail sums (lanes 0..7 head, 32..39 tail)
+    const bool ht_in = lane < nh || (lane >= 32 && lane - 32 < nt);
+    const int yht = ht_in ? bs_count_of<DT>(c, ht_raw) - m : 0;
     s1_t H1, TL1;
     s2_t H2, TL2;
     if constexpr (WIDE) {

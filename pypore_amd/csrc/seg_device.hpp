@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(256) void upload_kernel(const int4 *src, int4 *dst,
 // After the chain stops, the workgroup reserves `count` slots in the dense list with one
 // atomic and copies its anchors there so the host fetches a compact array.
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void spine_kernel(DevCfg c, const SpineJob *jobs, int2 *scratch,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void spine_kernel(DevCfg c, const SpineJob *__restrict__ jobs, int2 *scratch,
                                                    int2 *dense, int4 *meta, unsigned long long *dense_count,
                                                    unsigned *status, unsigned long long *work, int n_jobs)
 {
@@ -1505,7 +1505,7 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
 }
 
 template <int NT, int DT>
-__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void tree_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+__global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void tree_kernel(DevCfg c, const TreeJob *__restrict__ jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr)
 {
@@ -1518,6 +1518,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
     // one or two scans of a typical job: 0.28 ms against 0.17 ms for the 9 231 jobs of the bench trace).
     for (long long ji = blockIdx.x; ji < n_jobs; ji += gridDim.x) {
         const TreeJob job = jobs[ji];
+        // (all fields in one round trip: otherwise the compiler fetches out_cap, tests it, and only then the rest)
+        asm volatile("" : : "s"(job.base), "s"(job.start), "s"(job.end), "s"(job.j0), "s"(job.out_off), "s"(job.m), "s"(job.boff));
         if (job.out_cap == 0) continue;                // spine anchor without a left subtree (device stitch)
         tree_job<NT, DT>(c, ys, job, ji, scratch, spill, counts, sh, bad, wk);
     }
@@ -1536,7 +1538,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
                               // (4 streams: 0.354 -> 0.347 ms per step; single-wave workgroups 0.345)
 constexpr int TREE_W = PS_TREE_W;
 template <int DT>
-__global__ __launch_bounds__(64 * TREE_W, PS_BS_MINW) PS_SCAN_REGS void tree_mw_kernel(DevCfg c, const TreeJob *jobs, int32_t *scratch,
+__global__ __launch_bounds__(64 * TREE_W, PS_BS_MINW) PS_SCAN_REGS void tree_mw_kernel(DevCfg c, const TreeJob *__restrict__ jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr,
                                                   unsigned long long *tail_ctr, int tail_pct)
