@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 PARAMS = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10.,
               sampling_freq=1e5)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # written by tools/profile_round.sh from the PMC passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")     # written by tools/profile_round.sh from the PMC passes
 METRIC = "Msamples/sec segmented (SpeedyStatSplit, 10^8-sample trace); %HBM roofline"
 
 
@@ -451,9 +451,12 @@ def main():
                          if wl != "files" else "whole step incl. the host->HBM copies (PCIe-bound)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
-                         "traffic": traffic["total"] if traffic else None,
-                         "traffic_source": traffic["source"] if traffic else None,
-                         "traffic_over_algorithmic": round(traffic["total"] / per_gpu_bytes, 3) if traffic else None,
+                         # HBM bytes per launch (PMC): of one call at a time, and -- the headline configuration -- per call
+                         # with four calls in flight on four distinct traces
+                         "traffic": (traffic.get("total_4_streams") if T == 4 and traffic.get("total_4_streams") else traffic["total"]) if traffic else None,
+                         "traffic_one_call_at_a_time": traffic["total"] if traffic else None,
+                         "traffic_source": ((traffic.get("source_4_streams") + "; " if T == 4 and traffic.get("total_4_streams") else "") + traffic["source"]) if traffic else None,
+                         "traffic_over_algorithmic": round((traffic.get("total_4_streams") if T == 4 and traffic.get("total_4_streams") else traffic["total"]) / per_gpu_bytes, 3) if traffic else None,
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes),
                          "longest_kernel": dom.replace("_ms", "_kernel"),
                          "streaming_kernel": {"name": "blocksum_kernel", "ms": round(kern["blocksum_ms"], 4),

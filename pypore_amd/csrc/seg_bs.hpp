@@ -160,7 +160,10 @@ __device__ __forceinline__ DevCfg bs_cold_cfg(const BsCold &k)
 #endif
 constexpr int K0_BPT = 4;                              // consecutive blocks per thread after the transposition
 constexpr int K0_WB = 64 * K0_BPT;                     // blocks per wave
-constexpr int K0_WAVES = 4;                            // waves per workgroup (independent of each other)
+#ifndef PS_K0_WAVES
+#define PS_K0_WAVES 4
+#endif
+constexpr int K0_WAVES = PS_K0_WAVES;                  // waves per workgroup (independent of each other)
 __host__ __device__ inline long long k0_padded_blocks(long long nb_total) { return (nb_total + 1 + K0_WB - 1) / K0_WB * K0_WB; }
 
 template <int DT> struct K0Rec { int s1; unsigned s2; unsigned long long s2w; int ymin, ymax; };

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 counter passes for bench.py (run on the GPU box through gpurun); summaries land in gpurun_out/pmc_*.txt
-# usage: bash tools/pmc_run.sh [tag]   (extra env such as PORESEG_LIB is inherited)
+# usage: bash tools/pmc_run.sh [tag] [streams]   (extra env such as PORESEG_LIB is inherited)
 TAG=${1:-pmc}
+STREAMS=${2:-1}
 ROOT=$PWD
 export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out
@@ -9,7 +10,7 @@ cd /tmp
 run() {  # name counters...
   name=$1; shift
   rm -rf /tmp/prof_$name
-  rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -o out --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --streams 1 > /tmp/prof_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -o out --output-format csv -- python3 $ROOT/bench.py --steps $((3 * STREAMS)) --warmup $STREAMS --no-cpu --no-h2d --no-detail --streams $STREAMS > /tmp/prof_$name.log 2>&1
   python3 - "$name" <<'PY' >> $ROOT/gpurun_out/${TAG}_summary.txt
 import sys, csv, glob, collections
 name = sys.argv[1]

@@ -6,8 +6,10 @@
 #                               different calls overlap, so single launches run longer than alone)
 #   <tag>_s1_kernel_stats.csv   the same with --streams 1 (one call at a time: the per-kernel durations of roofline.kernel_ms)
 #   <tag>_bench.json            the default bench line (incl. cpu_baseline, h2d_inclusive)
-#   <tag>_pmc_summary.txt       PMC passes (tools/pmc_run.sh, --streams 1), <tag>_pmc_traffic.json: HBM bytes per launch
-TAG=${1:-r02}
+#   <tag>_pmc_summary.txt       PMC passes (tools/pmc_run.sh, --streams 1: instruction counts, traffic of one call at a time)
+#   <tag>_pmc4_summary.txt      the same passes with four calls in flight on four DISTINCT traces (--streams 4): what the
+#                               headline configuration fetches; <tag>_pmc_traffic.json: HBM bytes per launch from both
+TAG=${1:-r03}
 ROOT=$PWD
 export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out
@@ -22,10 +24,24 @@ for s in 4 1; do
 done
 cd $ROOT
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-bash tools/pmc_run.sh ${TAG}_pmc > /dev/null 2>&1
+bash tools/pmc_run.sh ${TAG}_pmc 1 > /dev/null 2>&1
+bash tools/pmc_run.sh ${TAG}_pmc4 4 > /dev/null 2>&1
 python3 - $TAG <<'PY'
 import sys, re, json, ast
 tag = sys.argv[1]
+def read(name):
+    per = {}
+    for line in open('gpurun_out/%s_summary.txt' % name):
+        m = re.match(r'(fetch|write|sq) (?:void )?ps::(\w+)(?:<[^>]*>)? (\{.*\})', line.strip())
+        if not m: continue
+        d = ast.literal_eval(m.group(3))
+        k = m.group(2)
+        per.setdefault(k, {})
+        if m.group(1) == 'fetch': per[k]['fetch_kib'] = d['FETCH_SIZE']
+        elif m.group(1) == 'write': per[k]['write_kib'] = d['WRITE_SIZE']
+        elif 'SQ_INSTS_VALU' in d: per[k]['valu'] = d['SQ_INSTS_VALU']
+    return per
+per4 = read(tag + '_pmc4')
 per = {}
 for line in open('gpurun_out/%s_pmc_summary.txt' % tag):
     m = re.match(r'(fetch|write|sq) (?:void )?ps::(\w+)(?:<[^>]*>)? (\{.*\})', line.strip())
@@ -36,12 +52,15 @@ for line in open('gpurun_out/%s_pmc_summary.txt' % tag):
     if m.group(1) == 'fetch': per[k]['fetch_kib'] = d['FETCH_SIZE']
     elif m.group(1) == 'write': per[k]['write_kib'] = d['WRITE_SIZE']
     elif 'SQ_INSTS_VALU' in d: per[k]['valu'] = d['SQ_INSTS_VALU']
-names = ['blocksum_kernel', 'spine_kernel', 'bridge_kernel', 'bridge_la_kernel', 'tree_mw_kernel', 'assemble_tiles_kernel',
+names = ['blocksum_kernel', 'spine_kernel', 'bridge_kernel', 'bridge_la_kernel', 'tree_kernel', 'tree_mw_kernel', 'assemble_tiles_kernel',
          'assemble_items_kernel', 'item_scan_kernel', 'gather_kernel', 'upload_kernel']
 pk = {k: (2 * per[k].get('fetch_kib', 0) + per[k].get('write_kib', 0)) * 1024 for k in names if k in per}
+pk4 = {k: (2 * per4[k].get('fetch_kib', 0) + per4[k].get('write_kib', 0)) * 1024 for k in names if k in per4}
 json.dump({"source": "profiles/%s_pmc_summary.txt: FETCH_SIZE (KiB) x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE (KiB) per "
                      "launch, rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --streams 1`" % tag,
            "total": sum(pk.values()), "per_kernel": pk,
+           "total_4_streams": sum(pk4.values()), "per_kernel_4_streams": pk4,
+           "source_4_streams": "profiles/%s_pmc4_summary.txt: the same passes with --streams 4 (four calls in flight, one trace each)" % tag,
            "valu_source": "profiles/%s_pmc_summary.txt: SQ_INSTS_VALU (wave-level vector instructions) per launch, same passes" % tag,
            "valu_per_kernel": {k: per[k]['valu'] for k in names if k in per and 'valu' in per[k]}},
           open('gpurun_out/%s_pmc_traffic.json' % tag, 'w'), indent=1)
