@@ -493,6 +493,10 @@ constexpr int BS_NC = 64;                                 // contenders kept per
 constexpr int BS_D = PS_BS_D;                             // rows in flight: a ring of digest entries in registers (8 bytes each), row r + BS_D
                                                           // is requested when row r has been evaluated -- the prefetch distance of a lone chain
 constexpr int BS_QN = 192;                                // queued blocks; a drain is forced when the next row may not fit
+#ifndef PS_TREE_SAMPLE
+#define PS_TREE_SAMPLE 0                                  // 1: subtree windows run the sampling pass too (measured: see scan_window_bs)
+#endif
+constexpr int BS_EARLY = 64;                              // ... and started early beyond this many (<= BS_QN - 64)
 constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
 constexpr int BS_LDS_BYTES = static_cast<int>(sizeof(BsQ)) * BS_QN + static_cast<int>(sizeof(BsC)) * BS_NC + 64 * 32;
 static_assert(sizeof(QEnt) * SharedT<64>::QN >= BS_LDS_BYTES, "SharedT<64>::q too small");   // (64 * 32: staged blocks of the wide digest, 8 int32 each)
@@ -669,10 +673,15 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     if constexpr (WIDE) { ct = c.chunk_tot[2 * cidx]; cm = c.chunk_tot[2 * cidx + 1]; }
     else ct = c.chunk_tot[cidx];
     const ent_t e0 = bsw[0], eN = bsw[nblk];
-    // one sampled boundary per lane, spread over the window (also in subtree windows, which rarely hold a split: without
-    // the raised pruning level the few that do queue hundreds of blocks -- measured, subtree kernel 0.175 -> 0.21 ms)
-    const int tS = min(nblk, lane * rows);
-    const ent_t smp = bsw[tS];
+    // One sampled boundary per lane, spread over the window -- in the instances that skip rows (spine, bridges).  Subtree
+    // windows rarely hold a split (95 % of the jobs find nothing): they start at the threshold level without the sampling
+    // pass (no gather of 64 scattered entries, ~100 instructions less) and RAISE the level from the gains seen so far
+    // whenever the queue has to be drained early (below) -- without that the few windows that do hold a split queue
+    // hundreds of blocks (measured: subtree kernel 0.175 -> 0.21 ms).
+    constexpr bool SAMPLE = ROWSKIP || PS_TREE_SAMPLE;
+    const int tS = SAMPLE ? min(nblk, lane * rows) : 0;
+    ent_t smp = e0;
+    if constexpr (SAMPLE) smp = bsw[tS];
     ent_t ring[BS_D];                                  // rows in flight
 #pragma unroll
     for (int i = 0; i < BS_D; ++i) ring[i] = row_load(i);
@@ -769,7 +778,9 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     float Tprune, Tc = INFINITY;
     float cbound = INFINITY;                           // bound of the stretch between this lane's sample and the next lane's
     bool hitlike = false;                              // (uniform) a sampled candidate lies above the threshold band
-    {
+    if constexpr (!SAMPLE) {
+        Tprune = (thr_log2 - dthr) - 2.0f * dlt;
+    } else {
         // pruning level from the sampled boundary candidates (one per lane, spread evenly over the window: 64 scattered
         // cache lines -- sampling the chunk starts instead, whose sums need no load, was measured: coarser samples skip
         // fewer rows and queue more blocks, spine 0.193 -> 0.225 ms)
@@ -924,6 +935,20 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             qcount = 0;
             PS_STAMP_AT(wk, 2);                        // drain
         };
+        // early drain (the queue is filling: this window probably holds a split): afterwards the pruning level follows the
+        // best gain seen so far -- a block whose bound lies more than 2 delta below a gain that WAS reached cannot hold the
+        // winner nor a contender (the same argument as for the sampled level, with real gains instead of sampled ones)
+        auto drain_early = [&]() {
+            drain();
+            if (phase == 0) {
+                float bx = top.b;
+#define PS_STEP(CTRL, RM) { bx = fmaxf(bx, dpp_movf<CTRL, RM>(-INFINITY, bx)); }
+                PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+                bx = __int_as_float(lane_get(__float_as_int(bx), 63));
+                Tprune = fmaxf(Tprune, fmaxf(thr_log2 - dthr, bx - 2.0f * dlt) - 2.0f * dlt);
+            }
+        };
         // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t); the row's boundaries lie in at most two chunks
         auto do_row = [&](int r, const ent_t &cur) {
             const bool first_row = r == 0;
@@ -999,7 +1024,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #pragma unroll
                 for (int i = 0; i < BS_D; ++i) {
                     if (r0 + i < rows) {
-                        if (qcount > BS_QN - 64) drain();
+                        if (qcount > BS_EARLY) drain_early();
                         do_row(r0 + i, ring[i]);
                     }
                     // (unconditional, clamped past the end: a load under a condition makes the compiler's count of the loads
@@ -1017,7 +1042,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #pragma unroll
                 for (int i = 0; i < BS_D; ++i) {
                     if (rr[i] >= 0) {
-                        if (qcount > BS_QN - 64) drain();
+                        if (qcount > BS_EARLY) drain_early();
                         do_row(rr[i], ring[i]);
                         any = true;
                     }
