@@ -149,3 +149,26 @@ def test_file_with_real_header_parses_end_to_end(tmp_path):
     from pypore_amd import pipeline
     dt, st_, ln_, bl = pipeline.parse_abf(path)
     assert list(zip(st_.tolist(), ln_.tolist())) == list(zip(es.tolist(), el.tolist()))
+
+
+def test_gridarray_is_read_only():
+    """an in-place edit of a reader's current (a baseline subtraction, a blanked artefact, a sort) returns the
+    same object without passing __array_finalize__, so the int16 counts would go stale and the device would segment the
+    unmodified trace.  The array is read-only: such an edit raises, a copy is a plain writable array without counts, and
+    affine_grid re-centres counts that touch both int16 rails."""
+    from pypore_amd.grid import GridArray, affine_grid, grid_of
+    counts = np.array([-32768, 5, 7, 32767, 100, -3], dtype=np.int16)
+    a = GridArray.from_counts(counts, 0.030517578125, 1.75)
+    assert grid_of(a) is not None and grid_of(a[1:4])[0].tolist() == [5, 7, 32767]
+    with pytest.raises(ValueError):
+        a -= 3
+    with pytest.raises(ValueError):
+        a[2:4] = 100
+    with pytest.raises(ValueError):
+        a.sort()
+    b = a.copy()
+    assert type(b) is np.ndarray and b.flags.writeable and grid_of(b) is None
+    b -= 3.0                                      # the caller's baseline subtraction: a bare array, grid found afresh
+    q, o, k = affine_grid(b)
+    assert abs(q - 0.030517578125) < 1e-12 and k.min() >= -32768 and k.max() <= 32767      # both rails: still int16
+    np.testing.assert_allclose(k * q + o, b, rtol=0, atol=1e-9)
