@@ -406,7 +406,7 @@ def main():
                 mine_g = b.cpu().numpy().astype(np.int64) + lo
                 lim = ranges[0][1] - 2 * W - 2 * mw
                 check["rank0_piece_prefix_equal"] = bool(np.array_equal(mine_g[mine_g <= lim], got[got <= lim]))
-            assert all(check.values()), check
+            assert all(v for v in check.values() if isinstance(v, bool)), check
     else:
         n_bounds = [int(sum(r[2].numel() for r in result))]
 

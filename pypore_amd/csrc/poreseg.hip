@@ -385,8 +385,10 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (n_tj) {
         const unsigned g = static_cast<unsigned>(std::min<size_t>(n_tj, 0x7fffffff));
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
-        int lrc = cfg.bsum != nullptr && cfg.bs_wide
+        int lrc = cfg.bsum != nullptr && cfg.bs_wide && ctx->tree_mw
                       ? (f32 ? launch_tree_mw<PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree_mw<PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr))
+                  : cfg.bsum != nullptr && cfg.bs_wide
+                      ? (f32 ? launch_tree<64, PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<64, PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr))
                   : cfg.bsum != nullptr && ctx->tree_mw
                       ? (f32 ? launch_tree_mw<PS_DTYPE_F32>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree_mw<PS_DTYPE_I16>(ctx, cfg, g, sm, n_tj, d_hdr))
                   : cfg.bsum != nullptr

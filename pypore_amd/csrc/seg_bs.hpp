@@ -678,7 +678,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     // pass (no gather of 64 scattered entries, ~100 instructions less) and RAISE the level from the gains seen so far
     // whenever the queue has to be drained early (below) -- without that the few windows that do hold a split queue
     // hundreds of blocks (measured: subtree kernel 0.175 -> 0.21 ms).
-    constexpr bool SAMPLE = ROWSKIP || PS_TREE_SAMPLE;
+    constexpr bool SAMPLE = ROWSKIP || WIDE || PS_TREE_SAMPLE;      // (wide digest: filtered events, whose subtree windows mostly DO hold splits)
     const int tS = SAMPLE ? min(nblk, lane * rows) : 0;
     ent_t smp = e0;
     if constexpr (SAMPLE) smp = bsw[tS];
