@@ -1608,38 +1608,47 @@ struct Item { int32_t job; int32_t anchor; };
 
 // single-workgroup exclusive scan of (tree count + 1) per item -> pos[n_items + 1]; then the per-event
 // offsets bounds_off[e] = pos[first_item[e]].
-// Sixteen items per thread and trip: their loads are issued together (a trip is one memory round trip).
+// 16 384 items per trip (one trip for the bench trace).  Loads and stores are coalesced (item b0 + 1024 k + t by thread
+// t) and pass through LDS, where every thread scans 16 CONSECUTIVE values: round 2 gave every thread 16 consecutive
+// items in global memory, i.e. 64 cache lines per load instruction and 16 K line requests per trip through one CU's
+// L1 (17.8 us for 9 735 items, 0.19 ms for the 98 007 of the 1e9-sample trace).
 __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, const int32_t *counts,
                                                          int64_t n_items_host, int64_t *pos, const AsmHeader *hdr,
                                                          const int64_t *first_item, int32_t n_ev, int64_t *bounds_off)
 {
-    constexpr int PER = 16;                            // 16 384 items per trip: one trip for the bench trace
+    constexpr int PER = 16;
+    constexpr int TRIP = 1024 * PER;
     if (hdr && hdr->fail) {                            // failed / refused stitch: first_item is not valid either
         for (int e = threadIdx.x; e <= n_ev; e += 1024) bounds_off[e] = 0;
         if (threadIdx.x == 0) pos[0] = 0;
         return;
     }
     const int64_t n_items = dev_count(hdr, n_items_host);
+    __shared__ int vals[TRIP];                         // the trip's values, then their exclusive prefix (relative to the trip)
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t b0 = 0; b0 < n_items; b0 += 1024 * PER) {
-        const int64_t i0 = b0 + static_cast<int64_t>(threadIdx.x) * PER;
-        int jb[PER], cn[PER];
+    for (int64_t b0 = 0; b0 < n_items; b0 += TRIP) {
+        // 1. coalesced: value of item b0 + 1024 k + t
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const bool in = i0 + k < n_items;
-            jb[k] = in ? items[i0 + k].job : -2;
-            cn[k] = in ? counts[i0 + k] : 0;            // (the device stitch numbers jobs like items: usually the right one)
+            const int64_t i = b0 + 1024 * k + threadIdx.x;
+            int v = 0;
+            if (i < n_items) {
+                const int jb = items[i].job;
+                // (the device stitch numbers jobs like items: usually the coalesced load is the right one)
+                v = 1 + (jb < 0 ? 0 : jb == i ? counts[i] : counts[jb]);
+            }
+            vals[1024 * k + threadIdx.x] = v;
         }
-        long long v[PER], tot = 0;
+        __syncthreads();
+        // 2. every thread: 16 consecutive values
+        int v[PER];
+        long long tot = 0;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            v[k] = jb[k] == -2 ? 0 : 1 + (jb[k] < 0 ? 0 : jb[k] == i0 + k ? cn[k] : counts[jb[k]]);
-            tot += v[k];
-        }
+        for (int k = 0; k < PER; ++k) { v[k] = vals[PER * threadIdx.x + k]; tot += v[k]; }
         long long inc = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1648,15 +1657,22 @@ __global__ __launch_bounds__(1024) void item_scan_kernel(const Item *items, cons
         }
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        long long run = carry_s + inc - tot;
+        long long run = inc - tot;                     // relative to the trip
         for (int w = 0; w < wave; ++w) run += wsum[w];
+        const long long base = carry_s;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            if (i0 + k < n_items) pos[i0 + k] = run;
+            vals[PER * threadIdx.x + k] = static_cast<int>(run);      // (a trip holds < 2^31 boundaries)
             run += v[k];
         }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run;
+        // 3. coalesced stores
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t i = b0 + 1024 * k + threadIdx.x;
+            if (i < n_items) pos[i] = base + vals[1024 * k + threadIdx.x];
+        }
+        if (threadIdx.x == 1023) carry_s = base + run;
         __syncthreads();
     }
     if (threadIdx.x == 0) pos[n_items] = carry_s;
