@@ -98,7 +98,13 @@ struct ps_ctx {
     int wide_bs = 1;          // 1: counts too wide for the 32-bit digest are retried on the 64-bit digest, 0: straight to the LDS-window scan
     int bridge_single = 1 << 30;   // anchors a single-wave bridge adds before it hands the seam to the look-ahead kernel (measured: handing over early is slower)
     int tree_tail_pct = 0;    // tree_mw_kernel: share of the job list drawn dynamically (counter in HBM) at the end
-    int slots_pct = 100;      // share of the resident wave slots the scan kernels are launched on (the rest is left to other calls' kernels)
+    // Share of the resident wave slots the single-wave scan kernels are launched on.  50 = two waves per SIMD: a SIMD's
+    // throughput does not grow beyond two scan waves (each is active about half of its time and the SIMD issues one
+    // instruction at a time), a window's latency doubles from two to four -- and the registers of the other two slots
+    // are where another call's scan kernels run at the same time.  Measured (bench trace, 100 / 75 / 62 / 50 / 44 / 37 %):
+    // four calls in flight 0.274 / 0.253 / 0.250 / 0.2445 / 0.257 / 0.270 ms per step, one call 0.522 / 0.499 / 0.511 /
+    // 0.505 / 0.572 / 0.563 ms (below 50 % the spine kernel's 2 048 tiles are no longer all resident).
+    int slots_pct = 50;
     // host-side caches: occupancy per kernel, dynamic-LDS attribute last set, the tile tables of the last call
     struct OccKey { const void *fn; int nt; size_t lds; unsigned slots; };
     std::vector<OccKey> occ_cache;
@@ -468,6 +474,8 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         fprintf(stderr, "[poreseg stamps] lane-0 cycles summed over waves (spine+bridge+tree):");
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hs.stamp[i] / (tot ? tot : 1));
         fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
+        fprintf(stderr, "[poreseg stamps] rows swept %llu, non-empty drains %llu, blocks drained %llu, hit-like windows %llu\n",
+                hs.stamp[8], hs.stamp[9], hs.stamp[10], hs.stamp[11]);
         for (int k = 0; k < 3; ++k)
             fprintf(stderr, "[poreseg stamps] %s: longest workgroup %llu cycles, windows %llu, sum of lifetimes %llu cycles\n",
                     k == 0 ? "spine" : k == 1 ? "bridge" : "tree", hs.life[3 * k], hs.life[3 * k + 1], hs.life[3 * k + 2]);

@@ -820,6 +820,9 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         }
     }
     PS_STAMP_AT(wk, 0);                                // totals, pruning level from the sampled boundaries
+#ifdef PS_STAMP
+    wk.ph[11] += hitlike;
+#endif
     int ccount = 0;
 #define PS_COLLECT(COND, G, JJ, A1, A2)                                                                       \
     {                                                                                                         \
@@ -870,6 +873,9 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             // drain: interior candidates of the queued blocks
             ps_sync<64>();
             PS_STAMP_AT(wk, 1);                        // boundary sweep
+#ifdef PS_STAMP
+            if (qcount) { wk.ph[9] += 1; wk.ph[10] += qcount; }           // (diagnostic build) non-empty drains, blocks drained
+#endif
             for (int r = 0; r < qcount; r += 64) {
                 // (a) one queued block per lane: its 8 samples, as int16 offsets from m, go to LDS
                 const int nb = min(64, qcount - r);
@@ -950,7 +956,12 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             }
         };
         // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t); the row's boundaries lie in at most two chunks
-        auto do_row = [&](int r, const ent_t &cur) {
+        struct RowOut { s1_t a1; s2_t a2; int nl; float ge, hb; bool blk, prunable, unsure; };
+        auto row_eval = [&](int r, const ent_t &cur_in) -> RowOut {
+            ent_t cur = cur_in;
+#ifdef PS_STAMP
+            wk.ph[8] += 1;                                                 // (diagnostic build) rows swept
+#endif
             const bool first_row = r == 0;
             const int tb = gbl + BS_STRIDE * r;                            // (uniform) chunk-relative index of the row's first boundary
             const int cA = min(tb >> BS_CHUNK_LOG, nch - 1), cB = min(cA + 1, nch - 1);
@@ -986,8 +997,6 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             // the boundary itself as a candidate (lane 0 of rows > 0 repeats a boundary already counted)
             const bool inr = static_cast<unsigned>(J - cand_lo) <= crange && (lane != 0 || first_row);
             const float ge = (inr && okL && okR) ? g : -INFINITY;
-            top2_push(top, ge, nl);
-            flag |= static_cast<unsigned>(inr && !(okL && okR));
             // the block (J - 8, J): left side bounded from boundary t-1 (the lane below), right side from this one
             const float aL = from_lane_below(lg.x), rlb = from_lane_below(rr.x);
             const bool pokL = from_lane_below(static_cast<int>(okL)) != 0;
@@ -1000,19 +1009,41 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const float cL1 = aL - 7.0f * LOG2E * rlb;
             const float h0 = -fmaf(nl0f, aL, nr0f * cR0);
             const float h1 = -fmaf(nlef, cL1, nref * cR1);
-            const bool pruned = pokL && okR && nl >= 9 && fmaxf(h0, h1) < Tprune;
-            const bool keep = blk && !pruned;
+            // (bitwise, not short-circuit: with && the compiler puts the bound under an exec-mask branch)
+            const bool prunable = static_cast<bool>(static_cast<int>(pokL) & static_cast<int>(okR) & static_cast<int>(nl >= 9));
+            return RowOut{a1, a2, nl, ge, fmaxf(h0, h1), blk, prunable, inr && !(okL && okR)};
+        };
+        // (the part with side effects, in row order: per-lane top-2, the block queue, the contender list)
+        auto row_commit = [&](const RowOut &o) {
+            top2_push(top, o.ge, o.nl);
+            flag |= static_cast<unsigned>(o.unsure);
+            // A row with a boundary gain that lies above the pruning level by more than the level's own margin: the level
+            // follows that gain BEFORE the row's blocks are judged (the argument of drain_early: a block bounded more than
+            // 2 delta below a gain that was reached holds neither the winner nor a contender).  Without it a window that
+            // holds a step queues every block of the slope that leads up to it -- each row lies above everything seen
+            // before -- and 5 % of the subtree windows did 80 % of the kernel's block drains.  Windows without a step
+            // never get here (two instructions per row).
+            if (phase == 0 && __ballot(o.ge - 4.0f * dlt > Tprune) != 0ull) {
+                float bx = o.ge;
+#define PS_STEP(CTRL, RM) { bx = fmaxf(bx, dpp_movf<CTRL, RM>(-INFINITY, bx)); }
+                PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+                bx = __int_as_float(lane_get(__float_as_int(bx), 63));
+                Tprune = fmaxf(Tprune, fmaxf(thr_log2 - dthr, bx - 2.0f * dlt) - 2.0f * dlt);
+            }
+            const bool keep = static_cast<bool>(static_cast<int>(o.blk) & static_cast<int>(!(o.prunable && o.hb < Tprune)));
             const unsigned long long km = __ballot(keep);
             if (km) {
                 if (keep) {
                     BsQ_t q;
-                    bs_q_put(q, J, ps, a1, a2);
+                    bs_q_put(q, ps + o.nl, ps, o.a1, o.a2);
                     queue[qcount + lanes_below(km)] = q;
                 }
                 qcount += __popcll(km);
             }
-            if (phase) PS_COLLECT(ge >= Tc, ge, J, a1, a2)
+            if (phase) PS_COLLECT(o.ge >= Tc, o.ge, ps + o.nl, o.a1, o.a2)
         };
+        auto do_row = [&](int r, const ent_t &cur) { row_commit(row_eval(r, cur)); };
         // One row at a time (no interleaving of rows: the four waves of the SIMD cover each other's latencies, and a row
         // evaluated alone keeps the kernel at 128 registers); its slot of the ring is refilled as soon as it is free.
         if (!hitlike) {
