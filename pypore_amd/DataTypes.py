@@ -14,7 +14,7 @@ the int16 counts next to the float64 current (pypore_amd.grid), so that parsing 
 """
 import numpy as np
 
-from .core import MetaSegment, Segment, SEGMENT_FIELDS, dump_json, fields_of, ignored, load_json, plain
+from .core import MetaSegment, Segment, SEGMENT_FIELDS, dump_json, fields_of, gc_paused, ignored, load_json, plain, raw_current
 from .parsers import SpeedyStatSplit, lambda_event_parser, parser as _parser_base
 
 EVENT_FIELDS = SEGMENT_FIELDS + ('filtered', 'filter_order', 'filter_cutoff', 'n', 'state_parser', 'segments')
@@ -74,7 +74,7 @@ class Event(Segment):
         if type(self) is not Event:
             raise TypeError("Cannot filter a metaevent. Must have the current.")
         from . import engine
-        s = engine.to_device(self.current, quantum)
+        s = engine.to_device(raw_current(self), quantum)
         ctx = engine.context(s.tensor.device.index)
         out = ctx.filter_bessel(s.tensor, s.quantum, cutoff=cutoff, sampling_freq=float(self.second), order=order)
         # (a DC offset passes a unit-gain low-pass unchanged: filter the counts, put the offset back)
@@ -92,7 +92,9 @@ class Event(Segment):
         if self.__dict__.get("filtered"):
             self.segments = self._parse_filtered(parser)
         else:
-            self.segments = parser.parse(self.current)
+            # (our own segmenter takes the counts behind a current that has not been written out; any other parser gets
+            #  the float64 array)
+            self.segments = parser.parse(raw_current(self) if isinstance(parser, SpeedyStatSplit) else self.current)
         rate = float(self.file.second)
         for segment in self.segments:
             segment.event = self
@@ -177,8 +179,13 @@ class File(Segment):
         if current is not None and timestep is not None:
             filename = ""
         elif filename and current is None and timestep is None:
-            from .abf import read_abf
-            timestep, current = read_abf(filename)          # a GridArray: float64 pA that still knows its int16 counts
+            from .abf import read_abf_counts
+            from .grid import Deferred
+            # The reference's reader returns float64 pA (read_abf.py:208-212).  Here the array is written out when
+            # somebody reads `file.current` (a GridArray then, as from abf.read_abf); detection and segmentation take
+            # the file's int16 counts and never ask for it: 0.10 s of an 0.21 s Experiment.parse on a 1e8-sample file.
+            timestep, counts, scale, offset = read_abf_counts(filename)
+            current = Deferred.from_counts(counts, scale, offset)
             filename = filename.split("\\")[-1]
             filename = filename[:-4] if filename.endswith(".abf") else filename
         else:
@@ -197,9 +204,10 @@ class File(Segment):
         if parser is None:
             parser = lambda_event_parser(threshold=90)
         rate = self.second
-        self.events = [Event(current=seg.current, start=seg.start / rate, end=(seg.start + seg.duration) / rate,
+        device_route = isinstance(parser, lambda_event_parser) and parser._builtin
+        self.events = [Event(current=raw_current(seg), start=seg.start / rate, end=(seg.start + seg.duration) / rate,
                              duration=seg.duration / rate, second=rate, file=self)
-                       for seg in parser.parse(self.current)]
+                       for seg in parser.parse(raw_current(self) if device_route else self.current)]
         self.event_parser = parser
 
     def parse_events(self, parser=None, filter_params=None):
@@ -210,13 +218,17 @@ class File(Segment):
         With a SpeedyStatSplit the filtered currents never leave the device between the two steps
         (parse_filtered_batch: filter, re-quantisation and segmentation on the device, one copy of the float64 result
         back for Event.current)."""
+        with gc_paused():                                # (one pause for the file: re-enabling after every event costs a
+            self._parse_events(parser, filter_params)    #  collection each time, 0.5 ms x the number of events)
+
+    def _parse_events(self, parser, filter_params):
         if parser is None:
             parser = SpeedyStatSplit(prior_segments_per_second=10)
         rate = float(self.second)
         if filter_params is not None and hasattr(parser, "parse_filtered_batch") and all(type(ev) is Event for ev in self.events):
             # filter -> grid -> segments without leaving the device: only the filtered float64 currents come back
             order, cutoff = (tuple(filter_params) + (2000.,))[:2] if len(tuple(filter_params)) else (1, 2000.)
-            done = parser.parse_filtered_batch([ev.current for ev in self.events], order, cutoff, rate)
+            done = parser.parse_filtered_batch([raw_current(ev) for ev in self.events], order, cutoff, rate)
             for ev, (cur, segs) in zip(self.events, done):
                 ev.current = cur
                 ev.filtered, ev.filter_order, ev.filter_cutoff = True, order, cutoff
@@ -232,7 +244,7 @@ class File(Segment):
         batched = hasattr(parser, "parse_batch")
         results = [None] * len(self.events)
         plain_idx = [i for i, ev in enumerate(self.events) if not ev.__dict__.get("filtered")]
-        currents = [self.events[i].current for i in plain_idx]
+        currents = [raw_current(self.events[i]) if batched else self.events[i].current for i in plain_idx]
         for i, segs in zip(plain_idx, parser.parse_batch(currents) if batched else [parser.parse(c) for c in currents]):
             results[i] = segs
         by_step = {}

@@ -7,7 +7,7 @@ Every compute call goes through the C ABI (include/poreseg.h); nothing here comp
 import numpy as np
 
 from . import _lib, engine
-from .core import Segment
+from .core import Segment, segments_from_edges
 
 
 class FastStatSplit(object):
@@ -118,14 +118,8 @@ class FastStatSplit(object):
                 rows = st[boff[e] + e: boff[e + 1] + e + 1]
                 if parts[e].offset:                 # device statistics are those of count * quantum
                     rows = rows + np.array([parts[e].offset, 0.0, parts[e].offset, parts[e].offset])
-                edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [n]))
-                segs = []
-                for k in range(len(edges) - 1):
-                    a, z = int(edges[k]), int(edges[k + 1])
-                    seg = Segment(current=cur[a:z], start=a, duration=(z - a), end=z)
-                    seg._gpu_stats = rows[k]
-                    segs.append(seg)
-                out[i] = segs
+                edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [n])).tolist()
+                out[i] = segments_from_edges(cur, edges, rows)
 
         # group the events by the representation they will have on the device
         from .grid import grid_of
@@ -139,10 +133,11 @@ class FastStatSplit(object):
 
     def parse_filtered_batch(self, currents, order=1, cutoff=2000., sampling_freq=1.e5):
         """Event.filter + Event.parse for many events without leaving the device in between (the inner loop of
-        Experiment.parse, DataTypes.py:975-984): every current is filtered (ps_filter_bessel), the float64 result is
-        copied to the host -- it becomes Event.current --, re-quantised on the device (ps_requantise) and the events
-        that share a grid step are segmented in one ps_segment_batch.  Returns [(filtered float64 current,
-        [Segment...])] in input order; the segments hold views of the filtered current, start / end in samples."""
+        Experiment.parse, DataTypes.py:975-984): every current is filtered (ps_filter_bessel), re-quantised on the
+        device (ps_requantise) and the events that share a grid step are segmented in one ps_segment_batch.  Returns
+        [(filtered float64 current, [Segment...])] in input order, start / end in samples.  The filtered current --
+        Event.current afterwards -- stays on the device until it is read (grid.Deferred: the copy of 8 B per sample
+        was 0.08 s of an 0.21 s Experiment.parse); the segments hold stretches of it."""
         import torch
         ctx = engine.context(self.device)
         filtered, onto_grid, by_step = [None] * len(currents), [None] * len(currents), {}
@@ -153,7 +148,8 @@ class FastStatSplit(object):
             filtered[i], onto_grid[i] = (y, s.offset), z
             by_step.setdefault(step, []).append(i)
         # (a DC offset passes a unit-gain low-pass unchanged: the counts were filtered, the offset is put back)
-        filtered = [y.cpu().numpy() + off if off else y.cpu().numpy() for y, off in filtered]
+        from .grid import Deferred
+        filtered = [Deferred.from_tensor(y, off) for y, off in filtered]
         out = [None] * len(currents)
         for step, idx in by_step.items():
             lens = np.array([onto_grid[i].numel() for i in idx], dtype=np.int64)
@@ -164,7 +160,7 @@ class FastStatSplit(object):
             for e, i in enumerate(idx):
                 cur = filtered[i]
                 edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [int(lens[e])])).tolist()
-                out[i] = (cur, [Segment(current=cur[a:z], start=a, duration=z - a, end=z) for a, z in zip(edges, edges[1:])])
+                out[i] = (cur, segments_from_edges(cur, edges))
         return out
 
     # ---- cparsers.pyx:120-155 -------------------------------------------------------------------

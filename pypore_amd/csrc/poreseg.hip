@@ -98,13 +98,14 @@ struct ps_ctx {
     int wide_bs = 1;          // 1: counts too wide for the 32-bit digest are retried on the 64-bit digest, 0: straight to the LDS-window scan
     int bridge_single = 1 << 30;   // anchors a single-wave bridge adds before it hands the seam to the look-ahead kernel (measured: handing over early is slower)
     int tree_tail_pct = 0;    // tree_mw_kernel: share of the job list drawn dynamically (counter in HBM) at the end
-    // Share of the resident wave slots the single-wave scan kernels are launched on.  50 = two waves per SIMD: a SIMD's
-    // throughput does not grow beyond two scan waves (each is active about half of its time and the SIMD issues one
-    // instruction at a time), a window's latency doubles from two to four -- and the registers of the other two slots
-    // are where another call's scan kernels run at the same time.  Measured (bench trace, 100 / 75 / 62 / 50 / 44 / 37 %):
-    // four calls in flight 0.274 / 0.253 / 0.250 / 0.2445 / 0.257 / 0.270 ms per step, one call 0.522 / 0.499 / 0.511 /
-    // 0.505 / 0.572 / 0.563 ms (below 50 % the spine kernel's 2 048 tiles are no longer all resident).
-    int slots_pct = 50;
+    // Share of the resident wave slots the single-wave scan kernels are launched on (experiments; the subtree kernel
+    // decides on the device how many of its slots work: tree_jobs_per_wave, seg_device.hpp: tree_kernel).  Measured on
+    // the bench trace with 100 / 75 / 62 / 50 / 44 / 37 %: four calls in flight 0.274 / 0.253 / 0.250 / 0.2445 / 0.257 /
+    // 0.270 ms per step, one call 0.522 / 0.499 / 0.511 / 0.505 / 0.572 / 0.563 ms (below 50 % the spine kernel's 2 048
+    // tiles are no longer all resident); on the 1e9-sample trace 50 % costs 23 % (spine 0.76 -> 1.12 ms, subtrees 0.68 ->
+    // 0.90): with many jobs per slot four waves per SIMD deliver 1.4 x the throughput of two.
+    int slots_pct = 100;
+    int tree_jobs_per_wave = 4;   // subtree kernel: jobs / this many slots work, between half and all of them (0: all)
     // host-side caches: occupancy per kernel, dynamic-LDS attribute last set, the tile tables of the last call
     struct OccKey { const void *fn; int nt; size_t lds; unsigned slots; };
     std::vector<OccKey> occ_cache;
@@ -255,7 +256,10 @@ template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsign
     hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
                        ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
-                       static_cast<long long>(n_jobs), d_hdr);
+                       static_cast<long long>(n_jobs), d_hdr,
+                       // (not on the 64-bit digest: those are filtered events, whose jobs hold many windows each -- 32 of them:
+                       //  subtree kernel 1.30 ms on all slots, 1.71 ms with the rule)
+                       NT == 64 && !(DT & DT_WIDE) ? ctx->tree_jobs_per_wave : 0);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -816,6 +820,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_TREE_JPW")) ctx->tree_jobs_per_wave = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_SLOTS_PCT")) ctx->slots_pct = std::max(1, std::min(100, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);

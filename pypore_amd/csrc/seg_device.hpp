@@ -1507,16 +1507,29 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
 template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void tree_kernel(DevCfg c, const TreeJob *__restrict__ jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
-                                                  unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr)
+                                                  unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr,
+                                                  int jobs_per_wave)
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
     const long long n_jobs = dev_count(hdr, n_jobs_host);
+    // How many of the launched slots work (jobs_per_wave > 0; the job count is only known on the device).  With few
+    // jobs per slot the kernel's duration is a handful of windows in a row, and a window's latency doubles from two to
+    // four waves per SIMD: then half the slots do the work -- and the other half of the SIMD's registers is where
+    // another call's kernels run meanwhile.  With many jobs per slot the SIMD's throughput counts, which is 1.4 x
+    // higher with four waves than with two.  Between: jobs / jobs_per_wave slots.  (bench trace, 9 231 jobs: 2 307
+    // slots; four calls in flight 0.274 -> 0.245 ms per step.  1e9-sample trace, 98 007 jobs: all 4 096, subtree
+    // kernel 0.68 ms against 0.90 ms on half of them.)
+    long long G = gridDim.x;
+    if (jobs_per_wave > 0) {
+        G = max(G / 2, min(G, n_jobs / jobs_per_wave));
+        if (static_cast<long long>(blockIdx.x) >= G) return;
+    }
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
     // One workgroup per resident slot, striding over the jobs (a workgroup per job costs more in launches than the
     // one or two scans of a typical job: 0.28 ms against 0.17 ms for the 9 231 jobs of the bench trace).
-    for (long long ji = blockIdx.x; ji < n_jobs; ji += gridDim.x) {
+    for (long long ji = blockIdx.x; ji < n_jobs; ji += G) {
         const TreeJob job = jobs[ji];
         // (all fields in one round trip: otherwise the compiler fetches out_cap, tests it, and only then the rest)
         asm volatile("" : : "s"(job.base), "s"(job.start), "s"(job.end), "s"(job.j0), "s"(job.out_off), "s"(job.m), "s"(job.boff));

@@ -413,9 +413,41 @@ def _int_counts_tensor(counts, dev):
         if counts.size and (counts.min() < -32768 or counts.max() > 32767):
             raise ValueError("ADC counts beyond int16 on a grid that is not a power of two: not supported")
         counts = counts.astype(np.int16)
+    if counts.size >= _STAGE_MIN:
+        return _staged_upload(counts, dev)
     with warnings.catch_warnings():                     # (a read-only memmap of an .abf: the tensor is only copied from)
         warnings.simplefilter("ignore", UserWarning)
         return torch.from_numpy(np.ascontiguousarray(counts)).to(dev)
+
+
+_STAGE_MIN = 1 << 22                                    # samples: below this one pageable copy is as fast
+_STAGE_CHUNK = 1 << 24                                  # int16 samples per staging buffer (32 MB)
+_stage = {}
+
+
+def _staged_upload(counts, dev):
+    """A long int16 array (the data section of an .abf, usually a memmap of the page cache) -> CUDA tensor through two
+    pinned staging buffers: the host's copy of chunk k+1 out of the page cache runs while chunk k crosses PCIe.  One
+    `np.ascontiguousarray` of the whole file plus a pageable copy of it is 2-3 x slower (tools/bench_experiment.py)."""
+    key = dev.index
+    if key not in _stage:
+        _stage[key] = ([torch.empty(_STAGE_CHUNK, dtype=torch.int16, pin_memory=True) for _ in range(2)],
+                       [torch.cuda.Event() for _ in range(2)], torch.cuda.Stream(device=dev))
+    bufs, events, stream = _stage[key]
+    out = torch.empty(counts.size, dtype=torch.int16, device=dev)
+    used = [False, False]
+    with torch.cuda.stream(stream):
+        for k, a in enumerate(range(0, counts.size, _STAGE_CHUNK)):
+            b = min(counts.size, a + _STAGE_CHUNK)
+            i = k & 1
+            if used[i]:
+                events[i].synchronize()                  # the copy that last read this buffer is done
+            np.copyto(bufs[i].numpy()[:b - a], counts[a:b])
+            out[a:b].copy_(bufs[i][:b - a], non_blocking=True)
+            events[i].record(stream)
+            used[i] = True
+    stream.synchronize()
+    return out
 
 
 def to_device(current, quantum=None, offset=None, device=None, full_detect=False):
@@ -433,6 +465,10 @@ def to_device(current, quantum=None, offset=None, device=None, full_detect=False
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
     g = grid_of(current) if quantum is None else None
     if g is not None:
+        from .grid import Deferred
+        if isinstance(current, Deferred) and current.counts is not None:
+            # (a file's counts go up once: events cut from the file are stretches of the same device tensor)
+            return Samples(current.device_counts(dev, _int_counts_tensor), g[1], g[2])
         return Samples(_int_counts_tensor(g[0], dev), g[1], g[2])
     if isinstance(current, torch.Tensor) or np.asarray(current).dtype == np.int16:
         t, q = to_device_samples(current, quantum, device, full_detect)

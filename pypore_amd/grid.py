@@ -54,6 +54,10 @@ def grid_of(current):
     """(counts, quantum, offset) if `current` still knows its counts, else None."""
     if isinstance(current, GridArray) and current.counts is not None and current.counts.shape == current.shape:
         return current.counts, current.quantum, current.offset
+    if isinstance(current, Deferred):
+        if current.counts is not None:
+            return current.counts, current.quantum, current.offset
+        return grid_of(current.value())
     return None
 
 
@@ -88,3 +92,158 @@ def affine_grid(x, sample=65536, tol=1e-6):
         frac = np.abs(k - kr)
         q = float(np.min(frac[frac > tol])) * q              # a remainder that is itself on the grid, or garbage
     raise ValueError("samples are not on an ADC grid (counts * quantum + offset); pass quantum= and offset=")
+
+
+class Deferred(object):
+    """A float64 current that has not been written out yet.
+
+    `File(filename)` and the device filter produce currents of 10^8 samples that most callers never look at sample by
+    sample: the event detector and the segmenter take the int16 counts (or the device tensor) they came from, and the
+    segments carry their own statistics.  A Deferred stands in for such an array until somebody asks for its values:
+    `value()` (also `numpy.asarray(d)`) builds the float64 ndarray once and keeps it; `d[a:b]` of an unbuilt current is
+    another Deferred over the same source, so events and segments cut from it stay unbuilt too.  The classes of
+    core.py / DataTypes.py hold it behind their `current` attribute, which builds it on first access -- user code only
+    ever sees the ndarray (for a file: the GridArray the reference-style reader returns).
+
+    Sources: int16 counts with scale and offset (`from_counts`; `grid_of` hands the triple to the device route), a
+    float64 device tensor (`from_tensor`), or a stretch of another Deferred (slices share the parent's array once it
+    exists)."""
+
+    live_device_bytes = 0                                # float64 results parked on the GPU (see from_tensor)
+    DEVICE_BYTES_MAX = 16 << 30
+
+    def __init__(self, n, make, counts=None, quantum=None, offset=0.0, parent=None, start=0):
+        self._n, self._make, self._value = int(n), make, None
+        self.counts, self.quantum, self.offset = counts, quantum, float(offset)
+        self._parent, self._start = parent, int(start)
+        self.tensor = None
+
+    # ---- constructors ---------------------------------------------------------------------------------------
+    @classmethod
+    def from_counts(cls, counts, quantum, offset=0.0):
+        """counts * quantum + offset, as abf.read_abf computes it (a read-only GridArray when built)."""
+        return cls(len(counts), lambda: GridArray.from_counts(counts, quantum, offset), counts, float(quantum), offset)
+
+    @classmethod
+    def from_tensor(cls, tensor, offset=0.0):
+        """A float64 result that lives on the GPU (the filtered current of an event).  The tensors parked this way are
+        capped at DEVICE_BYTES_MAX in total; beyond that the current is copied to the host right away."""
+        nbytes = tensor.numel() * tensor.element_size()
+        d = cls(tensor.numel(), None, offset=offset)
+        d.tensor = tensor                                # (built in value(): a closure over `d` would keep it alive)
+        d._parked = nbytes
+        Deferred.live_device_bytes += nbytes
+        if Deferred.live_device_bytes > Deferred.DEVICE_BYTES_MAX:
+            d.value()
+        return d
+
+    def device_counts(self, dev, upload):
+        """int16 CUDA tensor of this current's counts.  The root of a family of slices uploads its counts once
+        (`upload(counts, dev)`) and keeps the tensor while it fits the budget of parked device bytes; stretches are
+        views of it."""
+        root = self._parent if self._parent is not None else self
+        if root.counts is None or (self._parent is not None and self._parent.counts is None):
+            return upload(self.counts, dev)
+        cached = root.__dict__.get('_dev_counts')
+        if cached is None or cached.device != dev:
+            if self is not root and 4 * self._n < root._n:
+                return upload(self.counts, dev)          # a short stretch of a file nobody has sent up: only the stretch
+            cached = upload(root.counts, dev)
+            nbytes = cached.numel() * cached.element_size()
+            if Deferred.live_device_bytes + nbytes <= Deferred.DEVICE_BYTES_MAX:
+                root._dev_counts, root._parked_counts = cached, nbytes
+                Deferred.live_device_bytes += nbytes
+        if self is root:
+            return cached
+        part = cached[self._start:self._start + self._n]
+        # (the kernels load 16 bytes at a time relative to the pointer they are given: a stretch that does not start on
+        #  an allocation boundary is copied -- device to device, microseconds)
+        return part.clone() if part.data_ptr() % 256 else part
+
+    def _release(self):
+        if getattr(self, "_parked_counts", 0):
+            Deferred.live_device_bytes -= self._parked_counts
+            self._parked_counts = 0
+            self.__dict__.pop('_dev_counts', None)
+        if getattr(self, "_parked", 0):
+            Deferred.live_device_bytes -= self._parked
+            self._parked = 0
+        self.tensor = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ---- array-likeness -------------------------------------------------------------------------------------
+    dtype = np.dtype(np.float64)
+    ndim = 1
+
+    def __len__(self):
+        return self._n
+
+    @property
+    def shape(self):
+        return (self._n,)
+
+    @property
+    def size(self):
+        return self._n
+
+    @property
+    def built(self):
+        return self._value is not None
+
+    def value(self):
+        if self._value is None:
+            if self._parent is not None:
+                self._value = self._parent.value()[self._start:self._start + self._n]
+            elif self.tensor is not None:
+                out = self.tensor.cpu().numpy()
+                self._value = out + self.offset if self.offset else out
+                self._release()
+            else:
+                self._value = self._make()
+            self._make = None
+        return self._value
+
+    def __array__(self, dtype=None, copy=None):
+        v = self.value()
+        return v if dtype is None else np.asarray(v, dtype=dtype)
+
+    def __getitem__(self, index):
+        if self._value is None and isinstance(index, slice):
+            a, b, step = index.indices(self._n)
+            if step == 1:
+                counts = self.counts[a:b] if self.counts is not None else None
+                root, base = (self._parent, self._start) if self._parent is not None else (self, 0)
+                if root._value is not None:              # (the family's array exists by now: a plain view of it)
+                    return root._value[base + a:base + max(a, b)]
+                return Deferred(max(0, b - a), None, counts, self.quantum, self.offset, parent=root, start=base + a)
+        return self.value()[index]
+
+
+def stretches(current, edges):
+    """[current[a:z]] for consecutive edges (ascending ints inside the array).  For a current that has not been written
+    out the stand-ins are filled in directly -- one per segment of a file's events, 10^4 .. 10^5 of them."""
+    if not isinstance(current, Deferred) or current._value is not None:
+        cur = built(current)
+        return [cur[a:z] for a, z in zip(edges, edges[1:])]
+    root, base = (current._parent, current._start) if current._parent is not None else (current, 0)
+    if root._value is not None:
+        v = root._value
+        return [v[base + a:base + z] for a, z in zip(edges, edges[1:])]
+    counts, q, o = current.counts, current.quantum, current.offset
+    out, new = [], Deferred.__new__
+    for a, z in zip(edges, edges[1:]):
+        d = new(Deferred)
+        d.__dict__.update(_n=z - a, _make=None, _value=None, counts=None if counts is None else counts[a:z], quantum=q,
+                          offset=o, _parent=root, _start=base + a, tensor=None)
+        out.append(d)
+    return out
+
+
+def built(current):
+    """The ndarray behind `current` (a Deferred is built, anything else is returned as it is)."""
+    return current.value() if isinstance(current, Deferred) else current

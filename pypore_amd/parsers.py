@@ -108,8 +108,10 @@ class lambda_event_parser(parser):
                 host = host * s.quantum
             host = host + s.offset
         else:
-            host = current if isinstance(current, np.ndarray) else np.asarray(current)
-        # (slices, not copies: a GridArray keeps its counts that way and Event.parse stays on the int16 route)
+            from .grid import Deferred
+            host = current if isinstance(current, (np.ndarray, Deferred)) else np.asarray(current)
+        # (slices, not copies: a GridArray -- or a current that has not been written out -- keeps its counts that way
+        #  and Event.parse stays on the int16 route)
         return [Segment(current=host[a:a + n], start=a, duration=n) for a, n in zip(starts.tolist(), lens.tolist())]
 
 

@@ -14,16 +14,23 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 counts, _ = synth.file_trace_counts(n, 7)
 path = os.path.join(tempfile.mkdtemp(), "bench.abf")
 abf.write_abf(path, counts.astype(np.int16))
-for rep in range(2):                                   # (first pass: allocations, library load)
+times = []
+for rep in range(5):                                   # (first pass: allocations, library load; then every pass is printed)
+    exp = None                                         # (the previous result is dropped first, as a caller's loop would)
     exp = Experiment([path])
     t0 = time.perf_counter()
     exp.parse(verbose=False)
-    dt = time.perf_counter() - t0
-for rep in range(2):                                   # the same without the filter (BASELINE config 3 through the classes)
+    times.append(time.perf_counter() - t0)
+dt = sorted(times[1:])[len(times[1:]) // 2]
+print("Experiment.parse, wall clock of passes 1..5: " + " ".join("%.3f" % t for t in times) + " s (pass 1 sizes the buffers; median of the rest below)")
+times2 = []
+for rep in range(4):                                   # the same without the filter (BASELINE config 3 through the classes)
+    exp2 = None
     exp2 = Experiment([path])
     t0 = time.perf_counter()
     exp2.parse(filter_params=None, segmenter=__import__("pypore_amd.parsers", fromlist=["x"]).SpeedyStatSplit(prior_segments_per_second=10), verbose=False)
-    dt2 = time.perf_counter() - t0
+    times2.append(time.perf_counter() - t0)
+dt2 = sorted(times2[1:])[len(times2[1:]) // 2]
 print("Experiment.parse(filter_params=None): %d events, %d segments: %.3f s = %.1f Msamples/s of file"
       % (len(exp2.events), len(exp2.segments), dt2, n / dt2 / 1e6))
 ev = exp.events
