@@ -840,11 +840,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     }
     const int nl0 = nh + 8 * lane;                     // samples left of this lane's boundary in row 0
     ps_sync<64>();                                     // previous user of sh.q (this wave) is done
-#ifdef PS_X_NOPHASE1
-    for (int phase = 0; phase < 1; ++phase) {
-#else
     for (int phase = 0; phase < 2; ++phase) {
-#endif
         Top2 top = {-INFINITY, -INFINITY, -1};
         unsigned flag = 0;
         int qcount = 0;
@@ -867,9 +863,6 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             return r;
         };
         auto drain = [&]() {
-#ifdef PS_X_NODRAIN
-            qcount = 0; return;
-#endif
             // drain: interior candidates of the queued blocks
             ps_sync<64>();
             PS_STAMP_AT(wk, 1);                        // boundary sweep
@@ -883,11 +876,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                     const int64_t gq = base + bs_q_j(queue[r + lane], ps) - 8;
                     int y[8];
 #pragma unroll
-#ifdef PS_X_NODRAINLD
-                    for (int w = 0; w < 8; ++w) y[w] = static_cast<int>(gq & 3) + w;
-#else
                     for (int w = 0; w < 8; ++w) y[w] = bs_count<DT>(c, gq + w) - m;
-#endif
                     if constexpr (WIDE) {
                         ybuf[2 * lane] = make_int4(y[0], y[1], y[2], y[3]);
                         ybuf[2 * lane + 1] = make_int4(y[4], y[5], y[6], y[7]);
