@@ -494,6 +494,16 @@ constexpr int BS_D = PS_BS_D;                             // rows in flight: a r
                                                           // is requested when row r has been evaluated -- the prefetch distance of a lone chain
 constexpr int BS_QN = 192;                                // queued blocks; a drain is forced when the next row may not fit
 #ifndef PS_TREE_SAMPLE
+#ifndef PS_ROW_OFFSETS_BPERMUTE
+#define PS_ROW_OFFSETS_BPERMUTE 1
+#endif
+__device__ __forceinline__ int bs_from_lane(int x, int byte_index) { return __builtin_amdgcn_ds_bpermute(byte_index, x); }
+__device__ __forceinline__ long long bs_from_lane(long long x, int byte_index)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_index, static_cast<int>(x)), hi = __builtin_amdgcn_ds_bpermute(byte_index, static_cast<int>(x >> 32));
+    return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
+}
+__device__ __forceinline__ double bs_from_lane(double x, int byte_index) { return __longlong_as_double(bs_from_lane(__double_as_longlong(x), byte_index)); }
 #define PS_TREE_SAMPLE 0                                  // 1: subtree windows run the sampling pass too (measured: see scan_window_bs)
 #endif
 constexpr int BS_EARLY = 64;                              // ... and started early beyond this many (<= BS_QN - 64)
@@ -953,6 +963,13 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #endif
             const bool first_row = r == 0;
             const int tb = gbl + BS_STRIDE * r;                            // (uniform) chunk-relative index of the row's first boundary
+#if PS_ROW_OFFSETS_BPERMUTE
+            // every lane fetches the offsets of ITS chunk from the lane that holds them (ds_bpermute: three or four LDS-pipe
+            // instructions and the index) -- two v_readlane per value plus moves and selects were 22 instructions a row
+            const int cb = min((tb + lane) >> BS_CHUNK_LOG, nch - 1) << 2;
+            const s1_t o1 = bs_from_lane(off1, cb);
+            const o2_t o2 = bs_from_lane(off2, cb);
+#else
             const int cA = min(tb >> BS_CHUNK_LOG, nch - 1), cB = min(cA + 1, nch - 1);
             const int lsw = ((tb >> BS_CHUNK_LOG) + 1) * BS_CHUNK - tb;    // first lane in the second chunk (>= 64: none)
             const bool second = lane >= lsw;
@@ -960,6 +977,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const o2_t o2A = lane_get(off2, cA), o2B = lane_get(off2, cB);
             const s1_t o1 = second ? o1B : o1A;
             const o2_t o2 = second ? o2B : o2A;
+#endif
             const int nl = nl0 + 8 * BS_STRIDE * r, J = ps + nl;
             const float nlf = static_cast<float>(nl);
             const double nld = static_cast<double>(nl);

@@ -23,3 +23,5 @@ for k in sorted(acc):
 PY
 }
 for pct in 12 25 50 100; do export PORESEG_SLOTS_PCT=$pct; run occ$pct SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_WAVES; done
+# other groups used in round 3 (see profiles/r03_experiments/pmc_stall_counters.txt): TCP_UTCL1_*, TCP_TCC_READ_REQ_LATENCY_sum,
+# TCP_PENDING_STALL_CYCLES_sum, SQ_IFETCH, SQC_ICACHE_*, SQ_INSTS_VALU_*_F64, SQ_INSTS_BRANCH, SQ_ACTIVE_INST_SCA ...
