@@ -480,6 +480,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         fprintf(stderr, " total=%llu cycles, windows=%llu -> %.0f cycles/window\n", tot, hs.work0, (double)tot / (hs.work0 ? hs.work0 : 1));
         fprintf(stderr, "[poreseg stamps] rows swept %llu, non-empty drains %llu, blocks drained %llu, hit-like windows %llu\n",
                 hs.stamp[8], hs.stamp[9], hs.stamp[10], hs.stamp[11]);
+        fprintf(stderr, "[poreseg stamps] blocks queued although not prunable (first block of a window, variance floor): %llu\n", hs.stamp[6]);
         for (int k = 0; k < 3; ++k)
             fprintf(stderr, "[poreseg stamps] %s: longest workgroup %llu cycles, windows %llu, sum of lifetimes %llu cycles\n",
                     k == 0 ? "spine" : k == 1 ? "bridge" : "tree", hs.life[3 * k], hs.life[3 * k + 1], hs.life[3 * k + 2]);

@@ -1040,6 +1040,9 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             }
             const bool keep = static_cast<bool>(static_cast<int>(o.blk) & static_cast<int>(!(o.prunable && o.hb < Tprune)));
             const unsigned long long km = __ballot(keep);
+#ifdef PS_STAMP
+            wk.ph[6] += __popcll(__ballot(keep && !o.prunable));               // (diagnostic build) kept because not prunable
+#endif
             if (km) {
                 if (keep) {
                     BsQ_t q;
