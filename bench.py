@@ -30,6 +30,12 @@ import sys
 import threading
 import time
 
+# HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Four contexts in flight need four
+# of their own: with RCCL initialised (N > 1, or one rank under torch.distributed) the communicator's streams take some,
+# the contexts share what is left and the step goes from 0.25 to 0.33 ms (tools/gpu_dist1.sh; with 8 queues 0.241 plain,
+# 0.255 with RCCL).  Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -309,6 +315,10 @@ def main():
         seq_acc[t] += cx.seq_ms()                        # HIP events on the context's stream: first upload .. last result copy
         return r
 
+    # (the job's gather once before the clock starts, like the W warm-up steps of the hot path: the first collective of a
+    #  shape sets up RCCL's channels and buffers -- 9 ms, which a 100-step run showed as +0.09 ms per step under
+    #  torch.distributed and a 20-step run as +0.4)
+    final_gather()
     barrier()
     t0 = time.perf_counter()
     results = pool.run(steps, timed)                     # K steps, step k on stream k % T (T = 1: one after the other)
@@ -489,7 +499,8 @@ def main():
             # fallbacks of the last step: host-stitch repairs (a seam gave up: BR_MAX anchors), calls redone on the
             # LDS-window path (counts too wide for the block sums), full fp64 window scans
             "host": {"omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "torch_threads": torch.get_num_threads(),
-                     "affinity_cpus": len(os.sched_getaffinity(0)), "under_torchrun": "TORCHELASTIC_RUN_ID" in os.environ},
+                     "affinity_cpus": len(os.sched_getaffinity(0)), "under_torchrun": "TORCHELASTIC_RUN_ID" in os.environ,
+                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "fallbacks": {"host_stitch": int(tm["repairs"] >= 1000000), "seam_repairs": int(tm["repairs"] % 1000000),
                           "wide_range_redo": int(tm.get("wide_redo", 0)), "full_exact_scans": int(tm["full_exact_scans"]),
                           "near_ties": int(tm.get("near_ties", 0))},
