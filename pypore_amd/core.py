@@ -15,6 +15,8 @@ from contextlib import contextmanager
 
 import numpy as np
 
+from .grid import Deferred
+
 JSON_STYLE = dict(indent=4, separators=(',', ' : '))      # the layout of README.md:346-391
 STAT_COLUMNS = ('mean', 'std', 'min', 'max')              # column order of ps_segstat (include/poreseg.h)
 SEGMENT_FIELDS = STAT_COLUMNS + ('start', 'end', 'duration')
@@ -96,7 +98,7 @@ class _Current(object):
             value = obj.__dict__['current']
         except KeyError:
             raise AttributeError('current')
-        if type(value).__name__ == 'Deferred':
+        if isinstance(value, Deferred):
             value = obj.__dict__['current'] = value.value()
         return value
 

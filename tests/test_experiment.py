@@ -137,3 +137,41 @@ def test_filtered_batch_on_a_real_header_scale_with_offset(tmp_path):
         assert [int(round(s.start * file.second)) for s in ev.segments] == [int(round(s.start * file.second)) for s in one.segments]
         assert ev.segments[0].mean == pytest.approx(one.segments[0].mean, rel=1e-12)
     assert seg.parse_filtered_batch([]) == []
+
+
+@pytest.mark.gpu
+def test_experiment_currents_are_written_out_only_when_read(tmp_path):
+    """Experiment.parse never builds the file's float64 array nor copies a filtered current back (grid.Deferred behind the
+    `current` attribute); reading them afterwards gives what the eager route gives, and the file's counts went up once."""
+    from pypore_amd.core import raw_current
+    from pypore_amd.grid import Deferred, GridArray
+    counts, _ = synth.file_trace_counts(1_200_000, 91)
+    path = os.path.join(str(tmp_path), "lazy.abf")
+    abf.write_abf(path, counts.astype(np.int16))
+    before = Deferred.live_device_bytes
+    exp = Experiment([path])
+    exp.parse(verbose=False)
+    file = exp.files[0]
+    root = raw_current(file)
+    assert isinstance(root, Deferred) and not root.built and root.__dict__.get('_dev_counts') is not None
+    assert file.n >= 1
+    for ev in file.events:
+        cur = raw_current(ev)
+        assert isinstance(cur, Deferred) and not cur.built and cur.tensor is not None and cur.tensor.is_cuda
+        assert all(isinstance(raw_current(s), Deferred) for s in ev.segments)
+        assert sum(s.n for s in ev.segments) == len(cur)
+    assert Deferred.live_device_bytes > before                              # filtered currents and the file's counts
+    ev = file.events[0]
+    a, n = int(round(ev.start * file.second)), len(raw_current(ev))
+    got = ev.current                                                        # one copy of the event's float64 current
+    assert isinstance(got, np.ndarray) and raw_current(ev) is got and got.shape == (n,)
+    seg = ev.segments[1]
+    i, j = int(round(seg.start * file.second)), int(round(seg.end * file.second))
+    assert np.shares_memory(seg.current, got) and np.array_equal(seg.current, got[i:j])
+    assert not root.built                                                   # still nobody asked for the file's array
+    one = Event(current=np.array(file.current[a:a + n]), start=ev.start, end=ev.end, duration=ev.duration,
+                second=file.second, file=file)
+    assert root is not raw_current(file) and isinstance(file.current, GridArray)
+    one.filter(1, 2000)
+    np.testing.assert_array_equal(one.current, got)
+    exp.delete()
