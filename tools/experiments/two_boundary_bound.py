@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""numpy prototype of the two-boundary bound for the 8-sample blocks of a window scan (not in the kernels).
+
+For a window y[0..n) and a candidate k (left part y[:k]) the screened gain in log2 units is
+    g(k) = n log2(SS_tot / n) - k log2(SS_L(k) / k) - (n - k) log2(SS_R(k) / (n - k)),
+SS = sum of squared deviations from the part's own mean.  The sweep evaluates g at the block boundaries k = 8 t and needs
+an upper bound of g over the 7 candidates inside a block (p, q), q = p + 8.
+
+  corner bound (seg_bs.hpp today): SS_L(k) >= SS_L(p), SS_R(k) >= SS_R(q)  -- both at their minimum, which no k realises.
+  two-boundary bound (here): SS_L(k) + SS_R(k) = SS_tot - B(k), B(k) = N(k)^2 / (n k (n - k)), N(k) = n S1_L(k) - k T1, and
+      |N(k)| <= |N(p)| + n sqrt(7 Q),  Q = sum over the block of (y - T1/n)^2            (Cauchy-Schwarz)
+  so (SS_L, SS_R) lies in the box [SS_L(p), SS_L(q)] x [SS_R(q), SS_R(p)] on or above the line SS_L + SS_R = SS_tot - Bmax.
+  The cost k log2(SS_L/k) + (n-k) log2(SS_R/(n-k)) increases in both arguments and is concave along the line and in k:
+  its minimum is at an end of the line segment and at k = p + 1 or q - 1.
+
+The script checks validity (bound >= the largest interior gain, every block, many windows of several kinds) and prints how
+tight the two bounds are and how many blocks a window without a split would keep at the bench threshold.
+usage: two_boundary_bound.py [trials]"""
+import sys
+import numpy as np
+
+LOG2E = 1.4426950408889634
+
+
+def prefix(y):
+    c1 = np.concatenate(([0.0], np.cumsum(y)))
+    c2 = np.concatenate(([0.0], np.cumsum(y * y)))
+    return c1, c2
+
+
+def gains(y):
+    n = y.size
+    c1, c2 = prefix(y)
+    T1, T2 = c1[-1], c2[-1]
+    k = np.arange(1, n)
+    ssl = c2[k] - c1[k] ** 2 / k
+    ssr = (T2 - c2[k]) - (T1 - c1[k]) ** 2 / (n - k)
+    sst = T2 - T1 * T1 / n
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = n * np.log2(sst / n) - k * np.log2(ssl / k) - (n - k) * np.log2(ssr / (n - k))
+    return k, g, ssl, ssr, sst, c1, c2
+
+
+def bounds(y):
+    """per block (p, q = p + 8), p = 8, 16, ...: largest interior gain, corner bound, two-boundary bound"""
+    n = y.size
+    k, g, ssl, ssr, sst, c1, c2 = gains(y)
+    G = np.full(n + 1, -np.inf); G[1:n] = g
+    SSL = np.zeros(n + 1); SSL[1:n] = ssl
+    SSR = np.zeros(n + 1); SSR[1:n] = ssr
+    T1 = c1[-1]; mu = T1 / n
+    out = []
+    for p in range(8, n - 16, 8):
+        q = p + 8
+        inner = G[p + 1:q].max()
+        # corner: u = SS_L(p), v = SS_R(q), worst k in {p+1, q-1} (concave in k)
+        def cost(kk, u, v):
+            return kk * np.log2(u / kk) + (n - kk) * np.log2(v / (n - kk))
+        if SSL[p] <= 0 or SSR[q] <= 0:
+            continue
+        c0 = n * np.log2(sst / n)
+        corner = c0 - min(cost(p + 1, SSL[p], SSR[q]), cost(q - 1, SSL[p], SSR[q]))
+        # two boundaries
+        Np = n * c1[p] - p * T1
+        Nq = n * c1[q] - q * T1
+        blk = y[p:q] - mu
+        Q = float(np.dot(blk, blk))
+        Nmax = min(abs(Np), abs(Nq)) + n * np.sqrt(7.0 * Q)
+        Kmin = min(p * (n - p), q * (n - q))
+        Bmax = Nmax * Nmax / (n * Kmin)
+        C = sst - Bmax                                     # SS_L + SS_R >= C inside the block
+        u0, u1, v0, v1 = SSL[p], SSL[q], SSR[q], SSR[p]
+        if u0 + v0 >= C:
+            pts = [(u0, v0)]
+        else:
+            pts = [(max(u0, C - v1), min(v1, C - u0)), (min(u1, C - v0), max(v0, C - u1))]
+        two = c0 - min(cost(kk, u, v) for (u, v) in pts for kk in (p + 1, q - 1))
+        out.append((p, inner, corner, two, max(G[p], G[q])))
+    return np.array(out)
+
+
+def window(kind, rng, n):
+    if kind == "noise":
+        return np.rint(rng.normal(0, 32, n))
+    if kind == "offset":
+        return np.rint(rng.normal(3000, 32, n))
+    if kind == "step":
+        s = rng.integers(200, n - 200)
+        y = rng.normal(0, 32, n); y[s:] += rng.choice([40, 200, 2000])
+        return np.rint(y)
+    if kind == "spikes":
+        y = rng.normal(0, 32, n); idx = rng.integers(0, n, 6); y[idx] += rng.normal(0, 2000, 6)
+        return np.rint(y)
+    if kind == "ramp":
+        return np.rint(rng.normal(0, 32, n) + np.linspace(0, 300, n))
+    if kind == "quiet":
+        y = rng.normal(0, 1.0, n); y[n // 3: n // 3 + 64] = rng.normal(0, 200, 64)
+        return np.rint(y)
+    raise ValueError(kind)
+
+
+def main():
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.default_rng(5)
+    thr = 18.4204807339517 * LOG2E                         # the bench's min_gain in log2 units
+    worst = 0.0
+    for kind in ("noise", "offset", "step", "spikes", "ramp", "quiet"):
+        loose_c, loose_t, kept_c, kept_t, nblk = [], [], 0, 0, 0
+        for t in range(trials):
+            n = int(rng.choice([800, 3000, 10000]))
+            b = bounds(window(kind, rng, n))
+            ok = np.isfinite(b[:, 1])
+            b = b[ok]
+            viol = (b[:, 1] - b[:, 3]).max()               # interior gain above the two-boundary bound?
+            worst = max(worst, viol)
+            assert (b[:, 1] <= b[:, 2] + 1e-6).all(), "corner bound violated"
+            assert viol <= 1e-6, "two-boundary bound violated by %g (%s, n = %d)" % (viol, kind, n)
+            loose_c += list(b[:, 2] - b[:, 4]); loose_t += list(b[:, 3] - b[:, 4])
+            cand = (b[:, 0] >= 104) & (b[:, 0] <= n - 108)
+            kept_c += int((b[cand, 2] >= thr - 0.4).sum()); kept_t += int((b[cand, 3] >= thr - 0.4).sum()); nblk += int(cand.sum())
+        lc, lt = np.array(loose_c), np.array(loose_t)
+        print("%-7s bound minus the larger boundary gain: corner median %6.2f p99 %7.2f | two boundaries median %6.2f p99 %7.2f | "
+              "blocks kept at the bench threshold: %5.2f %% / %5.2f %%" % (kind, np.median(lc), np.percentile(lc, 99), np.median(lt),
+                                                                          np.percentile(lt, 99), 100.0 * kept_c / nblk, 100.0 * kept_t / nblk))
+    print("largest (interior gain - two-boundary bound) seen: %.3g (must be <= 0)" % worst)
+
+
+if __name__ == "__main__":
+    main()
