@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
 }
 
 // ---- screen arithmetic from window-relative sums ------------------------------------------------------
-struct BsEval { float g; f2 lg; f2 r; bool okL, okR; };
+struct BsEval { float g; f2 lg; f2 r; f2 u; bool okL, okR; };
 
 // Screened gain of the split (nl | nr) from the exact sums about m of the left part (a1, a2) and the right
 // part (b1, b2).  D = n*S2 - S1^2 is formed in fp64 (relative error kappa_m * 2^-52 with kappa_m = n*S2/D
@@ -443,6 +443,7 @@ __device__ __forceinline__ BsEval bs_eval(double a1d, double a2, double b1d, dou
     BsEval o;
     o.lg = lgu - cc;
     o.r = r;
+    o.u = u;
     o.okL = u.x >= vfloor;
     o.okR = u.y >= vfloor;
     const f2 t = nv * o.lg;
@@ -450,6 +451,47 @@ __device__ __forceinline__ BsEval bs_eval(double a1d, double a2, double b1d, dou
     return o;
 }
 
+
+// Upper bound of the screened gain of the 7 candidates inside the block (p, q), q = p + 8, from the evaluations of BOTH of
+// its boundaries (ep at p, eq at q) -- the corner bound of the sweep takes SS_L at p and SS_R at q together, which no
+// candidate has (tools/experiments/two_boundary_bound.py checks this form against the exact gains).
+// With SS the sums of squared deviations of the two parts and B(k) = N(k)^2 / (n k (n - k)), N(k) = n S1_L(k) - k T1:
+//     SS_L(k) + SS_R(k) = SS_tot - B(k)      exactly;
+// inside the block SS_L grows from SS_L(p) to SS_L(q), SS_R falls from SS_R(p) to SS_R(q), and
+//     |N(k)| <= min(|N(p)|, |N(q)|) + n sqrt(7 Q),   Q = sum over the block of (y - T1/n)^2      (Cauchy-Schwarz)
+//                                                      <= 2 (q/p) (SS_L(q) - SS_L(p)) + 16 B(p) (n - p) / (n p),
+// so (SS_L, SS_R) lies in that box on or above the line SS_L + SS_R = SS_tot - Bmax.  The cost
+// k log(SS_L/k) + (n-k) log(SS_R/(n-k)) increases in both arguments and is concave along the line and in k: its minimum is
+// next to one of the boundaries --
+//     gain(k) <= max( P(p) + (n-p) e1 ,  P(q) + q e2 ),    P = gain + 7 |lgL - lgR| + 49 log2e (1/nl + 1/nr),
+//     e1 = log2e s1 / (SS_R(p) - s1),  s1 = Bmax - B(p);    e2 = log2e s2 / (SS_L(q) - s2),  s2 = Bmax - B(q).
+// On noise the corner bound lies 10.7 (median) / 28.5 (99 %) log2 units above the larger boundary gain, this one 0.8 / 10.9.
+// Returns +inf when one of the four variances is below the floor.
+__device__ __forceinline__ float bs_block_bound2(const BsEval &ep, const BsEval &eq, int p, int n, float SSt, float rn)
+{
+    const float LOG2E = 1.4426950408889634f;
+    const float nf = static_cast<float>(n);
+    const float pf = static_cast<float>(p), qf = pf + 8.0f, npf = nf - pf, nqf = npf - 8.0f;
+    const float SSLp = pf * ep.u.x, SSRp = npf * ep.u.y, SSLq = qf * eq.u.x, SSRq = nqf * eq.u.y;
+    const float eB = SSt * 2.0e-6f;                                          // rounding of the fp32 sums of squares
+    const float Bp = (SSt - SSLp) - SSRp, Bq = (SSt - SSLq) - SSRq;
+    const float Bpu = fmaxf(Bp, 0.0f) + eB, Bqu = fmaxf(Bq, 0.0f) + eB;
+    const float DLb = fmaxf(SSLq - SSLp, 0.0f) + eB;
+    const float Qb = fmaf(2.0f * fmaf(8.0f, ep.r.x, 1.0f), DLb, 16.0f * Bpu * (npf * rn) * ep.r.x);
+    const float rK = __builtin_amdgcn_rcpf(fminf(pf * npf, qf * nqf));
+    const float kap = fmaf(8.0f, fmaxf(ep.r.x, eq.r.y), 1.0f);
+    const float sBQ = __builtin_amdgcn_sqrtf(fminf(Bpu, Bqu) * kap) + __builtin_amdgcn_sqrtf(7.0f * nf * Qb * rK);
+    const float Bm = fmaf(sBQ, sBQ * 1.00001f, eB);
+    const float s1 = fmaxf(Bm - (Bp - eB), 0.0f), s2 = fmaxf(Bm - (Bq - eB), 0.0f);
+    const float v1 = fmaxf(SSRp - s1, SSRq), u2 = fmaxf(SSLq - s2, SSLp);
+    const float e1 = (LOG2E * 1.00001f) * (SSRp - v1) * __builtin_amdgcn_rcpf(v1);
+    const float e2 = (LOG2E * 1.00001f) * (SSLq - u2) * __builtin_amdgcn_rcpf(u2);
+    const float Pp = ep.g + fmaf(7.0f, fabsf(ep.lg.x - ep.lg.y), (49.0f * LOG2E) * (ep.r.x + ep.r.y));
+    const float Pq = eq.g + fmaf(7.0f, fabsf(eq.lg.x - eq.lg.y), (49.0f * LOG2E) * (eq.r.x + eq.r.y));
+    const float hb = fmaxf(fmaf(npf, e1, Pp), fmaf(qf, e2, Pq)) + 1.0e-3f;
+    const bool sound = static_cast<bool>(static_cast<int>(ep.okL) & static_cast<int>(ep.okR) & static_cast<int>(eq.okL) & static_cast<int>(eq.okR));
+    return sound ? hb : INFINITY;
+}
 
 struct BsQ { int j, a1; double a2; };                     // queued block (J-8, J): its end J, sums of [ps, J)
 struct BsC { int j, a1; double a2; float g; int pad; };   // contender: candidate, its exact sums, screened gain
@@ -492,7 +534,10 @@ constexpr int BS_NC = 64;                                 // contenders kept per
 #endif
 constexpr int BS_D = PS_BS_D;                             // rows in flight: a ring of digest entries in registers (8 bytes each), row r + BS_D
                                                           // is requested when row r has been evaluated -- the prefetch distance of a lone chain
-constexpr int BS_QN = 192;                                // queued blocks; a drain is forced when the next row may not fit
+constexpr int BS_QN = 128;                                // queued blocks: a drain starts beyond BS_EARLY, and a row adds at most 63
+#ifndef PS_DRAIN_FILTER
+#define PS_DRAIN_FILTER 1                                 // queued blocks are re-judged from both of their boundaries before their samples are fetched (bs_block_bound2)
+#endif
 #ifndef PS_TREE_SAMPLE
 #ifndef PS_ROW_OFFSETS_BPERMUTE
 #define PS_ROW_OFFSETS_BPERMUTE 1
@@ -508,7 +553,7 @@ __device__ __forceinline__ double bs_from_lane(double x, int byte_index) { retur
 #endif
 constexpr int BS_EARLY = 64;                              // ... and started early beyond this many (<= BS_QN - 64)
 constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
-constexpr int BS_LDS_BYTES = static_cast<int>(sizeof(BsQ)) * BS_QN + static_cast<int>(sizeof(BsC)) * BS_NC + 64 * 32;
+constexpr int BS_LDS_BYTES = (static_cast<int>(sizeof(BsQ)) + 8) * BS_QN + static_cast<int>(sizeof(BsC)) * BS_NC + 64 * 32;   // (+ 8: the block's own sums)
 static_assert(sizeof(QEnt) * SharedT<64>::QN >= BS_LDS_BYTES, "SharedT<64>::q too small");   // (64 * 32: staged blocks of the wide digest, 8 int32 each)
 
 // Exact (reference-order, fp64) gain of one candidate from its exact integer sums about m.
@@ -768,6 +813,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     const float nf = static_cast<float>(n);
     const float rn = __builtin_amdgcn_rcpf(nf);
     const float c0f = uni(__builtin_amdgcn_logf(static_cast<float>(Dtot) * rn * rn));
+    const float SSt = uni(static_cast<float>(Dtot) * rn);                  // sum of squared deviations of the whole window
     const f2 cc = {c0f, c0f};
     const float dlt = screen_delta_log2(n);
     const float thr_log2 = static_cast<float>(thresh * 1.4426950408889634);
@@ -780,7 +826,8 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     const float vfloor = uni(fmaxf(mabsf * mabsf * 1.0e-9f, ymaxf * ymaxf * (WIDE ? 2.4e-7f : 1.5e-8f)));
     const unsigned crange = static_cast<unsigned>(cand_hi - cand_lo);
     BsQ_t *queue = reinterpret_cast<BsQ_t *>(sh.q);
-    BsC_t *cont = reinterpret_cast<BsC_t *>(queue + BS_QN);
+    int2 *qblk = reinterpret_cast<int2 *>(queue + BS_QN);             // the queued block's own sums (S1, S2 of its 8 samples; narrow digest)
+    BsC_t *cont = reinterpret_cast<BsC_t *>(qblk + BS_QN);
     int4 *ybuf = reinterpret_cast<int4 *>(cont + BS_NC);               // 64 staged blocks: 8 int16 offsets (wide digest: 8 int32)
 
     int result = -2;
@@ -876,6 +923,37 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             // drain: interior candidates of the queued blocks
             ps_sync<64>();
             PS_STAMP_AT(wk, 1);                        // boundary sweep
+            if constexpr (!WIDE && PS_DRAIN_FILTER) {
+                // First the queued blocks are judged again, from both of their boundaries (bs_block_bound2; one block per
+                // lane).  The sweep's corner bound keeps 3-5 % of the blocks of a window without a split; this one keeps
+                // practically none of them, and the window then needs neither the blocks' samples -- a dependent round trip
+                // to HBM -- nor the evaluation of their 7 x 23 candidates.  Blocks on the slope of a step stay, as before.
+                int kept = 0;
+                for (int r = 0; r < qcount; r += 64) {
+                    const int idx = min(r + lane, qcount - 1);
+                    const BsQ_t q = queue[idx];
+                    const int2 bl = qblk[idx];
+                    const int nlq = bs_q_j(q, ps) - ps, nlp = nlq - 8;
+                    const int a1q = bs_q_a1(q), a1p = a1q - bl.x;
+                    const double a2q = q.a2, a2p = a2q - static_cast<double>(static_cast<unsigned>(bl.y));
+                    bool stay = r + lane < qcount;
+                    if (nlp >= 1) {
+                        const BsEval eq = bs_eval(bs_d(a1q), a2q, bs_d(T1 - a1q), T2 - a2q, nlq, n - nlq, cc, vfloor);
+                        const BsEval ep = bs_eval(bs_d(a1p), a2p, bs_d(T1 - a1p), T2 - a2p, nlp, n - nlp, cc, vfloor);
+                        stay = stay && !(bs_block_bound2(ep, eq, nlp, n, SSt, rn) < Tprune);
+                    }
+                    const unsigned long long sm = __ballot(stay);
+                    ps_sync<64>();                       // every lane has read its entry
+                    if (stay) {
+                        const int slot = kept + lanes_below(sm);
+                        queue[slot] = q;
+                        qblk[slot] = bl;
+                    }
+                    kept += __popcll(sm);
+                    ps_sync<64>();
+                }
+                qcount = kept;
+            }
 #ifdef PS_STAMP
             if (qcount) { wk.ph[9] += 1; wk.ph[10] += qcount; }           // (diagnostic build) non-empty drains, blocks drained
 #endif
@@ -1044,10 +1122,18 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             wk.ph[6] += __popcll(__ballot(keep && !o.prunable));               // (diagnostic build) kept because not prunable
 #endif
             if (km) {
+                int2 bsum = make_int2(0, 0);
+                if constexpr (!WIDE && PS_DRAIN_FILTER) {
+                    // the block's own sums: this boundary's minus the one below (all lanes are here: the branch is the wave's)
+                    const double a2b = __hiloint2double(from_lane_below(__double2hiint(o.a2)), from_lane_below(__double2loint(o.a2)));
+                    bsum = make_int2(o.a1 - from_lane_below(o.a1), static_cast<int>(static_cast<unsigned>(o.a2 - a2b)));
+                }
                 if (keep) {
                     BsQ_t q;
                     bs_q_put(q, ps + o.nl, ps, o.a1, o.a2);
-                    queue[qcount + lanes_below(km)] = q;
+                    const int slot = qcount + lanes_below(km);
+                    queue[slot] = q;
+                    if constexpr (!WIDE && PS_DRAIN_FILTER) qblk[slot] = bsum;
                 }
                 qcount += __popcll(km);
             }
