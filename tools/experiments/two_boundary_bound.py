@@ -88,7 +88,37 @@ def bounds(y):
         Pp = G[p] + 7.0 * abs(lgL(p) - lgR(p)) + 49.0 * LOG2E * (1.0 / p + 1.0 / (n - p))
         Pq = G[q] + 7.0 * abs(lgL(q) - lgR(q)) + 49.0 * LOG2E * (1.0 / q + 1.0 / (n - q))
         lane = max(Pp + (n - p) * e1, Pq + q * e2)
-        out.append((p, inner, corner, two, max(G[p], G[q]), min(corner, lane)))
+        # ... and in the kernel's arithmetic: D = n S2 - S1^2 exact, everything after its conversion in float32, with the
+        # margins of bs_block_bound2 (seg_bs.hpp)
+        f = np.float32
+        def ev(kk):
+            DLk = kk * c2[kk] - c1[kk] ** 2; DRk = (n - kk) * (c2[-1] - c2[kk]) - (T1 - c1[kk]) ** 2
+            r = (f(1) / f(kk), f(1) / f(n - kk))
+            u = (f(DLk) * r[0] * r[0], f(DRk) * r[1] * r[1])
+            c0f = np.log2(f(n * c2[-1] - T1 * T1) * (f(1) / f(n)) * (f(1) / f(n)))
+            lg = (f(np.log2(u[0])) - f(c0f), f(np.log2(u[1])) - f(c0f))
+            return dict(u=u, r=r, lg=lg, g=f(-(f(kk) * lg[0] + f(n - kk) * lg[1])))
+        ep, eq = ev(p), ev(q)
+        rn = f(1) / f(n); SStf = f(n * c2[-1] - T1 * T1) * rn; nf = f(n)
+        pf, qf, npf, nqf = f(p), f(q), f(n - p), f(n - q)
+        SSLp, SSRp, SSLq, SSRq = pf * ep["u"][0], npf * ep["u"][1], qf * eq["u"][0], nqf * eq["u"][1]
+        eB = SStf * f(2.0e-6)
+        Bpf, Bqf = (SStf - SSLp) - SSRp, (SStf - SSLq) - SSRq
+        Bpu, Bqu = max(Bpf, f(0)) + eB, max(Bqf, f(0)) + eB
+        DLb = max(SSLq - SSLp, f(0)) + eB
+        Qf = f(2) * (f(8) * ep["r"][0] + f(1)) * DLb + f(16) * Bpu * (npf * rn) * ep["r"][0]
+        rK = f(1) / min(pf * npf, qf * nqf)
+        kapf = f(8) * max(ep["r"][0], eq["r"][1]) + f(1)
+        sBQ = np.sqrt(min(Bpu, Bqu) * kapf, dtype=f) + np.sqrt(f(7) * nf * Qf * rK, dtype=f)
+        Bmf = sBQ * (sBQ * f(1.00001)) + eB
+        s1f, s2f = max(Bmf - (Bpf - eB), f(0)), max(Bmf - (Bqf - eB), f(0))
+        v1, u2 = max(SSRp - s1f, SSRq), max(SSLq - s2f, SSLp)
+        L2 = f(LOG2E) * f(1.00001)
+        e1f, e2f = L2 * (SSRp - v1) * (f(1) / v1), L2 * (SSLq - u2) * (f(1) / u2)
+        Ppf = ep["g"] + (f(7) * abs(ep["lg"][0] - ep["lg"][1]) + f(49.0 * LOG2E) * (ep["r"][0] + ep["r"][1]))
+        Pqf = eq["g"] + (f(7) * abs(eq["lg"][0] - eq["lg"][1]) + f(49.0 * LOG2E) * (eq["r"][0] + eq["r"][1]))
+        kern = float(max(npf * e1f + Ppf, qf * e2f + Pqf) + f(1.0e-3))
+        out.append((p, inner, corner, two, max(G[p], G[q]), min(corner, lane), kern))
     return np.array(out)
 
 
@@ -133,6 +163,9 @@ def main():
             worst2 = max(worst2, viol2)
             assert viol2 <= 1e-6, "register form of the two-boundary bound violated by %g (%s, n = %d)" % (viol2, kind, n)
             loose_r += list(b[:, 5] - b[:, 4])
+            # float32 form: the screened gains it is compared with are themselves within delta = 0.02 + 8e-6 n of the exact ones
+            viol3 = (b[:, 1] - b[:, 6]).max()
+            assert viol3 <= 0.02 + 8e-6 * n, "float32 form of the bound violated by %g (%s, n = %d)" % (viol3, kind, n)
             loose_c += list(b[:, 2] - b[:, 4]); loose_t += list(b[:, 3] - b[:, 4])
             cand = (b[:, 0] >= 104) & (b[:, 0] <= n - 108)
             kept_c += int((b[cand, 2] >= thr - 0.4).sum()); kept_t += int((b[cand, 3] >= thr - 0.4).sum()); nblk += int(cand.sum())
