@@ -80,7 +80,7 @@ def bounds(y):
         DL = SSL[q] - SSL[p]
         Qb = 2.0 * (1.0 + 8.0 / p) * DL + 16.0 * Bp * (n - p) / (n * p)
         kap = 1.0 + 8.0 * max(1.0 / p, 1.0 / (n - q))
-        Bm = (np.sqrt(min(Bp, Bq) * kap) + np.sqrt(7.0 * n * Qb / Kmin)) ** 2
+        Bm = (np.sqrt(max(min(Bp, Bq), 0.0) * kap) + np.sqrt(max(7.0 * n * Qb / Kmin, 0.0))) ** 2
         s1, s2 = max(Bm - Bp, 0.0), max(Bm - Bq, 0.0)
         vv = max(SSR[p] - s1, SSR[q]); uu = max(SSL[q] - s2, SSL[p])
         e1 = LOG2E * (SSR[p] - vv) / vv; e2 = LOG2E * (SSL[q] - uu) / uu
