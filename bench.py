@@ -81,6 +81,156 @@ def cpu_parse_tiled(x, cores, halo):
     return pdist.stitch_pieces(pieces, n, PARAMS["window_width"], PARAMS["min_width"])
 
 
+# ---- the N > 1 pieces of the bench, factored out of main() so that tests/test_bench_contract.py can drive them over gloo
+#      on CPU tensors (torch.distributed is backend-agnostic: on the GPU box the same code runs on nccl = RCCL) ------------
+class JobGather:
+    """The one boundary gather of a trace / file job (as in Experiment.parse, which collects after all files are parsed):
+    every rank writes the boundaries of its K batches into row k of a [K, slot] send buffer and ONE all_gather of the
+    buffer plus one of the K counts runs at the end of the job, inside the timed region."""
+
+    def __init__(self, steps, slot, world, device):
+        import torch
+        self.steps, self.slot, self.world, self.device = steps, slot, world, device
+        self.acc = torch.zeros((steps, slot), dtype=torch.int32, device=device)
+        self.counts = np.zeros(steps, dtype=np.int64)
+        self.recv = torch.zeros(world * steps * slot, dtype=torch.int32, device=device)
+        self.recv_counts = torch.zeros(world * steps, dtype=torch.int64, device=device)
+
+    @staticmethod
+    def slot_for(most):
+        return 1 << int(np.ceil(np.log2(2 * most + 8)))
+
+    def put(self, k, b):
+        """batch k's boundaries (for callers that do not write into acc[k] themselves)"""
+        self.acc[k, :b.numel()].copy_(b)
+        self.counts[k] = b.numel()
+
+    def run(self):
+        import torch
+        import torch.distributed as dist
+        cnt = torch.from_numpy(self.counts).to(self.device)
+        dist.all_gather_into_tensor(self.recv_counts, cnt)
+        dist.all_gather_into_tensor(self.recv, self.acc.view(-1))
+
+    def last_counts(self):
+        """boundaries of the job's last batch, per rank"""
+        return [int(c) for c in self.recv_counts.view(self.world, self.steps).cpu().numpy()[:, -1]]
+
+    def row(self, rank, k):
+        cnt = int(self.recv_counts.view(self.world, self.steps)[rank, k])
+        return self.recv.view(self.world, self.steps, -1)[rank, k, :cnt]
+
+
+def sharded_trace_join(b, sp, ranges, n, W, mw, halo, repair):
+    """config 5, one step: this rank's piece boundaries + spine flags -> everybody's (two variable-length gathers) ->
+    joined at common spine anchors (every rank walks the same gathered data)"""
+    from pypore_amd import dist as pdist
+    allb = pdist.gather_varlen(b)
+    allf = pdist.gather_varlen(sp)
+    pieces = [(ranges[r][0], ranges[r][1], allb[r].cpu().numpy(), allf[r].cpu().numpy()) for r in range(len(ranges))]
+    return pdist.stitch_pieces(pieces, n, W, mw, repair=repair, halo=halo)
+
+
+def sharded_trace_repair(rank, r_up, piece_fn, device):
+    """a seam without a common anchor: the upstream rank re-segments the stretch, everybody receives it"""
+    import torch
+    from pypore_amd import dist as pdist
+    if rank == r_up:
+        rb, rf = piece_fn()
+    else:
+        rb = torch.zeros(0, dtype=torch.int32, device=device)
+        rf = torch.zeros(0, dtype=torch.uint8, device=device)
+    gb, gf = pdist.gather_varlen(rb), pdist.gather_varlen(rf)
+    return gb[r_up].cpu().numpy(), gf[r_up].cpu().numpy()
+
+
+def files_job_gather(bounds_per_file, device):
+    """config 4: the job's one gather -- the per-file counts, then the concatenated boundaries; returns per rank
+    (counts, boundaries)"""
+    import torch
+    from pypore_amd import dist as pdist
+    cat = torch.cat(bounds_per_file) if bounds_per_file else torch.zeros(0, dtype=torch.int32, device=device)
+    cnts = pdist.gather_varlen(torch.tensor([b.numel() for b in bounds_per_file], dtype=torch.int32, device=device))
+    return cnts, pdist.gather_varlen(cat)
+
+
+def max_over_ranks(dt, device):
+    """(MAX over ranks of the job's time, every rank's time) -- the contract's clock"""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([dt], dtype=torch.float64, device=device)
+    every = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(every, mine)
+    return float(every.max().item()), [float(x) for x in every.cpu().numpy()]
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` (N > 1) started as ONE process: start the N ranks as children under
+    torch.distributed.run, BEFORE anything here touches the GPU (no exec: a process that initialised HIP must not be
+    replaced), pass rank 0's JSON line through (the children inherit stdout) and leave with their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def selftest_dist(args):
+    """--selftest-dist: the N > 1 plumbing of this file on CPU tensors over gloo (no GPU, no library): the job gather,
+    the sharded-trace join with a synthetic per-rank segmenter, the files gather, the clock.  Rank 0 prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    from pypore_amd import dist as pdist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert world == args.gpus, (world, args.gpus)
+    dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    ok = {}
+    # job gather: K batches of rank-dependent boundaries
+    K = 5
+    mk = lambda r, k: torch.arange(3 + 2 * r + k, dtype=torch.int32) * (r + 1) + k                 # noqa: E731
+    jg = JobGather(K, JobGather.slot_for(3 + 2 * world + K), world, dev)
+    for k in range(K):
+        jg.put(k, mk(rank, k))
+    jg.run()
+    ok["job_gather"] = all(torch.equal(jg.row(r, k), mk(r, k)) for r in range(world) for k in range(K)) \
+        and jg.last_counts() == [3 + 2 * r + K - 1 for r in range(world)]
+    # sharded trace: boundaries every 700 samples, every one a spine anchor; a piece reports those inside it
+    n, W, mw = 200000, 2000, 100
+    halo = 8 * W
+    ranges = pdist.shard_ranges(n, world, halo)
+    truth = np.arange(700, n, 700, dtype=np.int64)
+
+    def piece(lo, hi):
+        b = truth[(truth >= lo + 1) & (truth < hi - mw)] - lo
+        return torch.from_numpy(b.astype(np.int32)), torch.ones(b.size, dtype=torch.uint8)
+
+    lo, hi = ranges[rank]
+    b, sp = piece(lo, hi)
+    got = sharded_trace_join(b, sp, ranges, n, W, mw, halo,
+                             lambda r_up, lo2, hi2: sharded_trace_repair(rank, r_up, lambda: piece(lo2, hi2), dev))
+    ok["sharded_trace_join"] = bool(np.array_equal(np.asarray(got, dtype=np.int64), truth[truth < n - mw]))
+    # files gather
+    mine = pdist.shard_units([1000 + 10 * f for f in range(7)], world)[rank]
+    cnts, cat = files_job_gather([torch.full((f + 1,), f, dtype=torch.int32) for f in mine], dev)
+    shards = pdist.shard_units([1000 + 10 * f for f in range(7)], world)
+    ok["files_gather"] = all([int(c) for c in cnts[r]] == [f + 1 for f in shards[r]] and
+                             [int(x) for x in cat[r]] == [f for f in shards[r] for _ in range(f + 1)] for r in range(world))
+    tmax, every = max_over_ranks(0.001 * (rank + 1), dev)
+    ok["clock"] = abs(tmax - 0.001 * world) < 1e-12 and len(every) == world
+    if rank == 0:
+        print(json.dumps({"selftest": "dist", "ok": bool(all(ok.values())), "checks": ok, "ranks_seen": dist.get_world_size(),
+                          "backend": dist.get_backend()}))
+    dist.destroy_process_group()
+    return 0 if all(ok.values()) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,7 +249,16 @@ def main():
                     help="contexts (HIP streams) the K steps of the trace / file workloads are spread over: independent "
                          "batches overlap on the GPU (engine.StreamPool); 1 = one batch at a time")
     ap.add_argument("--workload", choices=["trace", "file", "sharded-trace", "files"], default="trace")
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="run only the N > 1 plumbing of this file on CPU tensors over gloo (no GPU needed) and print one JSON line")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by itself: become the launcher of the N ranks (before torch or the GPU are touched)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    if args.selftest_dist:
+        if "WORLD_SIZE" not in os.environ:               # --gpus 1: a world of one
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+        sys.exit(selftest_dist(args))
     wl = args.workload
     defaults = {"trace": (100, 20, 100_000_000), "file": (100, 20, 100_000_000),
                 "sharded-trace": (20, 5, 1_000_000_000), "files": (3, 1, 75_000_000)}[wl]
@@ -137,7 +296,8 @@ def main():
 
     T = max(1, args.streams) if wl in ("trace", "file") else 1
     pool = engine.StreamPool(dev, T)
-    acc = acc_counts = recv = recv_counts = None
+    acc = acc_counts = None
+    jg = None                                            # the job's boundary gather (N > 1)
     check = {}                                           # parity evidence gathered outside the timed region
     final_gather = lambda: None                          # noqa: E731
     trace = None
@@ -188,16 +348,9 @@ def main():
             # (plus one of the K counts) runs at the end of the job, inside the timed region.
             b0 = step()
             most = max(int(t.numel()) for t in pdist.gather_varlen(b0))
-            slot = 1 << int(np.ceil(np.log2(2 * most + 8)))
-            acc = torch.zeros((steps, slot), dtype=torch.int32, device=device)
-            acc_counts = np.zeros(steps, dtype=np.int64)
-            recv = torch.zeros(world * steps * slot, dtype=torch.int32, device=device)
-            recv_counts = torch.zeros(world * steps, dtype=torch.int64, device=device)
-
-            def final_gather():                          # noqa: F811
-                cnt = torch.from_numpy(acc_counts).to(device)
-                dist.all_gather_into_tensor(recv_counts, cnt)
-                dist.all_gather_into_tensor(recv, acc.view(-1))
+            jg = JobGather(steps, JobGather.slot_for(most), world, device)
+            acc, acc_counts = jg.acc, jg.counts
+            final_gather = jg.run
 
     elif wl == "sharded-trace":
         halo = 8 * W
@@ -221,20 +374,11 @@ def main():
 
         if use_dist:
             def repair(r_up, lo2, hi2):
-                if rank == r_up:
-                    rb, rf = regen_segment(lo2, hi2)
-                else:
-                    rb = torch.zeros(0, dtype=torch.int32, device=device)
-                    rf = torch.zeros(0, dtype=torch.uint8, device=device)
-                gb, gf = pdist.gather_varlen(rb), pdist.gather_varlen(rf)
-                return gb[r_up].cpu().numpy(), gf[r_up].cpu().numpy()
+                return sharded_trace_repair(rank, r_up, lambda: regen_segment(lo2, hi2), device)
 
             def step(k=None):
                 b, sp = segment_piece(trace, piece_off, out1)
-                allb = pdist.gather_varlen(b)
-                allf = pdist.gather_varlen(sp)
-                pieces = [(ranges[r][0], ranges[r][1], allb[r].cpu().numpy(), allf[r].cpu().numpy()) for r in range(world)]
-                return pdist.stitch_pieces(pieces, n, W, mw, repair=repair, halo=halo)
+                return sharded_trace_join(b, sp, ranges, n, W, mw, halo, repair)
         else:
             def step(k=None):
                 b, sp = segment_piece(trace, piece_off, out1)
@@ -280,9 +424,7 @@ def main():
                 st_, ln_, b, o, _ = pipeline.segment_file_trace(dbuf[j % 2], synth.QUANTUM, params, threshold=90.0)
                 results.append((st_, ln_, b.clone(), o))
             if use_dist:                                 # the job's one gather: counts, then the padded payload
-                cat = torch.cat([r[2] for r in results]) if results else torch.zeros(0, dtype=torch.int32, device=device)
-                pdist.gather_varlen(torch.tensor([r[2].numel() for r in results], dtype=torch.int32, device=device))
-                pdist.gather_varlen(cat)
+                files_job_gather([r[2] for r in results], device)
             return results
         samples_per_step = n * n_files
         bytes_per_sample = 2
@@ -353,10 +495,10 @@ def main():
     ctx.set_option("timing", 1)
     for k in kern:
         kern[k] /= max(1, min(steps, 20))
+    per_rank_ms = [dt / steps * 1e3]
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, every = max_over_ranks(dt, device)
+        per_rank_ms = [t_ / steps * 1e3 for t_ in every]
     ms_per_step = dt / steps * 1e3
     value = samples_per_step / (dt / steps) / 1e6
 
@@ -389,11 +531,9 @@ def main():
                     check["g7_sha256_equal"] = None
             assert check["all_streams_equal_single_stream"] and check.get("g7_sha256_equal", True) is not False, check
         if use_dist:
-            all_counts = recv_counts.view(world, steps).cpu().numpy()
-            n_bounds = [int(c) for c in all_counts[:, -1]]            # the last batch's boundaries, all ranks
-            mine_row = recv.view(world, steps, -1)[rank, steps - 1, :n_bounds[rank]]
+            n_bounds = jg.last_counts()                               # the last batch's boundaries, all ranks
             # (the last batch ran on stream (steps - 1) % T, i.e. on that stream's trace)
-            assert torch.equal(mine_row, results[-1][:n_bounds[rank]]), "boundary gather returned something else for this rank"
+            assert torch.equal(jg.row(rank, steps - 1), results[-1][:n_bounds[rank]]), "boundary gather returned something else for this rank"
         else:
             n_bounds = [int(bounds.numel())]
     elif wl == "sharded-trace":
@@ -453,6 +593,9 @@ def main():
             "dtype": "int32/f64 (exact integer block sums of fp32 or int16 samples; decisions in fp64)", "data": "synthetic",
             "config": {"workload": workload_text, "name": wl, "samples_per_step": samples_per_step, "boundaries": n_bounds,
                        "segment_stats_in_step": bool(args.stats), "checks": check, "streams": T,
+                       # what torch.distributed (RCCL on the GPU box) itself reports, and every rank's own clock
+                       "ranks_seen": dist.get_world_size() if use_dist else 1,
+                       "ms_per_step_per_rank": [round(x_, 4) for x_ in per_rank_ms],
                        "streams_note": ("step k runs on context k %% %d (own HIP stream and scratch, one host thread each): "
                                         "independent batches overlap on the GPU; every step is a complete, synchronised "
                                         "ps_segment_batch" % T) if T > 1 else "one batch at a time"},
@@ -464,6 +607,7 @@ def main():
                          # HBM bytes per launch (PMC): of one call at a time, and -- the headline configuration -- per call
                          # with four calls in flight on four distinct traces
                          "traffic": (traffic.get("total_4_streams") if T == 4 and traffic.get("total_4_streams") else traffic["total"]) if traffic else None,
+                         "traffic_measured_in_run": False,       # read from the committed PMC summary of the same command (traffic_source)
                          "traffic_one_call_at_a_time": traffic["total"] if traffic else None,
                          "traffic_source": ((traffic.get("source_4_streams") + "; " if T == 4 and traffic.get("total_4_streams") else "") + traffic["source"]) if traffic else None,
                          "traffic_over_algorithmic": round((traffic.get("total_4_streams") if T == 4 and traffic.get("total_4_streams") else traffic["total"]) / per_gpu_bytes, 3) if traffic else None,
@@ -482,6 +626,10 @@ def main():
                              "frac_of_valu_peak": round(sum(traffic["valu_per_kernel"].values()) * 4 / (1024 * 2.4e9) * 1e3 / ms_per_step, 4),
                              "per_kernel": traffic["valu_per_kernel"], "source": traffic.get("valu_source"),
                              "note": "256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz"},
+                         # the secondary bound is instruction issue -- candidate positions the windows of one step
+                         # cover (every one is decided: evaluated or excluded by a bound) per second of the job's clock
+                         "evaluations_per_s": round(tm["candidates"] * world / (ms_per_step * 1e-3), 1) if wl != "files" else None,
+                         "evaluations_per_sample": round(tm["candidates"] / max(1, (trace.numel() if trace is not None else n)), 3),
                          "sequence_ms": round(seq_ms, 4),
                          "single_stream": None if single is None else {
                              "ms_per_step": round(single[0], 4), "sequence_ms": round(single[1], 4),

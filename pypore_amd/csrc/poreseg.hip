@@ -94,6 +94,7 @@ struct ps_ctx {
     int tree_mw = 0;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list (round 3: single-wave workgroups are faster at four waves per SIMD and need no spills)
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
+    int groups = 1;           // 1: K0 writes group records and the window scans start with the coarse pass over them (narrow digest), 0: every row is swept
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     int wide_bs = 1;          // 1: counts too wide for the 32-bit digest are retried on the 64-bit digest, 0: straight to the LDS-window scan
     int bridge_single = 1 << 30;   // anchors a single-wave bridge adds before it hands the seam to the look-ahead kernel (measured: handing over early is slower)
@@ -116,7 +117,7 @@ struct ps_ctx {
         std::vector<int64_t> ev_start, ev_len;
         size_t nj = 0, jb = 0, up_bytes = 0; int64_t list_entries = 0, total_len = 0, sample_end = 0, nb_total = 0;
     } tile_cache;
-    DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, filt_fwd, filt_agg, filt_zin, up_dev;
+    DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, grp, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
@@ -181,7 +182,7 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->mode = ctx->mode;
     c->prune = ctx->prune;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
-    c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr; c->bs_wide = 0;
+    c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr; c->grp = nullptr; c->bs_wide = 0;
     c->dbg = ctx->small.as<SmallLayout>()->stamp;
     c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
@@ -685,6 +686,10 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
         HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_pad) * (wide ? sizeof(int4) : sizeof(uint2))));
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
         HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(nb_pad / BS_CHUNK + 1) * (wide ? 2 : 1) * sizeof(int4)));
+        if (!wide && ctx->groups) {                    // group records of the coarse pass (16 B per 32 blocks; +1: the end boundary's)
+            HIP_TRY(ctx, ctx->grp.reserve(static_cast<size_t>(nb_pad / BS_GRP + 1) * sizeof(uint4)));
+            cfg.grp = ctx->grp.p;
+        }
         if (d_stats && !wide) {                        // per-block min/max for the statistics kernel (4 B per block; int16 pairs)
             HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_pad) * sizeof(int)));
             cfg.blk_mm = ctx->blk_mm.as<int>();
@@ -692,7 +697,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
 #define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), 0, ctx->stream, cfg,            \
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
-                                    reinterpret_cast<unsigned *>(&sm->status))
+                                    reinterpret_cast<unsigned *>(&sm->status), const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp)))
         if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
         else      { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
 #undef PS_K0
@@ -814,6 +819,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_GROUPS")) ctx->groups = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
@@ -840,7 +846,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->first_item, &ctx->ev_off, &ctx->bounds_off, &ctx->small, &ctx->bridges, &ctx->bmeta,
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
-                      &ctx->ev_boff, &ctx->blk_mm, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
+                      &ctx->ev_boff, &ctx->blk_mm, &ctx->grp, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
                       &ctx->align_in, &ctx->align_scratch};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
@@ -867,6 +873,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "stitch_host") ctx->stitch_host = value != 0;
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
+    else if (n == "groups") ctx->groups = value != 0;
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
     else if (n == "tree_tail_pct" && value >= 0 && value <= 100) ctx->tree_tail_pct = static_cast<int>(value);

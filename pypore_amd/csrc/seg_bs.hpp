@@ -140,6 +140,58 @@ __device__ __forceinline__ DevCfg bs_cold_cfg(const BsCold &k)
     return c;
 }
 
+// ---- groups (round 4): the coarse level of the window scan -----------------------------------------------------
+// A group is 32 consecutive blocks (256 samples, aligned in the global block index): the eight lanes of K0 that hold four
+// consecutive blocks each.  K0 leaves one 16-byte record per group: the digest entry of the group's first block (the
+// exact sums at the group's left boundary) and two amplitudes (D1, D2) as fp32, rounded up:
+//     D1 >= max_j | sum_{i<j} (y_i - mu_g) |,     D2 >= max_j | sum_{i<j} ((y_i - mu_g)^2 - v_g) |       (0 <= j <= 256)
+// -- how far the prefix sums of the group's centred samples and of their squares stray from their chords (mu_g, v_g:
+// the group's mean and variance).  Both are formed exactly at the 31 interior block boundaries from the block sums; inside
+// a block a centred partial sum of j of 8 values moves by at most 2 (max - min), so
+//     D1 = max over block boundaries + 2 (ymax_g - ymin_g),   D2 = max over block boundaries + 2 max|y - mu_g|^2.
+// The gain of a candidate is a convex function of the left part's (k, S1, S2) (seg_bs.hpp: bs_group_slack), so these two
+// numbers bound the gain of all 255 candidates inside the group from the evaluations of its two boundaries.
+constexpr int BS_GRP_LOG = 5;                            // blocks per group: 32
+constexpr int BS_GRP = 1 << BS_GRP_LOG;
+constexpr int BS_GRP_SAMPLES = 8 * BS_GRP;
+// sum / max / min over the eight lanes 8 j .. 8 j + 7, in all of them (quad_perm xor 1, xor 2, row_half_mirror)
+#define PS_OCT_STEPS(X) X(0xB1) X(0x4E) X(0x141)
+__device__ __forceinline__ int oct_allsum(int x)
+{
+#define PS_STEP(CTRL) { x += dpp_mov<CTRL, 0xf>(0, x); }
+    PS_OCT_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+__device__ __forceinline__ int oct_allmax(int x)
+{
+#define PS_STEP(CTRL) { x = max(x, dpp_mov<CTRL, 0xf>(x, x)); }
+    PS_OCT_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+__device__ __forceinline__ int oct_allmin(int x)
+{
+#define PS_STEP(CTRL) { x = min(x, dpp_mov<CTRL, 0xf>(x, x)); }
+    PS_OCT_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+__device__ __forceinline__ float oct_allmaxf(float x)
+{
+#define PS_STEP(CTRL) { x = fmaxf(x, dpp_movf<CTRL, 0xf>(x, x)); }
+    PS_OCT_STEPS(PS_STEP)
+#undef PS_STEP
+    return x;
+}
+// value of the first lane of this lane's group of eight (quad broadcast, then row_shr:4 for the upper quad)
+__device__ __forceinline__ int oct_first(int x, int lane)
+{
+    const int q = dpp_mov<0x00, 0xf>(x, x);
+    const int s = dpp_mov<0x114, 0xf>(q, q);
+    return (lane & 4) ? s : q;
+}
+
 // ---- K0 -----------------------------------------------------------------------------------------------
 // Event e owns the blocks [ev_boff[e], ev_boff[e+1]) of the global block index gb (events back to back in block units;
 // a last partial block is padded with k = m).  A wave takes 256 consecutive blocks = two chunks:
@@ -284,7 +336,7 @@ __device__ __attribute__((noinline)) K0Gen<DT> k0_block_general(BsCold k, const 
 template <int DT>
 __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len,
                                                                 const int64_t *ev_boff, int n_ev, int64_t n_samples, void *bs_out,
-                                                                int4 *ev_info, int4 *chunk_tot, unsigned *status)
+                                                                int4 *ev_info, int4 *chunk_tot, unsigned *status, uint4 *grp_out)
 {
     constexpr bool WIDE = bs_wide<DT>();
     constexpr int LIM = WIDE ? BSW_LIM : BS_WIDE;
@@ -415,6 +467,42 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
         bs[0] = make_uint4(ent[0].x, ent[0].y, ent[1].x, ent[1].y);
         bs[1] = make_uint4(ent[2].x, ent[2].y, ent[3].x, ent[3].y);
         if (c.blk_mm) *reinterpret_cast<int4 *>(c.blk_mm + gb4) = make_int4(t[0].z, t[1].z, t[2].z, t[3].z);
+        if (grp_out) {
+            // group record: the eight lanes 8 g .. 8 g + 7 hold the group's 32 blocks.  Totals by an all-reduce, the prefix
+            // at the group's first block from its first lane; then every lane looks at the boundaries behind its four blocks:
+            //     32 d1 = 32 P1 - jb S1g                          (int32: |P1| < 2^22)
+            //     d2z   = P2 - jb S2g / 32 - S1g d1 / 128         (fp64: exact integers / 4096 below 2^50)
+            // (P1, P2: sums of the group's first jb blocks).  The last boundary of the group gives 0 by itself.
+            const int S1g = oct_allsum(r1);
+            const int S2lo = oct_allsum(r2lo), S2hi = oct_allsum(r2hi);                          // < 2^19, < 2^20
+            const double S2g = static_cast<double>(S2hi) * 65536.0 + static_cast<double>(S2lo);
+            const int xlo = ilo - r2lo, xhi = ihi - r2hi;
+            int p1 = x1 - oct_first(x1, lane);
+            double p2 = static_cast<double>(xhi - oct_first(xhi, lane)) * 65536.0 + static_cast<double>(xlo - oct_first(xlo, lane));
+            const double S1gd = static_cast<double>(S1g);
+            const double k2 = S2g * (-1.0 / 32.0), k1 = S1gd * (-1.0 / 4096.0);
+            const int jb0 = K0_BPT * (lane & 7);
+            int m1 = 0;
+            double m2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < K0_BPT; ++j) {
+                p1 += t[j].x;
+                p2 += static_cast<double>(static_cast<unsigned>(t[j].y));
+                const int jb = jb0 + j + 1;
+                const int d1x = 32 * p1 - jb * S1g;
+                const double d2 = fma(k1, static_cast<double>(d1x), fma(static_cast<double>(jb), k2, p2));
+                m1 = max(m1, d1x < 0 ? -d1x : d1x);
+                m2 = fmax(m2, fabs(d2));
+            }
+            const int gmn = oct_allmin(mmn), gmx = oct_allmax(mmx);
+            m1 = oct_allmax(m1);
+            const float m2f = oct_allmaxf(static_cast<float>(m2) * 1.000001f);
+            const float mug = static_cast<float>(S1g) * (1.0f / static_cast<float>(BS_GRP_SAMPLES));
+            const float Mg = fmaxf(static_cast<float>(gmx) - mug, mug - static_cast<float>(gmn)) * 1.000001f + 0.01f;
+            const float D1 = (static_cast<float>(m1) * (1.0f / 32.0f) + 2.0f * static_cast<float>(gmx - gmn)) * 1.000001f;
+            const float D2 = fmaf(2.0f * Mg, Mg, m2f) * 1.000001f;
+            if ((lane & 7) == 0) grp_out[gb4 >> BS_GRP_LOG] = make_uint4(ent[0].x, ent[0].y, __float_as_uint(D1), __float_as_uint(D2));
+        }
         yabs = half_max_i32(yabs);
         if ((lane & 31) == 31) {
             const unsigned long long tot2 = (static_cast<unsigned long long>(static_cast<unsigned>(ihi)) << 16) + static_cast<unsigned>(ilo);
@@ -491,6 +579,38 @@ __device__ __forceinline__ float bs_block_bound2(const BsEval &ep, const BsEval 
     const float hb = fmaxf(fmaf(npf, e1, Pp), fmaf(qf, e2, Pq)) + 1.0e-3f;
     const bool sound = static_cast<bool>(static_cast<int>(ep.okL) & static_cast<int>(ep.okR) & static_cast<int>(eq.okL) & static_cast<int>(eq.okR));
     return sound ? hb : INFINITY;
+}
+
+// What the gain can rise by, inside a group next to the boundary evaluated as `e`, over the gain on the chord between the
+// group's two boundaries (log2 units; +inf when the expansion does not apply).  Derivation (DESIGN.md 4.4,
+// tools/experiments/group_bound.py): the gain is a convex function of the left part's (k, S1, S2) -- k phi(S1/k, S2/k) with
+// phi(a, b) = log(b - a^2) is the perspective of a concave function --, the prefix path of the group lies in the
+// parallelepiped  chord(k) + (0, d1, d2z + 2 mu_g d1),  |d1| <= D1, |d2z| <= D2  (the amplitudes K0 left in the group
+// record), so the gain on the path is at most the largest gain at the vertices: k at one of the two boundaries, (d1, d2z) at
+// the corners of the box.  At a boundary the displacement changes the sums of squared deviations by
+//     dSS_L = d2z + 2 wL d1 - d1^2 / k,        dSS_R = -d2z - 2 wR d1 - d1^2 / (n-k),      wL = mu_g - mu_L,  wR = mu_g - mu_R,
+// and with log(1 + t) >= t - 0.54 t^2 for |t| <= 0.09 the cost k log(SS_L/k) + (n-k) log(SS_R/(n-k)) falls by at most
+//     D2 |1/V_L - 1/V_R| + 2 D1 |wL/V_L - wR/V_R| + D1^2 (1/SS_L + 1/SS_R) + 0.54 (k tL^2 + (n-k) tR^2),
+//     tL = (D2 + 2 |wL| D1 + D1^2 / k) / SS_L,  tR alike.
+// The first-order terms keep the cancellation between the two sides (on noise 1/V_L - 1/V_R is ~ sqrt(2/k) / sigma^2).
+// wa, wb: mu_g - mu_L for the two neighbouring groups (the same value twice at the ends); dmu = mu_L - mu_R, so that
+// wR = wL + dmu and wL/V_L - wR/V_R = wL (1/V_L - 1/V_R) - dmu / V_R.  All inputs carry relative errors of a few 2^-24
+// (exact fp64 numerators), the result is inflated by 1e-4 + 1e-3.
+__device__ __forceinline__ float bs_group_slack(const BsEval &e, float D1, float D2, float wa, float wb, float dmu)
+{
+    const float LOG2E = 1.4426950408889634f;
+    const float iVL = __builtin_amdgcn_rcpf(e.u.x), iVR = __builtin_amdgcn_rcpf(e.u.y);
+    const float gS = iVL - iVR, dV = dmu * iVR;
+    const float c1 = fmaxf(fabsf(fmaf(wa, gS, -dV)), fabsf(fmaf(wb, gS, -dV)));
+    const float wL = fmaxf(fabsf(wa), fabsf(wb)), wR = fmaxf(fabsf(wa + dmu), fabsf(wb + dmu));
+    const float D11 = D1 * D1;
+    const float iSL = iVL * e.r.x, iSR = iVR * e.r.y;                        // 1 / SS_L, 1 / SS_R
+    const float first = fmaf(D2, fabsf(gS), fmaf(2.0f * D1, c1, D11 * (iSL + iSR)));
+    const float EL = fmaf(2.0f * wL, D1, fmaf(D11, e.r.x, D2)), ER = fmaf(2.0f * wR, D1, fmaf(D11, e.r.y, D2));
+    const float tL = EL * iSL, tR = ER * iSR;
+    const float second = 0.54f * fmaf(EL * iVL, tL, ER * iVR * tR);         // k tL^2 = EL^2 / (k V_L^2)
+    const float A = fmaf((LOG2E * 1.0001f), first + second, 1.0e-3f);
+    return (tL <= 0.09f && tR <= 0.09f) ? A : INFINITY;                     // (NaN compares false: +inf)
 }
 
 struct BsQ { int j, a1; double a2; };                     // queued block (J-8, J): its end J, sums of [ps, J)
@@ -733,10 +853,25 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     // pass (no gather of 64 scattered entries, ~100 instructions less) and RAISE the level from the gains seen so far
     // whenever the queue has to be drained early (below) -- without that the few windows that do hold a split queue
     // hundreds of blocks (measured: subtree kernel 0.175 -> 0.21 ms).
-    constexpr bool SAMPLE = ROWSKIP || WIDE || PS_TREE_SAMPLE;      // (wide digest: filtered events, whose subtree windows mostly DO hold splits)
+    // Round 4, narrow digest: the sampling pass is replaced by the COARSE PASS over the group records (below), which
+    // every instance runs -- it reads 16 contiguous bytes per 256 samples instead of 64 scattered digest entries, gives
+    // the same kind of pruning level, and decides for whole groups of 32 blocks whether the sweep has to look at them.
+    constexpr bool GROUPS = !WIDE;
+    constexpr bool SAMPLE = WIDE && (ROWSKIP || WIDE || PS_TREE_SAMPLE);      // (wide digest: filtered events, whose subtree windows mostly DO hold splits)
     const int tS = SAMPLE ? min(nblk, lane * rows) : 0;
     ent_t smp = e0;
     if constexpr (SAMPLE) smp = bsw[tS];
+    // group records: lane L takes the group boundary c = L, block boundary tC = 32 (G0 + L) - gb0 of the window -- the
+    // record of group G0 + L holds the exact sums at that boundary and the amplitudes of the group to its RIGHT
+    const long long G0 = (gb0 + BS_GRP - 1) >> BS_GRP_LOG;
+    const bool coarse = GROUPS && c.grp != nullptr && c.prune && rows <= 64;                   // (uniform)
+    const int ngc = coarse ? min(static_cast<int>(((gb0 + nblk) >> BS_GRP_LOG) - G0), 63) : 0;  // groups entirely inside the window (<= 0: none)
+    uint4 gent = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (GROUPS) {
+        // (unconditional load from a clamped index, like the rest of the setup: see above)
+        const uint4 *gp = coarse ? static_cast<const uint4 *>(c.grp) + G0 : reinterpret_cast<const uint4 *>(bsw);
+        gent = gp[coarse ? min(lane, max(ngc, 0)) : 0];
+    }
     ent_t ring[BS_D];                                  // rows in flight
 #pragma unroll
     for (int i = 0; i < BS_D; ++i) ring[i] = row_load(i);
@@ -876,6 +1011,57 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             }
         }
     }
+    // ---- coarse pass (narrow digest) ---------------------------------------------------------------------------------
+    // Lane L evaluates group boundary L (its exact sums: the record's entry plus the chunk offset) like any boundary of
+    // the sweep; the largest of those gains sets the pruning level, as the sampled boundaries used to.  Then every group
+    // (L-1, L) is bounded: gain(k) <= max(G(L-1) + A(L-1), G(L) + A(L)) for all of its 255 interior candidates, where
+    // A = bs_group_slack is what the group's prefix path can gain over its chord (one A per boundary, from the larger
+    // amplitudes and the worse mean of its two neighbours).  Rows of the sweep whose blocks all lie in groups below the
+    // pruning level are not swept -- nor loaded.  Blocks outside the groups (the window's two ends) are always swept.
+    float ghb = INFINITY;                              // bound of group (lane - 1, lane), lanes 1 .. ngc
+    if constexpr (GROUPS) {
+        if (ngc >= 1) {
+            const int tC = static_cast<int>((G0 << BS_GRP_LOG) - gb0) + BS_GRP * lane;
+            const bool cin = lane <= ngc;
+            const int nlc = cin ? nh + 8 * tC : 1;                          // samples left of the boundary (clamped lanes: any valid value)
+            const int cb = min((gbl + (cin ? tC : 0)) >> BS_CHUNK_LOG, nch - 1) << 2;
+            const uint2 gentry = make_uint2(gent.x, gent.y);
+            const s1_t a1 = bs_a1(gentry, static_cast<s1_t>(bs_from_lane(off1, cb)));
+            const s2_t a2 = bs_a2(gentry, static_cast<o2_t>(bs_from_lane(off2, cb)));
+            const bool bval = cin && nlc >= 1 && nlc <= n - 1;
+            const int nlv = bval ? nlc : 1;
+            const double a1d = bs_d(a1), nld = static_cast<double>(nlv);
+            const BsEval e = bs_eval(a1d, bs_d(a2), T1d - a1d, T2d - bs_d(a2), nlv, n - nlv, cc, vfloor);
+            const bool inr = bval && static_cast<unsigned>(ps + nlc - cand_lo) <= crange;
+            const bool eok = bval && e.okL && e.okR;
+            float bm = (inr && eok) ? e.g : -INFINITY;
+#define PS_STEP(CTRL, RM) { bm = fmaxf(bm, dpp_movf<CTRL, RM>(-INFINITY, bm)); }
+            PS_DPP_STEPS(PS_STEP)
+#undef PS_STEP
+            bm = __int_as_float(lane_get(__float_as_int(bm), 63));
+            Tprune = fmaxf(thr_log2 - dthr, bm - 2.0f * dlt) - 2.0f * dlt;
+            // the two neighbours of this boundary: group (L-1, L) -- amplitudes in the record of the lane below -- and (L, L+1)
+            const bool hasL = lane >= 1, hasR = lane < ngc;
+            const float D1r = __uint_as_float(gent.z), D2r = __uint_as_float(gent.w);
+            const float D1l = from_lane_below(D1r), D2l = from_lane_below(D2r);
+            const float D1 = fmaxf(hasL ? D1l : 0.0f, hasR ? D1r : 0.0f), D2 = fmaxf(hasL ? D2l : 0.0f, hasR ? D2r : 0.0f);
+            // mean of a neighbour minus the mean of the left part, well conditioned: (k S1g / 256 - a1) / k with an exact numerator
+            const int a1i = static_cast<int>(a1);
+            const int sgl = a1i - from_lane_below(a1i), sgr = from_lane_above(a1i) - a1i;          // S1 of the two groups
+            const double ig = 1.0 / static_cast<double>(BS_GRP_SAMPLES);
+            const float wLl = static_cast<float>(fma(nld, static_cast<double>(sgl) * ig, -a1d)) * e.r.x;
+            const float wLr = static_cast<float>(fma(nld, static_cast<double>(sgr) * ig, -a1d)) * e.r.x;
+            const float dmu = static_cast<float>(fma(dn, a1d, -(nld * T1d))) * e.r.x * e.r.y;   // mean left - mean right
+            const float A = bs_group_slack(e, D1, D2, hasL ? wLl : wLr, hasR ? wLr : wLl, dmu);
+            // (interior candidates have a variance of at least u P / Q on the left, u (n-Q) / (n-P) on the right: none below the floor)
+            const float nlf = static_cast<float>(nlv), nrf = nf - nlf;
+            const bool okF = e.u.x * nlf >= vfloor * (nlf + static_cast<float>(BS_GRP_SAMPLES)) &&
+                             e.u.y * nrf >= vfloor * (nrf + static_cast<float>(BS_GRP_SAMPLES));
+            const float GA = (eok && okF) ? e.g + A : INFINITY;             // (A itself is +inf when the expansion does not apply)
+            ghb = fmaxf(GA, from_lane_below(GA));
+            hitlike = true;
+        }
+    }
     PS_STAMP_AT(wk, 0);                                // totals, pruning level from the sampled boundaries
 #ifdef PS_STAMP
     wk.ph[11] += hitlike;
@@ -905,7 +1091,17 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         // lanes' samples; it is skipped when all of them are dead at this phase's pruning level).  Lane r works that out
         // for row r, a ballot makes the mask.  Windows that are not hit-like sweep rows 0 .. rows-1.
         unsigned long long live = ~0ull;
-        if (hitlike) {
+        if constexpr (GROUPS) {
+            if (hitlike) {
+                // row r holds the blocks 63 r + 1 .. min(63 r + 63, nblk) (block t lies left of boundary t); the group of a block
+                // is the group of its left boundary; bit L of `dead`: group (L-1, L) is below the pruning level
+                const unsigned long long dead = __ballot(lane >= 1 && lane <= ngc && ghb < Tprune);
+                const int tl = BS_STRIDE * lane, th = min(tl + BS_STRIDE, nblk) - 1;
+                const int lo = static_cast<int>(((gb0 + tl) >> BS_GRP_LOG) - G0) + 1, hi = static_cast<int>(((gb0 + th) >> BS_GRP_LOG) - G0) + 1;
+                const unsigned long long span = ((2ull << (hi - lo)) - 1ull) << max(lo, 0);
+                live = __ballot(lane < rows && !(lo >= 1 && hi <= ngc && (dead & span) == span));
+            }
+        } else if (hitlike) {
             const unsigned long long dead = __ballot(cbound < Tprune);
             const float rr_ = 1.0f / static_cast<float>(rows);
             const int lo = static_cast<int>((static_cast<float>(BS_STRIDE * lane) + 0.5f) * rr_);          // exact for these small integers

@@ -57,6 +57,8 @@ struct DevCfg {
     const int4 *ev_info;    // per event: (m, -, block offset lo, block offset hi)
     const int4 *chunk_tot;  // per chunk of 128 blocks: (S1, max |k-m|, S2 as int64); wide digest: two entries (S1, S2 as int64), (max |k-m|, -, -, -)
     int *blk_mm;            // per block: min / max of k-m as two int16 (written by K0 when statistics are wanted) or nullptr
+    const void *grp;        // per group of 32 blocks (256 samples; narrow digest): the digest entry of its first block + (D1, D2) as fp32,
+                            // the bridge amplitudes of the group bound (seg_bs.hpp); nullptr: no coarse pass
     int bs_wide;            // (host side) the digest is the 64-bit one: kernels compiled for DT | DT_WIDE
     unsigned long long *dbg;  // diagnostics scratch (12 words) or nullptr
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)

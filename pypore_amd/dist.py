@@ -154,7 +154,11 @@ def stitch_pieces(pieces, n, window_width, min_width, repair=None, halo=None):
     (a, N, data) (cparsers.pyx:180-203), so the chain is re-run from the last trusted upstream anchor a0 over
     [a0, next piece start + 2 halo), `repair(r, lo, hi) -> (bounds_local, is_spine)` segmenting [lo, hi) as a stand-alone
     trace on behalf of upstream piece r; the extension doubles until it shares an anchor with a downstream piece (pieces
-    it covers entirely are dropped) or reaches the end of the trace.  Without `repair` such a seam raises RuntimeError."""
+    it covers entirely are dropped) or reaches the end of the trace.  Without `repair` such a seam raises RuntimeError.
+    CONTRACT of `repair`: [lo, hi) may reach far beyond piece r's own shard plus halo (up to the end of the trace), and the
+    result is taken to cover all of it.  A callback that may come up short returns a third value, the number of samples it
+    really segmented: the repaired piece then ends there (its last anchors are not trusted), and RuntimeError is raised if
+    that does not get past the old end -- a silently truncated piece would otherwise give wrong boundaries without an error."""
     if halo is None:
         halo = 8 * window_width
     out = []
@@ -203,7 +207,18 @@ def stitch_pieces(pieces, n, window_width, min_width, repair=None, halo=None):
         new_hi = int(min(n, max(hi, nlo) + ext))
         out.append(g[(g > enter) & (g <= a0)])
         enter = max(enter, a0)
-        rb, rf = repair(r, a0, new_hi)
+        res = repair(r, a0, new_hi)
+        rb, rf = res[0], res[1]
+        if len(res) > 2 and res[2] is not None:
+            # the segmenter says how many samples it really had (a callback that can only reach part of the stretch, e.g.
+            # one that slices a local buffer): the piece ends THERE -- anchors next to that end are not trusted -- and a
+            # stretch that does not get past the old end cannot repair anything
+            got_hi = a0 + int(res[2])
+            if got_hi > new_hi or (got_hi < new_hi and got_hi <= max(hi, nlo)):
+                raise RuntimeError("sharded trace: the repair of the seam between pieces %d and %d asked for [%d, %d) and "
+                                   "got %d samples: the upstream segmenter cannot extend (it must serve any range inside "
+                                   "[0, n))" % (r, nxt, a0, new_hi, int(res[2])))
+            new_hi = got_hi
         cur = (a0, new_hi, np.asarray(rb, dtype=np.int64) + a0, np.asarray(rf, dtype=bool))
         repairs += 1
     stitch_pieces.last_repairs = repairs
@@ -216,8 +231,11 @@ stitch_pieces.last_repairs = 0
 def segment_trace_sharded(n, segment_piece_fn, window_width, min_width, halo=None, device=None, group=None):
     """Segments ONE trace of n samples across the ranks of `group`.
 
-    segment_piece_fn(lo, hi) -> (bounds_local int32, is_spine uint8): the local segmenter applied to
-    samples [lo, hi) as a stand-alone trace (ps_segment_batch_ex with d_is_spine on this rank's GPU).
+    segment_piece_fn(lo, hi) -> (bounds_local int32, is_spine uint8[, n_segmented]): the local segmenter applied to
+    samples [lo, hi) as a stand-alone trace (ps_segment_batch_ex with d_is_spine on this rank's GPU).  It is called once
+    with this rank's shard plus halo and, when a seam needs repair, with stretches that may lie ANYWHERE inside [0, n) --
+    far beyond the shard: it must be able to produce any range (regenerate, re-read from the file), or return as a third
+    value how many samples of [lo, hi) it really segmented (stitch_pieces then ends the piece there or raises).
     Every rank returns the full global breakpoint array.  Collectives: the boundary gather, and for every seam that
     finds no common anchor inside the halo one more gather of the stretch the UPSTREAM rank re-segments (all ranks
     walk the same gathered data, so they agree on which seam failed without an extra round)."""
@@ -227,7 +245,7 @@ def segment_trace_sharded(n, segment_piece_fn, window_width, min_width, halo=Non
         halo = 8 * window_width
     ranges = shard_ranges(n, world, halo)
     lo, hi = ranges[rank]
-    b, f = segment_piece_fn(lo, hi)
+    b, f = segment_piece_fn(lo, hi)[:2]
     dev = device if device is not None else torch.device("cpu")
 
     def gather2(bb, ff):
@@ -241,10 +259,13 @@ def segment_trace_sharded(n, segment_piece_fn, window_width, min_width, halo=Non
     def repair(r_up, lo2, hi2):
         # the upstream rank re-segments [lo2, hi2); everybody takes part in the gather of that one stretch
         if rank == r_up:
-            rb, rf = segment_piece_fn(lo2, hi2)
+            res = segment_piece_fn(lo2, hi2)
+            rb, rf = res[0], res[1]
+            ln = np.array([res[2] if len(res) > 2 and res[2] is not None else hi2 - lo2], dtype=np.int64)
         else:
-            rb, rf = np.zeros(0, np.int32), np.zeros(0, np.uint8)
+            rb, rf, ln = np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros(0, np.int64)
         gb, gf = gather2(rb, rf)
-        return gb[r_up].cpu().numpy(), gf[r_up].cpu().numpy()
+        gl = gather_varlen(torch.from_numpy(ln).to(dev), group)
+        return gb[r_up].cpu().numpy(), gf[r_up].cpu().numpy(), int(gl[r_up][0])
 
     return stitch_pieces(pieces, n, window_width, min_width, repair=repair, halo=halo)

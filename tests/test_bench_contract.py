@@ -26,6 +26,48 @@ def test_hardware_queues_are_requested_before_torch_is_imported():
     assert env < first_torch
 
 
+def test_gpus_n_starts_by_itself_and_relays_rank0_line():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment becomes the launcher of two ranks (children under
+    torch.distributed.run, 127.0.0.1) before anything touches a GPU; --selftest-dist makes the ranks run only the N > 1
+    plumbing of bench.py -- JobGather, the sharded-trace join + repair gather, the files gather, the max-over-ranks clock
+    -- on CPU tensors over gloo.  One JSON line comes back on stdout, the exit code is the children's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-dist"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["ok"] is True and d["ranks_seen"] == 2 and all(d["checks"].values()), d
+
+
+def test_self_launch_command_line(monkeypatch):
+    """the launcher's command: one node, N processes, rendezvous on 127.0.0.1, this file with the caller's arguments; no exec"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    rc = bench.self_launch(["--gpus", "4", "--steps", "3"], 4)
+    cmd = seen["cmd"]
+    assert rc == 7
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [BENCH, "--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["GPU_MAX_HW_QUEUES"] == os.environ.get("GPU_MAX_HW_QUEUES", "8")
+    src = open(BENCH).read()
+    assert "os.exec" not in src and "execv" not in src.replace("no exec", "")
+
+
 @pytest.mark.gpu
 def test_short_run_prints_the_contract_line():
     out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu", "--no-h2d"],
@@ -41,8 +83,9 @@ def test_short_run_prints_the_contract_line():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_run", "evaluations_per_s"):
         assert key in r, key
+    assert d["config"]["ranks_seen"] == 1 and len(d["config"]["ms_per_step_per_rank"]) == 1
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
     assert d["value"] == pytest.approx(1e8 / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)

@@ -173,6 +173,40 @@ def test_sharded_trace_seam_repair_equals_whole_trace(case, world, halo):
     assert all(hi - lo < n for _, lo, hi in calls[:1]) or world == 2     # a repair re-runs a stretch, not the trace
 
 
+def test_sharded_trace_repair_that_comes_up_short():
+    """a repair callback that can only reach part of the stretch it is asked for (it slices a local buffer)
+    must not give silently wrong boundaries: reporting the length it really segmented either ends the piece there -- and
+    the result is still the whole-trace result -- or, when that does not get past the old end, raises."""
+    import oracle
+    from pypore_amd.dist import shard_ranges, stitch_pieces
+    x = _long_dwell_trace(6_000_000, 64)
+    n = x.size
+    ref = oracle.parse(x, prior_segments_per_second=10.)
+    ranges = shard_ranges(n, 8, 80000)
+    pieces = []
+    for lo, hi in ranges:
+        b, f = oracle.parse_flags(x[lo:hi], prior_segments_per_second=10.)
+        pieces.append((lo, hi, b, f))
+    short = []
+
+    def repair_capped(r, lo, hi):                # reaches at most 1.2e6 samples past the start of the stretch
+        hi2 = min(hi, lo + 1_200_000)
+        short.append(hi2 < hi)
+        b, f = oracle.parse_flags(x[lo:hi2], prior_segments_per_second=10.)
+        return b, f, hi2 - lo
+
+    got = stitch_pieces(pieces, n, 10000, 100, repair=repair_capped, halo=80000)
+    np.testing.assert_array_equal(got, ref)
+
+    def repair_local_only(r, lo, hi):            # the old contract: only the rank's own shard + halo
+        hi2 = min(hi, ranges[r][1])
+        b, f = oracle.parse_flags(x[lo:hi2], prior_segments_per_second=10.)
+        return b, f, hi2 - lo
+
+    with pytest.raises(RuntimeError, match="cannot extend"):
+        stitch_pieces(pieces, n, 10000, 100, repair=repair_local_only, halo=80000)
+
+
 def _worker_trace(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
