@@ -94,10 +94,13 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * tiles + seam repairs, otherwise only the fallback); "timing" 0/1/2 (see ps_get_timings); "upload_by_kernel" 1
  * (default) the call's host tables are fetched by a kernel reading the pinned blob, 0 hipMemcpyAsync; "filter_fused" 1
  * (default) fast filters run both directions in one kernel over tiles with halos, 0 always the exact three-pass
- * scan; "tree_mw" 1 (default) subtree jobs of the block-sum
- * scan run on 8-wave workgroups whose waves share the workgroup's job list, 0 single-wave workgroups;
- * "spine_nt" 256/512/1024, "tree_nt" 256/512 workgroup sizes of the LDS-window kernels.  Unknown names
- * return PS_ERR_ARG. */
+ * scan; "tree_mw" 0 (default) subtree jobs of the block-sum scan run on single-wave workgroups, one per wave slot,
+ * striding over the job list, 1 two-wave workgroups whose waves share the workgroup's job list through an LDS counter
+ * (round 2's default; slower at four waves per SIMD); "groups" 1 (default) K0 writes one record per 256 samples and
+ * every window scan starts with the coarse pass over them (whole groups of 32 blocks are bounded, rows of the sweep
+ * that lie in pruned groups are skipped), 0 every row is swept; "wide_bs" 1 (default) counts too wide for the 32-bit
+ * digest are retried on the 64-bit one, 0 straight to the LDS-window scan; "spine_nt" 256/512/1024, "tree_nt" 256/512
+ * workgroup sizes of the LDS-window kernels.  Unknown names return PS_ERR_ARG. */
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);
 /* Blocks until all work submitted on the context's stream has finished. */
 int ps_synchronize(ps_ctx *ctx);

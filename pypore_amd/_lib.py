@@ -73,6 +73,7 @@ def lib():
     L.ps_filter_bessel.argtypes = [vp, vp, P(SampleFormat), i64, i32, dbl, dbl, vp]
     L.ps_requantise.argtypes = [vp, vp, i64, vp, P(dbl), P(dbl)]
     L.ps_align_batch.argtypes = [vp, P(dbl), P(dbl), P(dbl), i32, dbl, dbl, vp, vp, vp, P(i64), i32, vp, vp, vp]
+    L.ps_audit_bounds.argtypes = [vp, vp, P(SampleFormat), i64, P(SplitParams), P(i32), i32, P(dbl)]
     _lib = L
     return L
 

@@ -1233,6 +1233,83 @@ int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *
 }
 
 
+// Diagnostic (tests/test_bound_audit.py): the pruning bounds of the block-sum window scan against the gains they cover,
+// on the device, with the product's own scan code (scan_window_bs<.., AUDIT>).  K0 on the one event [0, n), then one wave
+// per window.  out[12]: see bs_audit_note (seg_bs.hpp); the three margins are returned as doubles.
+int ps_audit_bounds(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, const ps_split_params *params,
+                    const int32_t *h_windows, int32_t n_win, double *out)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!d_samples || !params || !h_windows || !out || n < 16 || n > 0x7fffffff || n_win < 1) return fail(ctx, PS_ERR_ARG, "bad argument");
+    double mg = 0;
+    int rc = ps_min_gain(params, &mg);
+    if (rc) return fail(ctx, rc, "invalid split parameters");
+    DevCfg cfg;
+    rc = make_cfg(ctx, d_samples, fmt, params->min_width, params->max_width, params->window_width, mg, &cfg);
+    if (rc) return rc;
+    if (params->min_width < 8) return fail(ctx, PS_ERR_ARG, "the block-sum scan needs min_width >= 8");
+    for (int i = 0; i < n_win; ++i)
+        if (h_windows[2 * i] < 0 || h_windows[2 * i + 1] > n || h_windows[2 * i + 1] - h_windows[2 * i] <= 2 * params->min_width)
+            return fail(ctx, PS_ERR_ARG, "window %d: [%d, %d) is not a window the recursion would scan", i, h_windows[2 * i], h_windows[2 * i + 1]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    cfg.mode = MODE_FAST;
+    const int64_t nb_total = (n + 7) / 8, nb_pad = k0_padded_blocks(nb_total);
+    const int64_t tab[4] = {0, n, 0, nb_total};                            // ev_start | ev_len | ev_boff[0..1]
+    const size_t win_bytes = static_cast<size_t>(n_win) * 2 * sizeof(int32_t);
+    HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_pad) * sizeof(uint2)));
+    HIP_TRY(ctx, ctx->ev_info.reserve(sizeof(int4)));
+    HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(nb_pad / BS_CHUNK + 1) * sizeof(int4)));
+    HIP_TRY(ctx, ctx->grp.reserve(static_cast<size_t>(nb_pad / BS_GRP + 1) * sizeof(uint4)));
+    HIP_TRY(ctx, ctx->up_dev.reserve(sizeof(tab) + 128 + win_bytes));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    char *d = ctx->up_dev.as<char>();
+    unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0x7fffffffull, 0x7fffffffull, 0x7fffffffull, 0, 0, 0};
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d, tab, sizeof(tab), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + 32, acc, sizeof(acc), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + 128, h_windows, win_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                        // (the host arrays are the caller's / the stack's)
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    const int64_t *dt = reinterpret_cast<const int64_t *>(d);
+    cfg.grp = ctx->grp.p;
+    const unsigned k0_grid = static_cast<unsigned>((nb_pad / K0_WB + K0_WAVES - 1) / K0_WAVES);
+    const bool f32 = cfg.dtype == PS_DTYPE_F32;
+#define PS_K0A(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), 0, ctx->stream, cfg, dt, dt + 1, dt + 2, 1, n, \
+                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(), reinterpret_cast<unsigned *>(&sm->status), \
+                                     static_cast<uint4 *>(ctx->grp.p))
+    if (f32) PS_K0A(PS_DTYPE_F32); else PS_K0A(PS_DTYPE_I16);
+#undef PS_K0A
+    HIP_TRY(ctx, hipGetLastError());
+    cfg.bsum = ctx->bsum.p;
+    cfg.ev_info = ctx->ev_info.as<int4>();
+    cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
+    cfg.dbg = reinterpret_cast<unsigned long long *>(d + 32);
+    const unsigned g = static_cast<unsigned>(std::min<int32_t>(n_win, 4096));
+    if (f32) hipLaunchKernelGGL((audit_kernel<PS_DTYPE_F32>), dim3(g), dim3(64), 0, ctx->stream, cfg, reinterpret_cast<const int2 *>(d + 128), n_win,
+                                reinterpret_cast<unsigned *>(&sm->status));
+    else     hipLaunchKernelGGL((audit_kernel<PS_DTYPE_I16>), dim3(g), dim3(64), 0, ctx->stream, cfg, reinterpret_cast<const int2 *>(d + 128), n_win,
+                                reinterpret_cast<unsigned *>(&sm->status));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(acc, d + 32, sizeof(acc), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tile_cache.valid = false;                                          // (the tables of the last batch call are gone)
+    const unsigned st = static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status);
+    if (st & ST_WIDE_RANGE) return fail(ctx, PS_ERR_ARG, "counts too wide for the 32-bit digest: nothing to audit");
+    rc = check_status(ctx, st);
+    if (rc) return rc;
+    for (int i = 0; i < 12; ++i) out[i] = static_cast<double>(acc[i]);
+    for (int i = 6; i < 9; ++i) {
+        int k = static_cast<int>(static_cast<unsigned>(acc[i] & 0xffffffffull));
+        if (k == 0x7fffffff) { out[i] = INFINITY; continue; }
+        k ^= (k >> 31) & 0x7fffffff;
+        float f;
+        std::memcpy(&f, &k, sizeof(f));
+        out[i] = static_cast<double>(f);
+    }
+    return PS_OK;
+}
+
 // Replaces lambda_event_parser.parse with the default rules (parsers.py:124-155).
 int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
                      double threshold, int64_t min_duration, double min_current,

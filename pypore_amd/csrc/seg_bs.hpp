@@ -163,23 +163,25 @@ __device__ __forceinline__ int oct_allsum(int x)
 #undef PS_STEP
     return x;
 }
+// (the `old` operand is the operation's identity, as in the wave scans: the compiler then folds the move into the
+//  operation -- v_max_i32_dpp -- instead of copying the register first; every lane has a source in these three controls)
 __device__ __forceinline__ int oct_allmax(int x)
 {
-#define PS_STEP(CTRL) { x = max(x, dpp_mov<CTRL, 0xf>(x, x)); }
+#define PS_STEP(CTRL) { x = max(x, dpp_mov<CTRL, 0xf>(static_cast<int>(0x80000000), x)); }
     PS_OCT_STEPS(PS_STEP)
 #undef PS_STEP
     return x;
 }
 __device__ __forceinline__ int oct_allmin(int x)
 {
-#define PS_STEP(CTRL) { x = min(x, dpp_mov<CTRL, 0xf>(x, x)); }
+#define PS_STEP(CTRL) { x = min(x, dpp_mov<CTRL, 0xf>(0x7fffffff, x)); }
     PS_OCT_STEPS(PS_STEP)
 #undef PS_STEP
     return x;
 }
-__device__ __forceinline__ float oct_allmaxf(float x)
+__device__ __forceinline__ float oct_allmaxf(float x)                       // x >= 0
 {
-#define PS_STEP(CTRL) { x = fmaxf(x, dpp_movf<CTRL, 0xf>(x, x)); }
+#define PS_STEP(CTRL) { x = __uint_as_float(max(__float_as_uint(x), static_cast<unsigned>(dpp_mov<CTRL, 0xf>(0, static_cast<int>(__float_as_uint(x)))))); }
     PS_OCT_STEPS(PS_STEP)
 #undef PS_STEP
     return x;
@@ -187,8 +189,8 @@ __device__ __forceinline__ float oct_allmaxf(float x)
 // value of the first lane of this lane's group of eight (quad broadcast, then row_shr:4 for the upper quad)
 __device__ __forceinline__ int oct_first(int x, int lane)
 {
-    const int q = dpp_mov<0x00, 0xf>(x, x);
-    const int s = dpp_mov<0x114, 0xf>(q, q);
+    const int q = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true);
+    const int s = __builtin_amdgcn_update_dpp(0, q, 0x114, 0xf, 0xf, true);
     return (lane & 4) ? s : q;
 }
 
@@ -671,6 +673,9 @@ __device__ __forceinline__ long long bs_from_lane(long long x, int byte_index)
 __device__ __forceinline__ double bs_from_lane(double x, int byte_index) { return __longlong_as_double(bs_from_lane(__double_as_longlong(x), byte_index)); }
 #define PS_TREE_SAMPLE 0                                  // 1: subtree windows run the sampling pass too (measured: see scan_window_bs)
 #endif
+#ifndef PS_EDGE_PRELOAD
+#define PS_EDGE_PRELOAD 1                                 // windows with a coarse pass request the rows of their two ends with the setup loads
+#endif
 constexpr int BS_EARLY = 64;                              // ... and started early beyond this many (<= BS_QN - 64)
 constexpr int BS_STRIDE = 63;                             // new boundaries per row (lane 0 repeats the previous row's last)
 constexpr int BS_LDS_BYTES = (static_cast<int>(sizeof(BsQ)) + 8) * BS_QN + static_cast<int>(sizeof(BsC)) * BS_NC + 64 * 32;   // (+ 8: the block's own sums)
@@ -789,6 +794,22 @@ __device__ __attribute__((noinline)) long long bs_decide(BsCold k, int m, const 
     return (static_cast<long long>(near) << 32) | static_cast<unsigned>(ei);
 }
 
+// audit record (c.dbg, 12 words): [0] blocks with a corner bound, [1] violations, [2] blocks with a two-boundary bound,
+// [3] violations, [4] groups with a bound, [5] violations, [6..8] smallest margin (bound - largest covered gain) per kind
+// as order-preserving int32, [9] windows.  A violation: a covered candidate's screened gain exceeds the bound by more
+// than `tol` (2 delta: the slack every pruning level carries).
+__device__ __forceinline__ void bs_audit_note(unsigned long long *a, int icnt, int iviol, int imin, float bound, float gmax, float tol)
+{
+    if (!(bound < INFINITY)) return;                   // no bound was claimed
+    atomicAdd(&a[icnt], 1ull);
+    if (gmax == -INFINITY) return;
+    const float margin = bound - gmax;
+    if (!(margin >= -tol)) atomicAdd(&a[iviol], 1ull);
+    int k = __float_as_int(margin);
+    k ^= (k >> 31) & 0x7fffffff;
+    atomicMin(reinterpret_cast<int *>(&a[imin]), k);
+}
+
 // One wave scans the window [ps, pe) of an event (samples at c.samples[base + .], event constants `er`).
 //
 // Setup (one memory round trip): the ragged head / tail samples, the totals of the <= 64 chunks the window touches (one
@@ -804,7 +825,10 @@ __device__ __attribute__((noinline)) long long bs_decide(BsCold k, int m, const 
 // Phase 1 (ambiguous windows only, ~1 %): the same sweep with the final maximum known collects the contenders
 // (screened gain within 3 delta of the decision level) and the reference's fp64 arithmetic picks among them
 // (bs_decide).  A whole-window fp64 scan remains for guard failures and contender overflow.
-template <int DT, bool ROWSKIP = true>
+// AUDIT (diagnostic instance, audit_kernel / ps_audit_bounds only): every row is swept, and every bound the scan forms --
+// the corner bound of a block, the two-boundary bound, the group bound -- is compared with the screened gains of the
+// candidates it covers, evaluated one by one from the raw samples; counts and smallest margins go to c.dbg.
+template <int DT, bool ROWSKIP = true, bool AUDIT = false>
 __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                               double thresh, SharedT<64> &sh, unsigned &bad, Work &wk)
 {
@@ -873,8 +897,13 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         gent = gp[coarse ? min(lane, max(ngc, 0)) : 0];
     }
     ent_t ring[BS_D];                                  // rows in flight
+    // (a window with a coarse pass sweeps its live rows only, and the rows at its two ends practically always are -- the
+    //  first and last groups cannot be bounded: they are requested here, with the rest of the setup, so that the sweep
+    //  does not start with a round trip of its own; the other windows start with rows 0 .. 3)
+    const bool edge_rows = PS_EDGE_PRELOAD && GROUPS && ngc >= 1;         // (uniform)
+    auto pre_row = [&](int i) { return !edge_rows ? i : i == 0 ? 0 : i == 1 ? rows - 1 : i == 2 ? 1 : rows - 2; };
 #pragma unroll
-    for (int i = 0; i < BS_D; ++i) ring[i] = row_load(i);
+    for (int i = 0; i < BS_D; ++i) ring[i] = row_load(pre_row(i));
     if (lane >= nch) ct = make_int4(0, 0, 0, 0);
     const int yab = lane < nch ? (WIDE ? cm.x : ct.y) : 0;
     // head / tail sums (lanes 0..7 head, 32..39 tail)
@@ -936,6 +965,9 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #undef PS_BC_STEPS
     }
     PS_STAMP_AT(wk, 5);                                // setup loads + head / tail / chunk scans
+#if defined(PS_CUT) && PS_CUT == 1
+    return uni(static_cast<int>(T1) == 0x7fffffff ? 0 : -1);       // (instruction-count experiment: WRONG results, never the product)
+#endif
     const double T1d = uni(bs_d(T1)), T2d = uni(bs_d(T2));                // window totals about m
     const double dn = static_cast<double>(n);
     const double Dtot = dn * T2d - T1d * T1d;
@@ -1060,9 +1092,34 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const float GA = (eok && okF) ? e.g + A : INFINITY;             // (A itself is +inf when the expansion does not apply)
             ghb = fmaxf(GA, from_lane_below(GA));
             hitlike = true;
+            if constexpr (AUDIT) {
+                // lane L walks the 255 candidates inside its group (L-1, L) from the sums at the boundary below
+                const int a1b = from_lane_below(a1i);
+                const double a2b = __hiloint2double(from_lane_below(__double2hiint(bs_d(a2))), from_lane_below(__double2loint(bs_d(a2))));
+                if (lane >= 1 && lane <= ngc) {
+                    int x1 = a1b;
+                    double x2 = a2b;
+                    const int nl0g = nlc - BS_GRP_SAMPLES;
+                    float gmx = -INFINITY;
+                    for (int j = 1; j < BS_GRP_SAMPLES; ++j) {
+                        const int y = bs_count<DT>(c, base + ps + nl0g + j - 1) - m;
+                        x1 += y; x2 += static_cast<double>(y) * static_cast<double>(y);
+                        const int nlj = nl0g + j;
+                        if (nlj >= 1 && nlj <= n - 1) {
+                            const BsEval ej = bs_eval(static_cast<double>(x1), x2, T1d - static_cast<double>(x1), T2d - x2, nlj, n - nlj, cc, vfloor);
+                            if (ej.okL && ej.okR) gmx = fmaxf(gmx, ej.g);
+                        }
+                    }
+                    bs_audit_note(c.dbg, 4, 5, 8, ghb, gmx, 2.0f * dlt);
+                }
+                if (lane == 0) atomicAdd(&c.dbg[9], 1ull);
+            }
         }
     }
     PS_STAMP_AT(wk, 0);                                // totals, pruning level from the sampled boundaries
+#if defined(PS_CUT) && PS_CUT == 2
+    return uni(__ballot(ghb < Tprune) == 0x123456789ull ? 0 : -1);  // (instruction-count experiment: WRONG results, never the product)
+#endif
 #ifdef PS_STAMP
     wk.ph[11] += hitlike;
 #endif
@@ -1100,6 +1157,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 const int lo = static_cast<int>(((gb0 + tl) >> BS_GRP_LOG) - G0) + 1, hi = static_cast<int>(((gb0 + th) >> BS_GRP_LOG) - G0) + 1;
                 const unsigned long long span = ((2ull << (hi - lo)) - 1ull) << max(lo, 0);
                 live = __ballot(lane < rows && !(lo >= 1 && hi <= ngc && (dead & span) == span));
+                if constexpr (AUDIT) live = __ballot(lane < rows);
             }
         } else if (hitlike) {
             const unsigned long long dead = __ballot(cbound < Tprune);
@@ -1296,6 +1354,29 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         };
         // (the part with side effects, in row order: per-lane top-2, the block queue, the contender list)
         auto row_commit = [&](const RowOut &o) {
+            if constexpr (AUDIT && !WIDE) {
+                if (phase == 0) {
+                    // the 7 candidates inside the block (J - 8, J), from the sums at the boundary below and the raw samples
+                    const int a1p = from_lane_below(o.a1);
+                    const double a2p = __hiloint2double(from_lane_below(__double2hiint(o.a2)), from_lane_below(__double2loint(o.a2)));
+                    const int nlp = o.nl - 8;
+                    if (o.blk && nlp >= 1 && o.nl <= n - 1) {
+                        int x1 = a1p;
+                        double x2 = a2p;
+                        float gmx = -INFINITY;
+                        for (int u = 1; u < 8; ++u) {
+                            const int y = bs_count<DT>(c, base + ps + nlp + u - 1) - m;
+                            x1 += y; x2 += static_cast<double>(y) * static_cast<double>(y);
+                            const BsEval ej = bs_eval(static_cast<double>(x1), x2, T1d - static_cast<double>(x1), T2d - x2, nlp + u, n - nlp - u, cc, vfloor);
+                            if (ej.okL && ej.okR) gmx = fmaxf(gmx, ej.g);
+                        }
+                        if (o.prunable) bs_audit_note(c.dbg, 0, 1, 6, o.hb, gmx, 2.0f * dlt);
+                        const BsEval eq = bs_eval(bs_d(o.a1), o.a2, bs_d(T1 - o.a1), T2 - o.a2, o.nl, n - o.nl, cc, vfloor);
+                        const BsEval ep = bs_eval(bs_d(a1p), a2p, bs_d(T1 - a1p), T2 - a2p, nlp, n - nlp, cc, vfloor);
+                        bs_audit_note(c.dbg, 2, 3, 7, bs_block_bound2(ep, eq, nlp, n, SSt, rn), gmx, 2.0f * dlt);
+                    }
+                }
+            }
             top2_push(top, o.ge, o.nl);
             flag |= static_cast<unsigned>(o.unsure);
             // A row with a boundary gain that lies above the pruning level by more than the level's own margin: the level
@@ -1359,7 +1440,13 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             // live rows only (a window that holds a split: typically 2 .. 4 of 20)
             int rr[BS_D];                              // (uniform) row of every slot, -1: none
 #pragma unroll
-            for (int i = 0; i < BS_D; ++i) { rr[i] = take_row(); ring[i] = row_load(rr[i]); }
+            for (int i = 0; i < BS_D; ++i) {
+                // (phase 0 of a window with a coarse pass: the slot already holds a row of the window's ends; taken if live)
+                const int pr = pre_row(i);
+                const bool have = GROUPS && phase == 0 && edge_rows && pr >= 0 && pr < rows && ((live >> pr) & 1ull) != 0ull;
+                if (have) { rr[i] = pr; live &= ~(1ull << pr); }
+                else { rr[i] = take_row(); ring[i] = row_load(rr[i]); }
+            }
             for (bool any = true; any;) {
                 any = false;
 #pragma unroll
@@ -1373,7 +1460,13 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 }
             }
         }
+#if defined(PS_CUT) && PS_CUT == 3
+        return uni(__ballot(top.b > 1.0e30f) != 0ull ? 0 : -1);    // (instruction-count experiment: WRONG results, never the product)
+#endif
         drain();
+#if defined(PS_CUT) && PS_CUT == 4
+        return uni(__ballot(top.b > 1.0e30f) != 0ull ? 0 : -1);    // (instruction-count experiment: WRONG results, never the product)
+#endif
         if (phase == 1) break;
         // the wave maximum decides the common case; top-2 (DPP) only when something reaches the threshold band
         anyflag = __ballot(flag != 0) != 0ull;

@@ -2090,6 +2090,22 @@ __global__ void synth_kernel(void *out, int dtype, int64_t n, unsigned long long
     }
 }
 
+// ---- diagnostic: the bounds of the scan against the gains they cover (ps_audit_bounds; tests only) ---------------------
+// One wave per window [win[i].x, win[i].y) of event 0, candidates as the recursion would give them (min_width from both ends).
+template <int DT>
+__global__ __launch_bounds__(64) PS_SCAN_REGS void audit_kernel(DevCfg c, const int2 *win, int n_win, unsigned *status)
+{
+    __shared__ SharedT<64> sh;
+    Work wk = PS_WORK_INIT;
+    unsigned bad = 0;
+    const EvRef er = ev_ref_of(c, 0);
+    for (int i = blockIdx.x; i < n_win; i += gridDim.x) {
+        const int ps = uni(win[i].x), pe = uni(win[i].y);
+        (void)scan_window_bs<DT, true, true>(c, er, 0, ps, pe, ps + c.mw, pe - c.mw, c.min_gain, sh, bad, wk);
+    }
+    if (bad) atomicOr(status, bad);
+}
+
 }  // namespace ps
 
 #include "seg_filter.hpp"

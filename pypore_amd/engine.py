@@ -179,6 +179,23 @@ class Context(object):
                                                samples.numel(), ctypes.byref(g), ctypes.byref(i)), self.handle)
         return g.value, i.value
 
+    def audit_bounds(self, samples, quantum, params, windows, offset_counts=0):
+        """ps_audit_bounds (diagnostic): the pruning bounds of the block-sum scan -- corner, two-boundary, group -- against
+        the gains they cover, evaluated on the device from the raw samples, for the given windows [(ps, pe), ...] of the
+        trace taken as one event.  Returns a dict of counts, violations and smallest margins per kind."""
+        fmt = self._fmt(samples, quantum, offset_counts)
+        w = np.ascontiguousarray(np.asarray(windows, dtype=np.int32).reshape(-1, 2))
+        out = (ctypes.c_double * 12)()
+        torch.cuda.current_stream(samples.device).synchronize()
+        _lib.check(self.L.ps_audit_bounds(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), samples.numel(),
+                                          ctypes.byref(params), w.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(w.shape[0]), out),
+                   self.handle)
+        o = list(out)
+        return {"corner": {"blocks": int(o[0]), "violations": int(o[1]), "min_margin": o[6]},
+                "two_boundary": {"blocks": int(o[2]), "violations": int(o[3]), "min_margin": o[7]},
+                "group": {"groups": int(o[4]), "violations": int(o[5]), "min_margin": o[8]},
+                "windows_with_coarse_pass": int(o[9])}
+
     def score_window(self, samples, quantum, min_width, min_gain, offset_counts=0):
         fmt = _lib.SampleFormat(_lib.PS_DTYPE_F32 if samples.dtype == torch.float32 else _lib.PS_DTYPE_I16,
                                 int(offset_counts), float(quantum))

@@ -142,6 +142,76 @@ def boundary_A(n, ssl, ssr, a1, T1, k, groups):
     return LOG2E * (first + 0.54 * (k * tL * tL + (n - k) * tR * tR))
 
 
+def run(y, c1, c2, wins, GS, mode):
+    """the bound on every group of every window in `wins`; returns counts (violations, groups, live rows of the fine sweep)"""
+    thr2 = THR * LOG2E
+    viol = 0
+    tot_groups = kept_groups = 0
+    rows_now = rows_live = 0
+    nosplit = split = 0
+    lr_ns = lr_s = 0
+    loose = []
+    for (ps, pe, res) in wins:
+        n = pe - ps
+        if n < 4 * GS:
+            continue
+        g, ssl, ssr, a1, a2, T1, T2 = window_gains(c1, c2, ps, pe)
+        dlt = 0.02 + 8.0e-6 * n
+        dthr = dlt + 3.0e-6 * n + 1.0e-6 * thr2
+        # groups aligned to the absolute sample index (global block index in the kernel)
+        P0 = -(-ps // GS) * GS
+        Ps = np.arange(P0, pe - GS + 1, GS)
+        Ps = Ps[(Ps - ps >= 1) & (Ps + GS - ps <= n - 1)]
+        if Ps.size == 0:
+            continue
+        kb = np.concatenate((Ps, [Ps[-1] + GS])) - ps          # coarse boundaries, window-relative
+        inr = (kb >= MW) & (kb <= n - MW)
+        bm = g[kb[inr] - 1].max() if inr.any() else -np.inf
+        Tprune = max(thr2 - dthr, bm - 2 * dlt) - 2 * dlt
+        nblk = n // 8
+        rows = (nblk + 62) // 63
+        live = np.zeros(rows, dtype=bool)
+        # blocks outside the coarse coverage: always swept
+        first_cov, last_cov = kb[0], kb[-1]
+        live[0: (first_cov // 8) // 63 + 1] = True
+        live[min(rows - 1, (last_cov // 8) // 63):] = True
+        if mode == "sym":
+            gd = []
+            for P in Ps:
+                D1, D2 = group_data(y, c1, c2, P, GS, "group")
+                gd.append((D1, D2, (a1[P - ps + GS - 1] - a1[P - ps - 1]) / GS))
+            GA = []
+            for ci, k in enumerate(kb):
+                adj = [gd[j] for j in (ci - 1, ci) if 0 <= j < len(gd)]
+                GA.append(g[k - 1] + boundary_A(n, ssl, ssr, a1, T1, k, adj))
+        for gi, P in enumerate(Ps):
+            kP, kQ = P - ps, P - ps + GS
+            if mode == "sym":
+                hb = max(GA[gi], GA[gi + 1])
+            else:
+                D1, D2 = group_data(y, c1, c2, P, GS, mode)
+                hb = max(group_bound(n, g, ssl, ssr, a1, T1, kP, kQ, D1, D2, GS),
+                         group_bound(n, g, ssl, ssr, a1, T1, kQ, kP, D1, D2, GS))
+            inner = g[kP:kQ - 1].max() if kQ - 1 > kP else -np.inf              # candidates kP+1 .. kQ-1, in range or not
+            if inner > hb + 1e-9:
+                viol += 1
+            tot_groups += 1
+            if res < 0 and np.isfinite(hb):
+                loose.append(hb - max(g[kP - 1], g[kQ - 1]))
+            if not hb < Tprune:
+                kept_groups += 1
+                live[min(rows - 1, (kP // 8) // 63): min(rows - 1, ((kQ + 7) // 8) // 63) + 1] = True
+        rows_now += rows
+        rows_live += int(live.sum())
+        if res < 0:
+            nosplit += 1; lr_ns += int(live.sum())
+        else:
+            split += 1; lr_s += int(live.sum())
+    return dict(violations=viol, groups=tot_groups, kept=kept_groups, rows=rows_now, rows_live=rows_live, windows=nosplit + split,
+                nosplit=nosplit, live_rows_nosplit=lr_ns / max(nosplit, 1), live_rows_split=lr_s / max(split, 1),
+                loose=np.array(loose))
+
+
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
@@ -149,78 +219,17 @@ def main():
     y -= y[0]
     c1, c2, wins, bounds = rec_windows(y)
     print("trace %d samples, %d windows scanned, %d boundaries" % (N, len(wins), len(bounds)))
-    thr2 = THR * LOG2E
-    for GS in (128, 256):
-        for mode in ("group", "sym"):
-            viol = 0
-            tot_groups = kept_groups = 0
-            rows_now = rows_live = 0
-            nosplit = split = 0
-            lr_ns = lr_s = 0
-            loose = []
-            for (ps, pe, res) in wins:
-                n = pe - ps
-                if n < 4 * GS:
-                    continue
-                g, ssl, ssr, a1, a2, T1, T2 = window_gains(c1, c2, ps, pe)
-                dlt = 0.02 + 8.0e-6 * n
-                dthr = dlt + 3.0e-6 * n + 1.0e-6 * thr2
-                # groups aligned to the absolute sample index (global block index in the kernel)
-                P0 = -(-ps // GS) * GS
-                Ps = np.arange(P0, pe - GS + 1, GS)
-                Ps = Ps[(Ps - ps >= 1) & (Ps + GS - ps <= n - 1)]
-                if Ps.size == 0:
-                    continue
-                kb = np.concatenate((Ps, [Ps[-1] + GS])) - ps          # coarse boundaries, window-relative
-                inr = (kb >= MW) & (kb <= n - MW)
-                bm = g[kb[inr] - 1].max() if inr.any() else -np.inf
-                Tprune = max(thr2 - dthr, bm - 2 * dlt) - 2 * dlt
-                nblk = n // 8
-                rows = (nblk + 62) // 63
-                live = np.zeros(rows, dtype=bool)
-                # blocks outside the coarse coverage: always swept
-                first_cov, last_cov = kb[0], kb[-1]
-                live[0: (first_cov // 8) // 63 + 1] = True
-                live[min(rows - 1, (last_cov // 8) // 63):] = True
-                if mode == "sym":
-                    gd = []
-                    for P in Ps:
-                        D1, D2 = group_data(y, c1, c2, P, GS, "group")
-                        gd.append((D1, D2, (a1[P - ps + GS - 1] - a1[P - ps - 1]) / GS))
-                    GA = []
-                    for ci, k in enumerate(kb):
-                        adj = [gd[j] for j in (ci - 1, ci) if 0 <= j < len(gd)]
-                        GA.append(g[k - 1] + boundary_A(n, ssl, ssr, a1, T1, k, adj))
-                for gi, P in enumerate(Ps):
-                    kP, kQ = P - ps, P - ps + GS
-                    if mode == "sym":
-                        hb = max(GA[gi], GA[gi + 1])
-                    else:
-                        D1, D2 = group_data(y, c1, c2, P, GS, mode)
-                        hb = max(group_bound(n, g, ssl, ssr, a1, T1, kP, kQ, D1, D2, GS),
-                                 group_bound(n, g, ssl, ssr, a1, T1, kQ, kP, D1, D2, GS))
-                    lo_c, hi_c = max(kP + 1, MW), min(kQ - 1, n - MW)
-                    inner = g[lo_c - 1:hi_c].max() if hi_c >= lo_c else -np.inf
-                    if inner > hb + 1e-9:
-                        viol += 1
-                    tot_groups += 1
-                    if res < 0 and np.isfinite(hb):
-                        loose.append(hb - max(g[kP - 1], g[kQ - 1]))
-                    if not hb < Tprune:
-                        kept_groups += 1
-                        live[min(rows - 1, (kP // 8) // 63): min(rows - 1, ((kQ + 7) // 8) // 63) + 1] = True
-                rows_now += rows
-                rows_live += int(live.sum())
-                if res < 0:
-                    nosplit += 1; lr_ns += int(live.sum())
-                else:
-                    split += 1; lr_s += int(live.sum())
-            loose = np.array(loose)
+    for GS in (64, 128, 256, 512):
+        for mode in ("sample", "block", "group", "sym"):
+            if mode == "sym" and GS == 64:
+                continue
+            r = run(y, c1, c2, wins, GS, mode)
+            lo = r["loose"]
             print("GS %3d %-6s: violations %d | groups kept %.2f %% | fine rows live %.1f %% (%d of %d; %d windows: %d no split)"
                   " | bound - max boundary gain on no-split windows: median %.2f  90%% %.2f  99%% %.2f" %
-                  (GS, mode, viol, 100.0 * kept_groups / max(tot_groups, 1), 100.0 * rows_live / max(rows_now, 1), rows_live,
-                   rows_now, nosplit + split, nosplit, np.median(loose), np.quantile(loose, 0.9), np.quantile(loose, 0.99)))
-            print("      live rows per window: no split %.2f, split %.2f" % (lr_ns / max(nosplit, 1), lr_s / max(split, 1)))
+                  (GS, mode, r["violations"], 100.0 * r["kept"] / max(r["groups"], 1), 100.0 * r["rows_live"] / max(r["rows"], 1),
+                   r["rows_live"], r["rows"], r["windows"], r["nosplit"], np.median(lo), np.quantile(lo, 0.9), np.quantile(lo, 0.99)))
+            print("      live rows per window: no split %.2f, split %.2f" % (r["live_rows_nosplit"], r["live_rows_split"]))
 
 
 if __name__ == "__main__":

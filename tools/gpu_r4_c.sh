@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 4: the bound audit on the device, the suite in default + verify mode, then the step at 4 / 6 / 8 contexts
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+export GPU_MAX_HW_QUEUES=8
+timeout 900 python -m pytest tests/test_bound_audit.py -x -q -m gpu 2>&1 | tail -15
+for env in "X=0" "PORESEG_MODE=2"; do
+  echo "== $env"; env $env timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+done
+P='import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print(d["ms_per_step"], "seq", r["sequence_ms"], "single", r["single_stream"]["sequence_ms"] if r["single_stream"] else None, r["kernel_ms"])'
+for s in 4 6 8 4 8; do
+  echo -n "[streams $s] "; python bench.py --no-cpu --no-h2d --steps 120 --warmup 24 --streams $s 2>/dev/null | python -c "$P"
+done
