@@ -44,6 +44,8 @@ extern "C" {
 
 #define PS_DTYPE_F32 0            /* float pA on the grid k*quantum */
 #define PS_DTYPE_I16 1            /* raw int16 ADC counts (read_abf.py:208) */
+#define PS_DTYPE_F64 2   /* float64 pA on no grid: accepted by ps_filter_bessel ONLY (the current of an event that was
+                            filtered before, DataTypes.py:258-274); quantum and offset_counts are ignored */
 
 typedef struct ps_ctx ps_ctx;
 
@@ -165,6 +167,19 @@ int ps_score_window(ps_ctx *ctx, const void *d_samples, const ps_sample_format *
                     int64_t n, int32_t min_width, double min_gain,
                     double *d_scores, int32_t *split_out);
 
+/* Diagnostic (tests only; no reference counterpart): audits the pruning bounds of the block-sum window scan ON THE
+ * DEVICE, with the scan code of the product.  The trace [0, n) is taken as one event (K0 digest), every window
+ * [h_windows[2i], h_windows[2i+1]) is scanned with all rows swept, and each bound the scan forms is compared with the
+ * screened gains of the candidates it covers, evaluated one by one from the raw samples:
+ *   out[0] blocks with a corner bound        out[1] of which violated      out[6] smallest margin (bound - largest gain)
+ *   out[2] blocks with a two-boundary bound  out[3] of which violated      out[7] smallest margin
+ *   out[4] groups (256 samples) with a bound out[5] of which violated      out[8] smallest margin
+ *   out[9] windows with a coarse pass
+ * A violation is a covered gain above the bound by more than 2 delta(n), the slack every pruning level carries
+ * (DESIGN.md 4.3, 4.4).  Needs min_width >= 8 and counts inside the 32-bit digest (PS_ERR_ARG otherwise). */
+int ps_audit_bounds(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                    const ps_split_params *params, const int32_t *h_windows, int32_t n_win, double *out12);
+
 /* Replaces lambda_event_parser(threshold).parse with the default rules (parsers.py:124-155, rules
  * :133-135): events are the maximal runs of samples on one side of `threshold` (mask = x < threshold,
  * cut at every mask edge) that satisfy  length > min_duration,  min > min_current,  max < threshold.
@@ -234,6 +249,10 @@ int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_mod
  * (gains differ by ~1e-11), so the reference could have decided such a window the other way; exact ties are decided like
  * the reference (first maximum wins, cparsers.pyx:175-177) and counted too. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);
+/* The twelve work counters of ps_get_timings in place (valid for the life of the context; host memory, updated by every
+ * call before it returns): a caller that checks one of them after each call -- counters[11], the near ties -- reads it
+ * there instead of making a second call. */
+const int64_t *ps_counters(const ps_ctx *ctx);
 
 /* Synthetic step-signal generator (bit-identical to pypore_amd/synth.py):
  * sample i = level_counts[segment containing i] + noise(seed, i), written as fp32 pA

@@ -66,19 +66,38 @@ class Event(Segment):
     # ---- Event.filter (DataTypes.py:258-274) ----------------------------------------------------------------
     def filter(self, order=1, cutoff=2000., quantum=None):
         """Bessel low-pass, cutoff relative to the Nyquist frequency of the file's sampling rate, run forward and
-        backward (scipy.signal.filtfilt semantics) on the device; `current` becomes the float64 result.  Orders 1..4
-        run on the device (1, the reference's default, by scans; 2..4 by segments with halos); higher orders raise
-        ValueError.  The result no longer lies on the ADC grid: see parse.  The INPUT must lie on an ADC grid (what a
-        file reader returns): filtering an already filtered current again raises ValueError where the reference would
-        filter it again."""
+        backward (scipy.signal.filtfilt semantics) on the device; `current` becomes the float64 result.  Orders 1..8
+        run on the device (1, the reference's default, by scans; 2..8 by segments with halos); higher orders raise
+        ValueError.  The result no longer lies on the ADC grid: see parse.  Like the reference, this filters whatever
+        `current` holds: a current on an ADC grid (what a file reader returns) goes up as counts, anything else -- an
+        event that was filtered before (Experiment.parse twice on the same files), float64 data on no grid -- as float64."""
         if type(self) is not Event:
             raise TypeError("Cannot filter a metaevent. Must have the current.")
+        import torch
         from . import engine
-        s = engine.to_device(raw_current(self), quantum)
-        ctx = engine.context(s.tensor.device.index)
-        out = ctx.filter_bessel(s.tensor, s.quantum, cutoff=cutoff, sampling_freq=float(self.second), order=order)
-        # (a DC offset passes a unit-gain low-pass unchanged: filter the counts, put the offset back)
-        self.current = out.cpu().numpy() + s.offset if s.offset else out.cpu().numpy()
+        cur = raw_current(self)
+        s = None
+        if not self.__dict__.get("filtered") or quantum is not None:
+            try:
+                s = engine.to_device(cur, quantum)
+            except ValueError:
+                if quantum is not None:
+                    raise                                # the caller named a grid the data does not lie on
+        if s is not None:
+            ctx = engine.context(s.tensor.device.index)
+            out = ctx.filter_bessel(s.tensor, s.quantum, cutoff=cutoff, sampling_freq=float(self.second), order=order)
+            # (a DC offset passes a unit-gain low-pass unchanged: filter the counts, put the offset back)
+            self.current = out.cpu().numpy() + s.offset if s.offset else out.cpu().numpy()
+        else:
+            # no grid: the float64 values themselves (a current still parked on the device stays there)
+            t = getattr(cur, "tensor", None)
+            if t is None or not t.is_cuda:
+                a = np.ascontiguousarray(np.asarray(self.current), dtype=np.float64)
+                if a.ndim != 1:
+                    raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % a.ndim)
+                t = torch.from_numpy(a).cuda()
+            ctx = engine.context(t.device.index)
+            self.current = ctx.filter_bessel(t.contiguous(), 1.0, cutoff=cutoff, sampling_freq=float(self.second), order=order).cpu().numpy()
         self.filtered, self.filter_order, self.filter_cutoff = True, order, cutoff
 
     # ---- Event.parse (DataTypes.py:276-289, :333) -----------------------------------------------------------

@@ -12,12 +12,13 @@ PS_OK = 0
 PS_ERR_ARG, PS_ERR_ASSERT_WIDTH, PS_ERR_ASSERT_WINDOW, PS_ERR_ASSERT_CUTOFF = -1, -2, -3, -4
 PS_ERR_CAPACITY, PS_ERR_OFF_GRID, PS_ERR_HIP, PS_ERR_NO_DEVICE, PS_ERR_INTERNAL = -5, -6, -7, -8, -9
 PS_DTYPE_F32, PS_DTYPE_I16 = 0, 1
+PS_DTYPE_F64 = 2          # float64 pA on no grid: ps_filter_bessel input only
 PS_ALIGN_OK, PS_ALIGN_VALUE_ERROR, PS_ALIGN_INDEX_ERROR, PS_ALIGN_ZERO_DIVISION, PS_ALIGN_UNDEFINED = 0, 1, 2, 3, 4
 
 EXPORTS = ["ps_version", "ps_device_count", "ps_create", "ps_destroy", "ps_last_error", "ps_set_tiling", "ps_set_option",
            "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_segment_batch_ex", "ps_segment_events", "ps_detect_events", "ps_bounds_capacity",
            "ps_best_single_split", "ps_score_window", "ps_get_timings", "ps_synth_trace", "ps_filter_bessel",
-           "ps_requantise", "ps_align_batch"]
+           "ps_requantise", "ps_align_batch", "ps_audit_bounds", "ps_counters"]
 
 
 class SplitParams(ctypes.Structure):
@@ -73,6 +74,8 @@ def lib():
     L.ps_filter_bessel.argtypes = [vp, vp, P(SampleFormat), i64, i32, dbl, dbl, vp]
     L.ps_requantise.argtypes = [vp, vp, i64, vp, P(dbl), P(dbl)]
     L.ps_align_batch.argtypes = [vp, P(dbl), P(dbl), P(dbl), i32, dbl, dbl, vp, vp, vp, P(i64), i32, vp, vp, vp]
+    L.ps_counters.argtypes = [vp]
+    L.ps_counters.restype = P(i64)
     L.ps_audit_bounds.argtypes = [vp, vp, P(SampleFormat), i64, P(SplitParams), P(i32), i32, P(dbl)]
     _lib = L
     return L

@@ -142,10 +142,25 @@ class FastStatSplit(object):
         ctx = engine.context(self.device)
         filtered, onto_grid, by_step = [None] * len(currents), [None] * len(currents), {}
         for i, cur in enumerate(currents):
-            s = engine.to_device(cur, self.quantum, self.offset, self.device)
-            y = ctx.filter_bessel(s.tensor, s.quantum, cutoff=cutoff, sampling_freq=sampling_freq, order=order)
+            t64 = getattr(cur, "tensor", None)               # a current filtered before and still parked on the device
+            if t64 is not None and t64.is_cuda and t64.dtype == torch.float64:
+                y, off = ctx.filter_bessel(t64.contiguous(), 1.0, cutoff=cutoff, sampling_freq=sampling_freq, order=order), float(cur.offset)
+            else:
+                try:
+                    s = engine.to_device(cur, self.quantum, self.offset, self.device)
+                    y, off = ctx.filter_bessel(s.tensor, s.quantum, cutoff=cutoff, sampling_freq=sampling_freq, order=order), s.offset
+                except ValueError:
+                    if self.quantum is not None:
+                        raise
+                    # on no grid (filtered before, resampled on the host): the float64 values themselves, like the reference
+                    a = np.ascontiguousarray(np.asarray(cur), dtype=np.float64)
+                    if a.ndim != 1:
+                        raise
+                    y = ctx.filter_bessel(torch.from_numpy(a).to(torch.device("cuda", ctx.device)), 1.0, cutoff=cutoff,
+                                          sampling_freq=sampling_freq, order=order)
+                    off = 0.0
             z, _, step = ctx.requantise(y)
-            filtered[i], onto_grid[i] = (y, s.offset), z
+            filtered[i], onto_grid[i] = (y, off), z
             by_step.setdefault(step, []).append(i)
         # (a DC offset passes a unit-gain low-pass unchanged: the counts were filtered, the offset is put back)
         from .grid import Deferred

@@ -94,6 +94,7 @@ struct ps_ctx {
     int tree_mw = 0;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list (round 3: single-wave workgroups are faster at four waves per SIMD and need no spills)
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
+    int tree_par = 1;         // 1: subtree jobs on the 64-bit digest (filtered events: deep recursions) are shared by the waves of a workgroup (tree_par_kernel), 0: one wave per job
     int groups = 1;           // 1: K0 writes group records and the window scans start with the coarse pass over them (narrow digest), 0: every row is swept
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
     int wide_bs = 1;          // 1: counts too wide for the 32-bit digest are retried on the 64-bit digest, 0: straight to the LDS-window scan
@@ -249,7 +250,7 @@ template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsig
 }
 
 template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, size_t n_jobs,
-                                          const AsmHeader *d_hdr)
+                                          const AsmHeader *d_hdr, int par_max_jobs = 0)
 {
     const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(tree_kernel<NT, DT>), static_cast<int>(lds)));
@@ -260,7 +261,7 @@ template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsign
                        static_cast<long long>(n_jobs), d_hdr,
                        // (not on the 64-bit digest: those are filtered events, whose jobs hold many windows each -- 32 of them:
                        //  subtree kernel 1.30 ms on all slots, 1.71 ms with the rule)
-                       NT == 64 && !(DT & DT_WIDE) ? ctx->tree_jobs_per_wave : 0);
+                       NT == 64 && !(DT & DT_WIDE) ? ctx->tree_jobs_per_wave : 0, par_max_jobs);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -279,6 +280,25 @@ template <int DT> int launch_tree_mw(ps_ctx *ctx, const DevCfg &cfg, unsigned nj
                        static_cast<long long>(n_jobs), d_hdr, &sm->tree_tail, ctx->tree_tail_pct);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
+}
+
+// deep jobs (filtered events on the 64-bit digest): the PAR_W waves of a workgroup share one job (tree_par_kernel)
+template <int DT> int launch_tree_par(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, size_t n_jobs,
+                                      const AsmHeader *d_hdr)
+{
+    const size_t lds = sizeof(SharedT<64>) * PAR_W + sizeof(ParQ);
+    HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(tree_par_kernel<DT>), static_cast<int>(lds)));
+    const unsigned slots = resident_slots(ctx, tree_par_kernel<DT>, 64 * PAR_W, lds);
+    const unsigned grid = std::max(1u, std::min(nj, slots));
+    // calls with at most one job per workgroup slot are this kernel's; the others go to tree_kernel (decided on the device,
+    // where the job count is known: both are launched, one of them returns at once)
+    const int par_max = static_cast<int>(slots);
+    hipLaunchKernelGGL((tree_par_kernel<DT>), dim3(grid), dim3(64 * PAR_W), lds, ctx->stream, cfg,
+                       ctx->tree_jobs.as<TreeJob>(), ctx->tree_scratch.as<int32_t>(), ctx->tree_spill.as<int2>(),
+                       ctx->tree_counts.as<int32_t>(), reinterpret_cast<unsigned *>(&sm->status), &sm->work0,
+                       static_cast<long long>(n_jobs), d_hdr, par_max);
+    HIP_TRY(ctx, hipGetLastError());
+    return launch_tree<64, DT>(ctx, cfg, nj, sm, n_jobs, d_hdr, par_max);
 }
 
 struct Anchor { int32_t pos, kind; };
@@ -396,7 +416,9 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (n_tj) {
         const unsigned g = static_cast<unsigned>(std::min<size_t>(n_tj, 0x7fffffff));
         const bool f32 = cfg.dtype == PS_DTYPE_F32;
-        int lrc = cfg.bsum != nullptr && cfg.bs_wide && ctx->tree_mw
+        int lrc = cfg.bsum != nullptr && cfg.bs_wide && ctx->tree_par
+                      ? (f32 ? launch_tree_par<PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree_par<PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr))
+                  : cfg.bsum != nullptr && cfg.bs_wide && ctx->tree_mw
                       ? (f32 ? launch_tree_mw<PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree_mw<PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr))
                   : cfg.bsum != nullptr && cfg.bs_wide
                       ? (f32 ? launch_tree<64, PS_DTYPE_F32 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr) : launch_tree<64, PS_DTYPE_I16 | DT_WIDE>(ctx, cfg, g, sm, n_tj, d_hdr))
@@ -820,6 +842,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_GROUPS")) ctx->groups = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_TREE_PAR")) ctx->tree_par = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
@@ -874,6 +897,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "prune") ctx->prune = value != 0;
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
     else if (n == "groups") ctx->groups = value != 0;
+    else if (n == "tree_par") ctx->tree_par = value != 0;
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
     else if (n == "tree_tail_pct" && value >= 0 && value <= 100) ctx->tree_tail_pct = static_cast<int>(value);
@@ -1403,6 +1427,10 @@ int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counter
     return PS_OK;
 }
 
+// The context's twelve work counters where ps_get_timings copies them from: a host that looks at one of them after every
+// call (the near-tie count, counters[11]) reads it in place instead of making a second call.
+const int64_t *ps_counters(const ps_ctx *ctx) { return ctx ? ctx->counters : nullptr; }
+
 int ps_synth_trace(ps_ctx *ctx, void *d_out, int32_t dtype, int64_t n, uint64_t seed,
                    const int64_t *h_seg_end, const int32_t *h_level_counts, int64_t nseg)
 {
@@ -1425,18 +1453,24 @@ int ps_synth_trace(ps_ctx *ctx, void *d_out, int32_t dtype, int64_t n, uint64_t 
 }
 
 namespace {
-// scipy.signal.bessel(N, wn, 'low', analog=False, output='ba') for N = 2..4: poles of the phase-normalised analog
+// scipy.signal.bessel(N, wn, 'low', analog=False, output='ba') for N = 2..8: poles of the phase-normalised analog
 // prototype (what scipy.signal.besselap(N, 'phase') returns; conjugates implied), lp2lp with the pre-warped frequency,
 // bilinear transform with fs = 2, polynomial expansion.  Then lfilter_zi (steady state of the delays for a unit step:
 // (I - A) zi = B), the halo from the powers of the state matrix, and one launch of filt_halo_kernel.
 int filter_order_n(ps_ctx *ctx, const DevCfg &cfg, int64_t n, int order, double wn, double *d_out)
 {
     typedef std::complex<double> cd;
-    static const double poles[FILT_MAXORD + 1][2][2] = {
+    static const double poles[FILT_MAXORD + 1][4][2] = {       // [order][pair][re, im]; im == 0: a single real pole
         {{0, 0}}, {{-0.9999999999999998, 0.0}},
         {{-0.8660254037844384, 0.4999999999999999}},
         {{-0.9416000265332067, 0.0}, {-0.7456403858480766, 0.7113666249728351}},
-        {{-0.9047587967882447, 0.27091873300387465}, {-0.6572111716718827, 0.830161435004873}}};
+        {{-0.9047587967882447, 0.27091873300387465}, {-0.6572111716718827, 0.830161435004873}},
+        {{-0.9264420773877602, 0.0}, {-0.8515536193688396, 0.44271746394433265}, {-0.5905759446119191, 0.9072067564574549}},
+        {{-0.9093906830472273, 0.1856964396793047}, {-0.7996541858328288, 0.5621717346937318}, {-0.5385526816693109, 0.9616876881954278}},
+        {{-0.919487155649029, 0.0}, {-0.8800029341523375, 0.32166527623077396}, {-0.7527355434093214, 0.6504696305522552},
+         {-0.4966917256672317, 1.0025085084544205}},
+        {{-0.909683154665291, 0.1412437976671423}, {-0.8473250802359334, 0.42590175382729345}, {-0.7111381808485397, 0.7186517314108402},
+         {-0.4621740412532123, 1.0343886811269012}}};
     const double wo = 4.0 * std::tan(3.14159265358979323846 * wn / 2.0);
     std::vector<cd> p;
     for (int k = 0; k < (order + 1) / 2; ++k) {
@@ -1505,8 +1539,9 @@ int filter_order_n(ps_ctx *ctx, const DevCfg &cfg, int64_t n, int order, double 
     HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
     unsigned *st = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->status);
     const dim3 grid(static_cast<unsigned>((nseg + 63) / 64));
-    if (cfg.dtype == PS_DTYPE_F32) hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_F32>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
-    else                           hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_I16>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
+    if (cfg.dtype == PS_DTYPE_F32)      hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_F32>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
+    else if (cfg.dtype == PS_DTYPE_F64) hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_F64>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
+    else                                hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_I16>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1527,7 +1562,15 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     if (!(wn > 0.0) || !(wn < 1.0)) return fail(ctx, PS_ERR_ARG, "cutoff must lie strictly between 0 and the Nyquist frequency");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevCfg cfg;
-    int rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);
+    int rc;
+    if (fmt && fmt->dtype == PS_DTYPE_F64) {
+        // float64 input (this entry only): the values are the current itself
+        const ps_sample_format f32 = {PS_DTYPE_F32, 0, 1.0};
+        rc = make_cfg(ctx, d_samples, &f32, 1, 1, 2, 0.0, &cfg);
+        cfg.dtype = PS_DTYPE_F64; cfg.q = 1.0; cfg.q2 = 1.0; cfg.inv_q = 1.0f;
+    } else {
+        rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);
+    }
     if (rc) return rc;
     if (order > 1) return filter_order_n(ctx, cfg, n, order, wn, d_out);
     // scipy.signal.bessel(1, wn, 'low', analog=False): one real pole, bilinear transform with pre-warping (fs = 2)
@@ -1550,8 +1593,9 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
             HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
             HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
             unsigned *fst = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->status);
-            if (cfg.dtype == PS_DTYPE_F32) hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_F32>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
-            else                           hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_I16>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
+            if (cfg.dtype == PS_DTYPE_F32)      hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_F32>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
+            else if (cfg.dtype == PS_DTYPE_F64) hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_F64>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
+            else                                hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_I16>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1578,7 +1622,7 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     hipLaunchKernelGGL((filt_apply_kernel<0, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, g, zin, fwd, agg_b, st); \
     hipLaunchKernelGGL((filt_carry_kernel<1, DT>), dim3(1), dim3(1024), 0, ctx->stream, cfg, f, fwd, g, agg_b, n_chunks, zin); \
     hipLaunchKernelGGL((filt_apply_kernel<1, DT>), grid, dim3(FILT_NT), 0, ctx->stream, cfg, f, fwd, g, zin, d_out, agg_b, st);
-    if (cfg.dtype == PS_DTYPE_F32) { PS_FILT(PS_DTYPE_F32) } else { PS_FILT(PS_DTYPE_I16) }
+    if (cfg.dtype == PS_DTYPE_F32) { PS_FILT(PS_DTYPE_F32) } else if (cfg.dtype == PS_DTYPE_F64) { PS_FILT(PS_DTYPE_F64) } else { PS_FILT(PS_DTYPE_I16) }
 #undef PS_FILT
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));

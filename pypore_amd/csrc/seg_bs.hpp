@@ -810,6 +810,11 @@ __device__ __forceinline__ void bs_audit_note(unsigned long long *a, int icnt, i
     atomicMin(reinterpret_cast<int *>(&a[imin]), k);
 }
 
+#ifdef PS_MARKS
+#define PS_MARK(n) asm volatile("; PSMARK " #n)
+#else
+#define PS_MARK(n) do { } while (0)
+#endif
 // One wave scans the window [ps, pe) of an event (samples at c.samples[base + .], event constants `er`).
 //
 // Setup (one memory round trip): the ragged head / tail samples, the totals of the <= 64 chunks the window touches (one
@@ -854,6 +859,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         return uni(static_cast<int>(ex));
     }
     PS_STAMP_AT(wk, 7);                                // (diagnostic build) time between scans: recursion control, stack
+    PS_MARK(scan_begin);
     const int m = er.m;
     const ent_t *bsw = static_cast<const ent_t *>(c.bsum) + gb0;      // bsw[t]: chunk prefix at boundary t = 0..nblk
     const long long c0 = gb0 >> BS_CHUNK_LOG;
@@ -965,6 +971,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #undef PS_BC_STEPS
     }
     PS_STAMP_AT(wk, 5);                                // setup loads + head / tail / chunk scans
+    PS_MARK(setup_done);
 #if defined(PS_CUT) && PS_CUT == 1
     return uni(static_cast<int>(T1) == 0x7fffffff ? 0 : -1);       // (instruction-count experiment: WRONG results, never the product)
 #endif
@@ -1117,6 +1124,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         }
     }
     PS_STAMP_AT(wk, 0);                                // totals, pruning level from the sampled boundaries
+    PS_MARK(coarse_done);
 #if defined(PS_CUT) && PS_CUT == 2
     return uni(__ballot(ghb < Tprune) == 0x123456789ull ? 0 : -1);  // (instruction-count experiment: WRONG results, never the product)
 #endif
@@ -1175,6 +1183,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         };
         auto drain = [&]() {
             // drain: interior candidates of the queued blocks
+            PS_MARK(drain_begin);
             ps_sync<64>();
             PS_STAMP_AT(wk, 1);                        // boundary sweep
             if constexpr (!WIDE && PS_DRAIN_FILTER) {
@@ -1270,6 +1279,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 ps_sync<64>();
             }
             qcount = 0;
+            PS_MARK(drain_end);
             PS_STAMP_AT(wk, 2);                        // drain
         };
         // early drain (the queue is filling: this window probably holds a split): afterwards the pruning level follows the
@@ -1289,6 +1299,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         // row r: lane L takes boundary t = 63 r + L (J = g0 + 8 t); the row's boundaries lie in at most two chunks
         struct RowOut { s1_t a1; s2_t a2; int nl; float ge, hb; bool blk, prunable, unsure; };
         auto row_eval = [&](int r, const ent_t &cur_in) -> RowOut {
+            PS_MARK(row_eval_begin);
             ent_t cur = cur_in;
 #ifdef PS_STAMP
             wk.ph[8] += 1;                                                 // (diagnostic build) rows swept
@@ -1354,6 +1365,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         };
         // (the part with side effects, in row order: per-lane top-2, the block queue, the contender list)
         auto row_commit = [&](const RowOut &o) {
+            PS_MARK(row_commit_begin);
             if constexpr (AUDIT && !WIDE) {
                 if (phase == 0) {
                     // the 7 candidates inside the block (J - 8, J), from the sums at the boundary below and the raw samples
@@ -1415,6 +1427,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 qcount += __popcll(km);
             }
             if (phase) PS_COLLECT(o.ge >= Tc, o.ge, ps + o.nl, o.a1, o.a2)
+            PS_MARK(row_commit_end);
         };
         auto do_row = [&](int r, const ent_t &cur) { row_commit(row_eval(r, cur)); };
         // One row at a time (no interleaving of rows: the four waves of the SIMD cover each other's latencies, and a row
@@ -1491,6 +1504,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
 #ifdef PS_NOEXACT
         if (result == -2) result = ab < thr_log2 ? -1 : ps + ai;       // timing experiment only: never the product
 #endif
+        PS_MARK(decide_done);
         PS_STAMP_AT(wk, 3);                            // wave maximum / top-2, decision
         if (result != -2 || anyflag) break;
         // Ambiguous for the screen (inside the threshold band, or a near tie): collect the contenders.
@@ -1512,6 +1526,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         result = uni(static_cast<int>(dr));
         wk.exact += 1; wk.near += uni(static_cast<int>(dr >> 32));
     }
+    PS_MARK(scan_end);
     PS_STAMP_AT(wk, 4);                                // contenders + fp64 decision
     if (c.mode == MODE_VERIFY || result == -2) {
         wk.exact += (1LL << 32);                       // high word: full exact scans

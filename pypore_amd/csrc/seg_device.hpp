@@ -1510,11 +1510,12 @@ template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void tree_kernel(DevCfg c, const TreeJob *__restrict__ jobs, int32_t *scratch,
                                                   int2 *spill, int32_t *counts, unsigned *status,
                                                   unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr,
-                                                  int jobs_per_wave)
+                                                  int jobs_per_wave, int par_max_jobs = 0)
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
     const long long n_jobs = dev_count(hdr, n_jobs_host);
+    if (n_jobs <= par_max_jobs) return;                // (few, deep jobs: tree_par_kernel, launched next to this one, takes the call)
     // How many of the launched slots work (jobs_per_wave > 0; the job count is only known on the device).  With few
     // jobs per slot the kernel's duration is a handful of windows in a row, and a window's latency doubles from two to
     // four waves per SIMD: then half the slots do the work -- and the other half of the SIMD's registers is where
@@ -1589,6 +1590,125 @@ __global__ __launch_bounds__(64 * TREE_W, PS_BS_MINW) PS_SCAN_REGS void tree_mw_
             if (ps_tid<64>() == 0) kk = atomicAdd(&next_k, 1);
             k = __builtin_amdgcn_readfirstlane(kk);
         }
+    }
+    flush_wave(bad, wk, status, work, 2);
+}
+
+// ---- subtree jobs whose recursion is DEEP: the waves of a workgroup share ONE job ---------------------------------------
+// rec(start, s) and rec(s, end) (cparsers.pyx:203) are independent of each other: after a split the left part is somebody
+// else's work.  A filtered event (the reference's default workflow, DataTypes.py:975-984) has a few hundred subtree jobs
+// of ~60 window scans each -- on one wave per job nine tenths of the chip idle while every job walks its recursion depth
+// first.  Here the PAR_W waves of a workgroup take one job together: an interval queue in LDS (append-only, tickets; no
+// traffic leaves the CU -- round 3 tried a queue in HBM for all workgroups and lost to the contention on its lines), the
+// wave that finds a split appends the LEFT part and goes on with the right one, a wave without work takes the next
+// ticket and waits for its slot to be filled or for the count of unfinished intervals to reach zero.  Boundaries are
+// collected unordered in LDS and written by rank.  The scans and their order within an interval are tree_job's: the same
+// windows, the same decisions.  Jobs too large for the LDS queue (more than PAR_ON possible boundaries) are walked by
+// wave 0 alone, as in tree_kernel.
+#ifndef PS_PAR_W
+#define PS_PAR_W 4
+#endif
+constexpr int PAR_W = PS_PAR_W;
+constexpr int PAR_ON = 768;                            // boundaries of a job handled in LDS (job length <= PAR_ON * min_width)
+constexpr int PAR_QN = PAR_ON + 8;                     // appended intervals: one per split (the right part stays with its wave) + the job itself
+struct ParQ {
+    int head, tail, pending, ocnt;                     // tickets handed out, intervals appended, intervals unfinished, boundaries found
+    int out[PAR_ON];
+    int ready[PAR_QN];
+    int4 q[PAR_QN];                                    // (start, end, first window j0, -)
+};
+template <int DT>
+// (its LDS -- PAR_W scan scratches and the queue, 58 KB -- admits two workgroups per CU, i.e. two waves per SIMD: the
+//  scan body may keep everything in registers here)
+__global__ __launch_bounds__(64 * PAR_W, 2) void tree_par_kernel(DevCfg c, const TreeJob *__restrict__ jobs, int32_t *scratch,
+                                                  int2 *spill, int32_t *counts, unsigned *status,
+                                                  unsigned long long *work, long long n_jobs_host, const AsmHeader *hdr,
+                                                  int par_max_jobs)
+{
+    extern __shared__ int ys[];                        // PAR_W x SharedT<64>, then the queue
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    SharedT<64> &sh = reinterpret_cast<SharedT<64> *>(ys)[wave];
+    ParQ &Q = *reinterpret_cast<ParQ *>(reinterpret_cast<SharedT<64> *>(ys) + PAR_W);
+    const long long n_jobs = dev_count(hdr, n_jobs_host);
+    // The job count is only known on the device.  With more jobs than workgroup slots one wave per job at four waves per
+    // SIMD has the higher throughput (32 filtered events, 7 232 jobs: 1.24 ms against 2.21 ms here): tree_kernel, launched
+    // behind this kernel with the same limit, takes those calls and this one leaves.
+    if (n_jobs > par_max_jobs) return;
+    unsigned bad = 0;
+    Work wk = PS_WORK_INIT;
+    auto ld = [](const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    for (long long ji = blockIdx.x; ji < n_jobs; ji += gridDim.x) {
+        const TreeJob job = jobs[ji];
+        if (job.out_cap == 0) continue;                // spine anchor without a left subtree (uniform over the workgroup)
+        if (job.out_cap > PAR_ON) {                    // too long for the LDS queue: depth first on one wave
+            if (wave == 0) tree_job<64, DT>(c, nullptr, job, ji, scratch, spill, counts, sh, bad, wk);
+            __syncthreads();
+            continue;
+        }
+        if (threadIdx.x == 0) {
+            Q.head = 0; Q.tail = 1; Q.pending = 1; Q.ocnt = 0;
+            Q.q[0] = make_int4(job.start, job.end, job.j0, 0);
+            Q.ready[0] = 1;
+        }
+        for (int i = 1 + threadIdx.x; i < PAR_QN; i += 64 * PAR_W) Q.ready[i] = 0;
+        __syncthreads();
+        const EvRef er = {job.m, job.boff};
+        for (;;) {
+            // a ticket, then its interval -- or the end of the job
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&Q.head, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            bool have = false;
+            for (;;) {
+                const int r = t < PAR_QN ? ld(&Q.ready[t]) : 0;
+                const int p = ld(&Q.pending);          // (read after `ready`: a slot filled later keeps pending above zero)
+                if (__builtin_amdgcn_readfirstlane(r)) { have = true; break; }
+                if (__builtin_amdgcn_readfirstlane(p) == 0) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!have) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int4 it = Q.q[t];
+            int start = __builtin_amdgcn_readfirstlane(it.x), end = __builtin_amdgcn_readfirstlane(it.y), j0 = __builtin_amdgcn_readfirstlane(it.z);
+            for (;;) {                                 // this interval, then the right parts of its splits
+                int kind;
+                const int sp = find_split<64, DT, false, true, PS_TREE_ROWSKIP>(c, nullptr, job.base, start, end, j0, kind, sh, bad, wk, job.end, er);
+                if (kind == KIND_NONE) {
+                    if (lane == 0) atomicSub(&Q.pending, 1);
+                    break;
+                }
+                if (lane == 0) {
+                    const int o = atomicAdd(&Q.ocnt, 1);
+                    if (o < PAR_ON) Q.out[o] = sp;
+                    if (kind != KIND_EARLY) {          // HIT / LATE: rec(start, sp) goes to the queue (:203); EARLY has no left part (:189-191)
+                        atomicAdd(&Q.pending, 1);
+                        const int i = atomicAdd(&Q.tail, 1);
+                        if (i < PAR_QN) {
+                            Q.q[i] = make_int4(start, sp, left_child_j0(start, sp, c.W, c.half), 0);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __hip_atomic_store(&Q.ready[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+                start = sp; j0 = 0;                    // rec(sp, end)
+            }
+        }
+        __syncthreads();
+        // boundaries by rank (they are distinct), then the count
+        const int cnt = Q.ocnt;
+        if (cnt > PAR_ON || cnt > job.out_cap || Q.tail > PAR_QN) bad |= ST_OUT_OVERFLOW;
+        else {
+            int32_t *out = scratch + job.out_off;
+            for (int i = threadIdx.x; i < cnt; i += 64 * PAR_W) {
+                const int v = Q.out[i];
+                int rank = 0;
+                for (int k = 0; k < cnt; ++k) rank += Q.out[k] < v ? 1 : 0;
+                out[rank] = v;
+            }
+            if (threadIdx.x == 0 && counts && cnt) counts[ji] = cnt;
+        }
+        __syncthreads();                               // the queue is reused by the next job
     }
     flush_wave(bad, wk, status, work, 2);
 }

@@ -25,6 +25,16 @@ constexpr int FILT_PAD = 6;                         // scipy: padlen = 3 * max(l
 
 struct FiltCoef { double b0, b1, a1, alpha, beta, zi; };
 
+// Input of the filter kernels, in the units the caller's c.q scales to pA: ADC counts for fp32 / int16 samples (grid checked,
+// as everywhere), or -- PS_DTYPE_F64, this entry only -- the float64 current itself (c.q = 1): what Event.filter is handed
+// when the event's current was filtered before (DataTypes.py:258-274 filters whatever self.current holds).
+template <int DT>
+__device__ __forceinline__ double filt_load(const DevCfg &c, int64_t idx, unsigned &bad)
+{
+    if constexpr (DT == PS_DTYPE_F64) return static_cast<const double *>(c.samples)[idx];
+    else return static_cast<double>(load_count<DT>(c, idx, bad));
+}
+
 // Sequence element i (0 <= i < total = n + 12) of a pass.
 //   PASS 0 (forward): the odd extension of the samples (in counts; scaled by the caller):  j = i - 6;
 //                     j < 0: 2 x[0] - x[-j];  j >= n: 2 x[n-1] - x[2(n-1) - j];  else x[j]
@@ -81,8 +91,8 @@ __device__ __forceinline__ Affine filt_thread_map(const DevCfg &c, const FiltCoe
     double v[FILT_PER];
     double x_first = 0.0, x_last = 0.0;
     if (PASS == 0) {
-        x_first = static_cast<double>(load_count<DT>(c, 0, bad));
-        x_last = static_cast<double>(load_count<DT>(c, g.n - 1, bad));
+        x_first = filt_load<DT>(c, 0, bad);
+        x_last = filt_load<DT>(c, g.n - 1, bad);
     }
 #pragma unroll
     for (int k = 0; k < FILT_PER; ++k) {
@@ -93,7 +103,7 @@ __device__ __forceinline__ Affine filt_thread_map(const DevCfg &c, const FiltCoe
         else {
             const int64_t j = i - FILT_PAD;
             const int64_t idx = j < 0 ? -j : (j >= g.n ? 2 * (g.n - 1) - j : j);
-            v[k] = static_cast<double>(load_count<DT>(c, idx, bad));
+            v[k] = filt_load<DT>(c, idx, bad);
         }
     }
 #pragma unroll
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(1024) void filt_carry_kernel(DevCfg c, FiltCoef f, 
 {
     unsigned bad = 0;
     const double first = PASS == 1 ? fwd[g.padded - 1]
-                                   : (2.0 * load_count<DT>(c, 0, bad) - static_cast<double>(load_count<DT>(c, FILT_PAD, bad))) * c.q;
+                                   : (2.0 * filt_load<DT>(c, 0, bad) - filt_load<DT>(c, FILT_PAD, bad)) * c.q;
     const double z0 = f.zi * first;
     const int64_t per = (n_chunks + 1023) / 1024;
     const int64_t c0 = static_cast<int64_t>(threadIdx.x) * per, c1 = min(n_chunks, c0 + per);
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(FILT_NT, PS_FILT_OCC) void filt_fused_kernel(DevCfg
 // at the start of the sequence) to H samples behind it, the forward values kept in a private scratch row, then
 // backward from the end of that row (exact zi * last value at the end of the sequence).  The arithmetic per sample is
 // scipy's lfilter's, in its order; only the warm-up replaces the history.  Work: (S + 2H) + (S + H) samples per S.
-constexpr int FILT_MAXORD = 4;
+constexpr int FILT_MAXORD = 8;
 struct FiltN { int order, pad; double b[FILT_MAXORD + 1], a[FILT_MAXORD + 1], zi[FILT_MAXORD]; };
 
 template <int DT>
@@ -343,11 +353,11 @@ __global__ __launch_bounds__(64) void filt_halo_kernel(DevCfg c, FiltN f, int64_
     const int64_t hi = min(m, lo + S);
     const int64_t fs = max(static_cast<int64_t>(0), lo - H), fe = min(m, hi + H);
     unsigned bad = 0;
-    const double x0 = static_cast<double>(load_count<DT>(c, 0, bad)), xl = static_cast<double>(load_count<DT>(c, n - 1, bad));
+    const double x0 = filt_load<DT>(c, 0, bad), xl = filt_load<DT>(c, n - 1, bad);
     auto x_ext = [&](int64_t j) {
         const int64_t jj = j - f.pad;
         const int64_t idx = jj < 0 ? -jj : (jj >= n ? 2 * (n - 1) - jj : jj);
-        const double v = static_cast<double>(load_count<DT>(c, idx, bad));
+        const double v = filt_load<DT>(c, idx, bad);
         return (jj < 0 ? 2.0 * x0 - v : (jj >= n ? 2.0 * xl - v : v)) * c.q;
     };
     double *row = scratch + t * static_cast<int64_t>(S + H);

