@@ -658,6 +658,35 @@ def main():
                           "wide_range_redo": int(tm.get("wide_redo", 0)), "full_exact_scans": int(tm["full_exact_scans"]),
                           "near_ties": int(tm.get("near_ties", 0))},
         }
+        # ---- the same job on what a file holds: int16 ADC counts (read_abf.py:208-210) -------------------------
+        # BASELINE config 3 beside the fp32 headline: one 1e8-sample .abf-shaped int16 trace per stream,
+        # lambda_event_parser(threshold=90) then per-event SpeedyStatSplit, end to end on the GPU, T batches in flight like
+        # the headline; priced at ITS algorithmic bytes, 2 B per sample.  Outside the timed region of `value`.
+        if wl == "trace" and not args.no_detail and world == 1 and n == 100_000_000 and not args.dwell:
+            from pypore_amd import pipeline
+            ftraces = []
+            for t_ in range(T):
+                fe, fl, _ = synth.file_trace_table(n, seed + 1000 * t_)
+                ftraces.append(ctx.synth_trace(n, seed + 1000 * t_, fe, fl, dtype=torch.int16))
+
+            def fstep(cx, k, t):
+                return pipeline.segment_file_trace(ftraces[t], synth.QUANTUM, params, threshold=90.0, ctx=cx)[2]
+
+            pool.run(2 * T, fstep)
+            torch.cuda.synchronize()
+            kf = min(steps, 40)
+            t1 = time.perf_counter()
+            fres = pool.run(kf, fstep)
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - t1) / kf
+            out["int16_file"] = {
+                "workload": "BASELINE config 3: one %.0e-sample int16 .abf-shaped trace per stream @100 kHz, lambda_event_parser("
+                            "threshold=90) -> per-event SpeedyStatSplit, end to end on the GPU, %d batches in flight" % (n, T),
+                "ms_per_step": round(tf * 1e3, 4), "value": round(n / tf / 1e6, 2), "unit": "Msamples/s", "steps": kf,
+                "boundaries": int(fres[-1].numel()),
+                "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": 2 * n, "achieved": round(2 * n / tf / 1e9, 2),
+                             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(2 * n / tf / HBM_PEAK, 5)}}
+            del ftraces
         # ---- PCIe-inclusive rate (report H2D-inclusive separately; never `value`) ------------------
         if wl == "trace" and not args.no_h2d and world == 1:
             P = 8

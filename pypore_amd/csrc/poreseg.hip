@@ -94,6 +94,7 @@ struct ps_ctx {
     int tree_mw = 0;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list (round 3: single-wave workgroups are faster at four waves per SIMD and need no spills)
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
+    int k0_waves = 0;         // > 0: at most this many K0 waves per SIMD (LDS padding), 0: whatever the registers allow (five)
     int tree_par = 1;         // 1: subtree jobs on the 64-bit digest (filtered events: deep recursions) are shared by the waves of a workgroup (tree_par_kernel), 0: one wave per job
     int groups = 1;           // 1: K0 writes group records and the window scans start with the coarse pass over them (narrow digest), 0: every row is swept
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
@@ -716,7 +717,16 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
             HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_pad) * sizeof(int)));
             cfg.blk_mm = ctx->blk_mm.as<int>();
         }
-#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), 0, ctx->stream, cfg,            \
+        // K0 streams: a few waves per SIMD saturate HBM, and at full occupancy (five waves of 82 registers) it leaves no
+        // room on a SIMD for a 128-register scan wave of another call in flight.  Option "k0_waves" caps its waves per SIMD
+        // by giving every workgroup (K0_WAVES waves, one per SIMD of its CU) a share of the CU's 160 KB of LDS it never touches.
+        size_t k0_lds = 0;
+        if (ctx->k0_waves > 0) {
+            const size_t per_wg = (160 * 1024) / static_cast<size_t>(ctx->k0_waves) - 256;
+            const size_t stat = sizeof(int4) * K0_WAVES * K0_WB;
+            k0_lds = per_wg > stat ? std::min<size_t>(per_wg - stat, 64 * 1024 - stat - 256) : 0;
+        }
+#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), k0_lds, ctx->stream, cfg,       \
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
                                     reinterpret_cast<unsigned *>(&sm->status), const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp)))
@@ -843,6 +853,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_GROUPS")) ctx->groups = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TREE_PAR")) ctx->tree_par = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_K0_WAVES")) ctx->k0_waves = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
@@ -898,6 +909,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
     else if (n == "groups") ctx->groups = value != 0;
     else if (n == "tree_par") ctx->tree_par = value != 0;
+    else if (n == "k0_waves" && value >= 0 && value <= 8) ctx->k0_waves = static_cast<int>(value);
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
     else if (n == "tree_tail_pct" && value >= 0 && value <= 100) ctx->tree_tail_pct = static_cast<int>(value);

@@ -106,6 +106,17 @@ __device__ __forceinline__ int wave_max_i32(int x)            // result in lane 
 #undef PS_STEP
     return x;
 }
+// Maximum over the wave of a float that is not NaN (-inf allowed), returned uniform -- through the order-preserving integer
+// image of the float: the compiler folds an integer DPP move into v_max_i32_dpp, while a float maximum costs a move, a
+// canonicalisation and the maximum per step (24 instructions for the six steps instead of 6).
+__device__ __forceinline__ float wave_max_f32(float x)
+{
+    int k = __float_as_int(x);
+    k ^= (k >> 31) & 0x7fffffff;
+    k = __builtin_amdgcn_readlane(wave_max_i32(k), 63);
+    k ^= (k >> 31) & 0x7fffffff;
+    return __int_as_float(k);
+}
 // uniform values into scalar registers (the compiler cannot prove uniformity of what comes out of LDS or a lane read)
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
@@ -1024,10 +1035,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         const bool inr = static_cast<unsigned>(J - cand_lo) <= crange;
         const float bmine = (inr && e.okL && e.okR) ? e.g : -INFINITY;
         float bm = bmine;
-#define PS_STEP(CTRL, RM) { bm = fmaxf(bm, dpp_movf<CTRL, RM>(-INFINITY, bm)); }
-        PS_DPP_STEPS(PS_STEP)
-#undef PS_STEP
-        bm = __int_as_float(lane_get(__float_as_int(bm), 63));
+        bm = wave_max_f32(bm);
         Tprune = fmaxf(thr_log2 - dthr, bm - 2.0f * dlt) - 2.0f * dlt;
         // A window that holds a split (a sampled gain above the threshold band; rows <= 64: windows up to 32 000
         // samples): the same monotone bound as for an 8-sample block, applied to the whole stretch [J, Jb) up to the
@@ -1074,10 +1082,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const bool inr = bval && static_cast<unsigned>(ps + nlc - cand_lo) <= crange;
             const bool eok = bval && e.okL && e.okR;
             float bm = (inr && eok) ? e.g : -INFINITY;
-#define PS_STEP(CTRL, RM) { bm = fmaxf(bm, dpp_movf<CTRL, RM>(-INFINITY, bm)); }
-            PS_DPP_STEPS(PS_STEP)
-#undef PS_STEP
-            bm = __int_as_float(lane_get(__float_as_int(bm), 63));
+            bm = wave_max_f32(bm);
             Tprune = fmaxf(thr_log2 - dthr, bm - 2.0f * dlt) - 2.0f * dlt;
             // the two neighbours of this boundary: group (L-1, L) -- amplitudes in the record of the lane below -- and (L, L+1)
             const bool hasL = lane >= 1, hasR = lane < ngc;
@@ -1289,10 +1294,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             drain();
             if (phase == 0) {
                 float bx = top.b;
-#define PS_STEP(CTRL, RM) { bx = fmaxf(bx, dpp_movf<CTRL, RM>(-INFINITY, bx)); }
-                PS_DPP_STEPS(PS_STEP)
-#undef PS_STEP
-                bx = __int_as_float(lane_get(__float_as_int(bx), 63));
+                bx = wave_max_f32(bx);
                 Tprune = fmaxf(Tprune, fmaxf(thr_log2 - dthr, bx - 2.0f * dlt) - 2.0f * dlt);
             }
         };
@@ -1399,10 +1401,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             // never get here (two instructions per row).
             if (phase == 0 && __ballot(o.ge - 4.0f * dlt > Tprune) != 0ull) {
                 float bx = o.ge;
-#define PS_STEP(CTRL, RM) { bx = fmaxf(bx, dpp_movf<CTRL, RM>(-INFINITY, bx)); }
-                PS_DPP_STEPS(PS_STEP)
-#undef PS_STEP
-                bx = __int_as_float(lane_get(__float_as_int(bx), 63));
+                bx = wave_max_f32(bx);
                 Tprune = fmaxf(Tprune, fmaxf(thr_log2 - dthr, bx - 2.0f * dlt) - 2.0f * dlt);
             }
             const bool keep = static_cast<bool>(static_cast<int>(o.blk) & static_cast<int>(!(o.prunable && o.hb < Tprune)));
@@ -1484,10 +1483,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         // the wave maximum decides the common case; top-2 (DPP) only when something reaches the threshold band
         anyflag = __ballot(flag != 0) != 0ull;
         float mx = top.b;
-#define PS_STEP(CTRL, RM) { mx = fmaxf(mx, dpp_movf<CTRL, RM>(-INFINITY, mx)); }
-        PS_DPP_STEPS(PS_STEP)
-#undef PS_STEP
-        const float ab = __int_as_float(lane_get(__float_as_int(mx), 63));
+        const float ab = wave_max_f32(mx);
         float as = -INFINITY;
         int ai = -1;
         if (!anyflag && ab < thr_log2 - dthr) {

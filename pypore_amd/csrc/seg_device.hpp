@@ -231,11 +231,18 @@ __device__ __forceinline__ float dpp_movf(float identity, float x)
 {
     return __int_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_int(identity), __float_as_int(x)));
 }
+// identity 0: with every row enabled the lanes without a source read 0 through bound_ctrl, and the compiler does not have to
+// initialise the destination first (two moves less per fp64 step of the scans)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov0(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_movd(double x)          // identity 0.0
 {
-    const int lo = dpp_mov<CTRL, ROW_MASK>(0, __double2loint(x));
-    const int hi = dpp_mov<CTRL, ROW_MASK>(0, __double2hiint(x));
+    const int lo = dpp_mov0<CTRL, ROW_MASK>(__double2loint(x));
+    const int hi = dpp_mov0<CTRL, ROW_MASK>(__double2hiint(x));
     return __hiloint2double(hi, lo);
 }
 #define PS_DPP_STEPS(X) X(0x111, 0xf) X(0x112, 0xf) X(0x114, 0xf) X(0x118, 0xf) X(0x142, 0xa) X(0x143, 0xc)

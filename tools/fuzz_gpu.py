@@ -16,7 +16,7 @@ bad = 0
 SCALE = int(os.environ.get("FUZZ_SCALE", "1"))
 Q = synth.QUANTUM / SCALE
 routes = {}
-shifted = unchecked = 0
+shifted = unchecked = cross = 0
 for seed in range(n_seeds):
     rng = np.random.RandomState(10_000 + seed + int(os.environ.get("FUZZ_BASE", "0")))
     mw = int(rng.choice([8, 20, 100, 250]))
@@ -55,7 +55,9 @@ for seed in range(n_seeds):
     # The reference's own prefix sums are exact only while n_event * max|k|^2 < 2^53.  Beyond that
     # (possible with FUZZ_SCALE > 1) its rounding decides near-ties, so the check is against the oracle on the same
     # event with its first sample subtracted -- the gains are shift invariant and those sums are exact -- if that is
-    # inside the domain, and the event is left unchecked otherwise.
+    # inside the domain; an event outside even that (none of the reference's sums is exact: its decisions on near ties are
+    # its own rounding noise) is compared between the two device routes that share no scan code -- the block-sum scan on
+    # the 64-bit digest and the LDS-window kernels (wide_bs = 0) -- which both form exact window-local sums.
     refs = []
     for k in evs:
         if len(k) * float(np.abs(k).max()) ** 2 < 2.0 ** 53:
@@ -81,7 +83,27 @@ for seed in range(n_seeds):
             bad += 1
             print("ERROR seed", seed, "mode", mode, params, "sigma", sigma, "dc", dc, "i16", use_i16, repr(ex)[:300])
     ctx.set_option("mode", 0)
+    if any(r is None for r in refs):
+        try:
+            b1, o1, _ = ctx.segment_events(dev, np.array(starts, dtype=np.int64), np.array(lens, dtype=np.int64), sp, Q, want_stats=False)
+            r1 = ctx.timings()["wide_redo"]
+            ctx.set_option("wide_bs", 0)
+            b2, o2, _ = ctx.segment_events(dev, np.array(starts, dtype=np.int64), np.array(lens, dtype=np.int64), sp, Q, want_stats=False)
+            r2 = ctx.timings()["wide_redo"]
+            b1, b2 = b1.cpu().numpy(), b2.cpu().numpy()
+            for e in range(n_ev):
+                if refs[e] is None:
+                    cross += 1
+                    if r1 == r2 or not np.array_equal(b1[o1[e]:o1[e + 1]], b2[o2[e]:o2[e + 1]]):
+                        bad += 1
+                        print("ROUTE MISMATCH seed", seed, "event", e, params, "routes", r1, r2)
+        except Exception as ex:
+            bad += 1
+            print("ERROR (route check) seed", seed, repr(ex)[:300])
+        finally:
+            ctx.set_option("wide_bs", 1)
 print("fuzz: %d seeds, %d problems, %.0f s, scale %d, calls per route (0 32-bit digest, 1 64-bit digest, 2 LDS-window) %s, "
-      "events beyond the reference's exact sums: %d checked on the shifted event, %d unchecked; counters %s"
-      % (n_seeds, bad, time.time() - t0, SCALE, routes, shifted, unchecked, ctx.timings()))
+      "events beyond the reference's exact sums: %d checked on the shifted event, %d beyond that too, of which %d compared "
+      "between the 64-bit digest and the LDS-window route; counters %s"
+      % (n_seeds, bad, time.time() - t0, SCALE, routes, shifted, unchecked, cross, ctx.timings()))
 sys.exit(1 if bad else 0)
