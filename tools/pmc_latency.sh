@@ -1,6 +1,8 @@
 #!/bin/bash
 # average latency of the vector / scalar / LDS memory instructions of the scan kernels: SQ_INST_LEVEL_x / SQ_INSTS_x
-ROOT=$PWD; export TMPDIR=/tmp; mkdir -p $ROOT/gpurun_out; cd /tmp
+ROOT=$PWD; export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
+mkdir -p $ROOT/gpurun_out; cd /tmp
 run() { name=$1; shift
   rm -rf /tmp/prof_$name
   rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -o out --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --no-detail --streams 1 > /tmp/prof_$name.log 2>&1

@@ -9,10 +9,14 @@
 #   <tag>_pmc_summary.txt       PMC passes (tools/pmc_run.sh, --streams 1: instruction counts, traffic of one call at a time)
 #   <tag>_pmc4_summary.txt      the same passes with four calls in flight on four DISTINCT traces (--streams 4): what the
 #                               headline configuration fetches; <tag>_pmc_traffic.json: HBM bytes per launch from both
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$PWD
 export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out
+# (bench.py sets this itself, but under rocprofv3 the tool library may start the runtime first: the profiles and the headline
+#  must run on the same number of hardware queues -- ADVICE r3)
+export GPU_MAX_HW_QUEUES=8
+echo "GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES" > $ROOT/gpurun_out/${TAG}_profile_env.txt
 cd /tmp
 for s in 4 1; do
   rm -rf /tmp/kstats
