@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
     // kernel 0.68 ms against 0.90 ms on half of them.)
     long long G = gridDim.x;
     if (jobs_per_wave > 0) {
-        G = max(G / 2, min(G, n_jobs / jobs_per_wave));
+        G = max(1LL, max(G / 2, min(G, n_jobs / jobs_per_wave)));      // (never 0: a one-workgroup grid with fewer than jobs_per_wave jobs)
         if (static_cast<long long>(blockIdx.x) >= G) return;
     }
     unsigned bad = 0;

@@ -4,6 +4,7 @@ compute is in the HIP kernels behind the C ABI.
 """
 import collections
 import ctypes
+import threading
 import warnings
 
 import numpy as np
@@ -444,6 +445,7 @@ def _int_counts_tensor(counts, dev):
 _STAGE_MIN = 1 << 22                                    # samples: below this one pageable copy is as fast
 _STAGE_CHUNK = 1 << 24                                  # int16 samples per staging buffer (32 MB)
 _stage = {}
+_stage_lock = threading.Lock()                          # the staging buffers of a device are shared: one upload at a time
 
 
 def _staged_upload(counts, dev):
@@ -451,23 +453,27 @@ def _staged_upload(counts, dev):
     pinned staging buffers: the host's copy of chunk k+1 out of the page cache runs while chunk k crosses PCIe.  One
     `np.ascontiguousarray` of the whole file plus a pageable copy of it is 2-3 x slower (tools/bench_experiment.py)."""
     key = dev.index
-    if key not in _stage:
-        _stage[key] = ([torch.empty(_STAGE_CHUNK, dtype=torch.int16, pin_memory=True) for _ in range(2)],
-                       [torch.cuda.Event() for _ in range(2)], torch.cuda.Stream(device=dev))
-    bufs, events, stream = _stage[key]
-    out = torch.empty(counts.size, dtype=torch.int16, device=dev)
-    used = [False, False]
-    with torch.cuda.stream(stream):
-        for k, a in enumerate(range(0, counts.size, _STAGE_CHUNK)):
-            b = min(counts.size, a + _STAGE_CHUNK)
-            i = k & 1
-            if used[i]:
-                events[i].synchronize()                  # the copy that last read this buffer is done
-            np.copyto(bufs[i].numpy()[:b - a], counts[a:b])
-            out[a:b].copy_(bufs[i][:b - a], non_blocking=True)
-            events[i].record(stream)
-            used[i] = True
-    stream.synchronize()
+    with _stage_lock:                                    # (two host threads uploading to one device would overwrite each other's chunks)
+        if key not in _stage:
+            _stage[key] = ([torch.empty(_STAGE_CHUNK, dtype=torch.int16, pin_memory=True) for _ in range(2)],
+                           [torch.cuda.Event() for _ in range(2)], torch.cuda.Stream(device=dev))
+        bufs, events, stream = _stage[key]
+        out = torch.empty(counts.size, dtype=torch.int16, device=dev)
+        # `out` comes from the caching allocator on the CURRENT stream: work still queued there on a recycled block must
+        # be finished before the side stream writes into it
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        used = [False, False]
+        with torch.cuda.stream(stream):
+            for k, a in enumerate(range(0, counts.size, _STAGE_CHUNK)):
+                b = min(counts.size, a + _STAGE_CHUNK)
+                i = k & 1
+                if used[i]:
+                    events[i].synchronize()              # the copy that last read this buffer is done
+                np.copyto(bufs[i].numpy()[:b - a], counts[a:b])
+                out[a:b].copy_(bufs[i][:b - a], non_blocking=True)
+                events[i].record(stream)
+                used[i] = True
+        stream.synchronize()
     return out
 
 

@@ -10,6 +10,8 @@ works on exact integer sums of the counts, so the float64 array has to find its 
   the int16 route (2 B/sample over PCIe and HBM) without the caller doing anything.
 * affine_grid() -- recovers (quantum, offset, counts) from a bare float64 array `k * q + o` of any origin.
 """
+import threading
+
 import numpy as np
 
 
@@ -109,8 +111,43 @@ class Deferred(object):
     float64 device tensor (`from_tensor`), or a stretch of another Deferred (slices share the parent's array once it
     exists)."""
 
-    live_device_bytes = 0                                # float64 results parked on the GPU (see from_tensor)
-    DEVICE_BYTES_MAX = 16 << 30
+    live_device_bytes = 0                                # bytes parked on GPUs, all devices (see from_tensor, device_counts)
+    DEVICE_BYTES_MAX = 16 << 30                          # per device, and never more than a quarter of its memory
+    _lock = threading.Lock()                             # the accounting is shared by the host threads of a process
+    _by_device = {}                                      # device index -> bytes parked there
+
+    @classmethod
+    def _park(cls, dev_key, nbytes):
+        """Reserve `nbytes` of the budget of parked tensors on device `dev_key` (None: no device, the accounting only).
+        The budget is DEVICE_BYTES_MAX, at most a quarter of the device's memory, and nothing at all while less than a
+        tenth of the device is free -- an Experiment over many files, or several ranks on one GPU, must not run the
+        allocator dry where the eager route (copy to the host at once) would have worked."""
+        with cls._lock:
+            cap = cls.DEVICE_BYTES_MAX
+            if dev_key is not None:
+                try:
+                    import torch
+                    free, total = torch.cuda.mem_get_info(dev_key)
+                    cap = 0 if free < total // 10 else min(cap, total // 4)
+                except Exception:
+                    pass
+            used = cls._by_device.get(dev_key, 0)
+            if used + nbytes > cap:
+                return False
+            cls._by_device[dev_key] = used + nbytes
+            cls.live_device_bytes += nbytes
+            return True
+
+    @classmethod
+    def _unpark(cls, dev_key, nbytes):
+        with cls._lock:
+            cls._by_device[dev_key] = cls._by_device.get(dev_key, 0) - nbytes
+            cls.live_device_bytes -= nbytes
+
+    @staticmethod
+    def _dev_key(tensor):
+        dev = getattr(tensor, "device", None)
+        return dev.index if dev is not None and getattr(dev, "type", "") == "cuda" else None
 
     def __init__(self, n, make, counts=None, quantum=None, offset=0.0, parent=None, start=0):
         self._n, self._make, self._value = int(n), make, None
@@ -131,10 +168,11 @@ class Deferred(object):
         nbytes = tensor.numel() * tensor.element_size()
         d = cls(tensor.numel(), None, offset=offset)
         d.tensor = tensor                                # (built in value(): a closure over `d` would keep it alive)
-        d._parked = nbytes
-        Deferred.live_device_bytes += nbytes
-        if Deferred.live_device_bytes > Deferred.DEVICE_BYTES_MAX:
-            d.value()
+        d._park_key = cls._dev_key(tensor)
+        if cls._park(d._park_key, nbytes):
+            d._parked = nbytes
+        else:
+            d.value()                                    # over the budget: to the host right away, the tensor is let go
         return d
 
     def device_counts(self, dev, upload):
@@ -148,11 +186,12 @@ class Deferred(object):
         if cached is None or cached.device != dev:
             if self is not root and 4 * self._n < root._n:
                 return upload(self.counts, dev)          # a short stretch of a file nobody has sent up: only the stretch
+            if cached is not None:                       # parked on another device: that copy is given up first
+                root._release_counts()
             cached = upload(root.counts, dev)
             nbytes = cached.numel() * cached.element_size()
-            if Deferred.live_device_bytes + nbytes <= Deferred.DEVICE_BYTES_MAX:
-                root._dev_counts, root._parked_counts = cached, nbytes
-                Deferred.live_device_bytes += nbytes
+            if Deferred._park(Deferred._dev_key(cached), nbytes):
+                root._dev_counts, root._parked_counts, root._counts_key = cached, nbytes, Deferred._dev_key(cached)
         if self is root:
             return cached
         part = cached[self._start:self._start + self._n]
@@ -160,13 +199,16 @@ class Deferred(object):
         #  an allocation boundary is copied -- device to device, microseconds)
         return part.clone() if part.data_ptr() % 256 else part
 
-    def _release(self):
+    def _release_counts(self):
         if getattr(self, "_parked_counts", 0):
-            Deferred.live_device_bytes -= self._parked_counts
+            Deferred._unpark(getattr(self, "_counts_key", None), self._parked_counts)
             self._parked_counts = 0
-            self.__dict__.pop('_dev_counts', None)
+        self.__dict__.pop('_dev_counts', None)
+
+    def _release(self):
+        self._release_counts()
         if getattr(self, "_parked", 0):
-            Deferred.live_device_bytes -= self._parked
+            Deferred._unpark(getattr(self, "_park_key", None), self._parked)
             self._parked = 0
         self.tensor = None
 
