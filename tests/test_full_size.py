@@ -41,7 +41,8 @@ def test_config2_full_1024_events(ctx, mode):
     ev_off = np.arange(n_ev + 1, dtype=np.int64) * n
     try:
         bounds, boff, stats = ctx.segment_batch(t, ev_off, _lib.split_params(**DEF), synth.QUANTUM, want_stats=True)
-        if mode == 2:
+        # (the counter of whole-window fp64 scans belongs to the block-sum scan of the device-stitch pipeline: the default)
+        if mode == 2 and not (os.environ.get("PORESEG_SCAN_BS") or os.environ.get("PORESEG_STITCH")):
             assert ctx.timings()["full_exact_scans"] >= ctx.timings()["windows"] > 2 * n_ev     # every window was scanned twice
     finally:
         ctx.set_option("mode", int(os.environ.get("PORESEG_MODE", "0")))      # (what the context started with: tools/gpu_validate.sh)

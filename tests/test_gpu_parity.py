@@ -283,7 +283,8 @@ def test_1e8_trace_digest(ctx, mode):
     ctx.set_option("mode", mode)
     try:
         bounds, boff, _ = ctx.segment_batch(t, np.array([0, n]), params, synth.QUANTUM, want_stats=False)
-        if mode == 2:
+        # (the counter of whole-window fp64 scans belongs to the block-sum scan of the device-stitch pipeline: the default)
+        if mode == 2 and not (os.environ.get("PORESEG_SCAN_BS") or os.environ.get("PORESEG_STITCH")):
             assert ctx.timings()["full_exact_scans"] >= ctx.timings()["windows"] > 30000
     finally:
         ctx.set_option("mode", int(os.environ.get("PORESEG_MODE", "0")))      # (what the context started with: tools/gpu_validate.sh)
