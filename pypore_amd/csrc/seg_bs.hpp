@@ -684,9 +684,6 @@ __device__ __forceinline__ long long bs_from_lane(long long x, int byte_index)
 __device__ __forceinline__ double bs_from_lane(double x, int byte_index) { return __longlong_as_double(bs_from_lane(__double_as_longlong(x), byte_index)); }
 #define PS_TREE_SAMPLE 0                                  // 1: subtree windows run the sampling pass too (measured: see scan_window_bs)
 #endif
-#ifndef PS_ROWS_ALIGNED
-#define PS_ROWS_ALIGNED 0                                 // 1: windows with a coarse pass sweep rows of 64 blocks aligned to pairs of groups (see scan_window_bs)
-#endif
 #ifndef PS_EDGE_PRELOAD
 #define PS_EDGE_PRELOAD 1                                 // windows with a coarse pass request the rows of their two ends with the setup loads
 #endif
@@ -878,6 +875,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     const ent_t *bsw = static_cast<const ent_t *>(c.bsum) + gb0;      // bsw[t]: chunk prefix at boundary t = 0..nblk
     const long long c0 = gb0 >> BS_CHUNK_LOG;
     const int rows = (nblk + BS_STRIDE - 1) / BS_STRIDE;               // nblk + 1 boundaries, 63 new ones per row
+    auto row_load = [&](int r) { return bsw[min(max(r, 0) * BS_STRIDE + lane, nblk)]; };
     // everything the window needs before its first boundary, issued together
     const int nh = g0 - ps, nt = pe - g1;              // ragged head [ps, g0) and tail [g1, pe): <= 7 raw samples each
     // (loaded by every lane from a clamped index and converted after all of the setup's loads are out: under a lane
@@ -915,28 +913,12 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         const uint4 *gp = coarse ? static_cast<const uint4 *>(c.grp) + G0 : reinterpret_cast<const uint4 *>(bsw);
         gent = gp[coarse ? min(lane, max(ngc, 0)) : 0];
     }
-    // Row geometry.  Default: row r holds boundaries 63 r .. 63 r + 63 (lane 0 repeats the previous row's last boundary, so
-    // that every block finds its left neighbour one lane below).  PS_ROWS_ALIGNED, windows with a coarse pass: rows of 64
-    // blocks aligned to PAIRS OF GROUPS in the global block index -- row r holds the blocks 64 (A0 + r) .. + 63, lane L
-    // evaluates the right boundary of its block, t = 64 (A0 + r) + L + 1 - gb0, and lane 0 takes its left neighbour, which
-    // is a group boundary, from the coarse pass (values kept in registers: cg_*).  A surviving group then costs half a row
-    // instead of one or two.
-    constexpr bool ALIGNED = GROUPS && PS_ROWS_ALIGNED;
-    const long long A0 = gb0 >> 6;
-    const int rowsA = static_cast<int>(((gb0 + nblk - 1) >> 6) - A0) + 1;
-    const bool al = ALIGNED && ngc >= 1 && rowsA <= 64;                    // (uniform)
-    const int nrows = al ? rowsA : rows;
-    auto tbase = [&](int r) { return al ? static_cast<int>(64 * (A0 + max(r, 0)) + 1 - gb0) : max(r, 0) * BS_STRIDE; };   // boundary of lane 0 in row r
-    auto row_load = [&](int r) { return bsw[min(max(tbase(r) + lane, 0), nblk)]; };
-    float cg_lgx = 0.0f, cg_rrx = 0.0f;                // coarse pass, per lane = group boundary: log2 V_L - c0, 1 / k (negative: not sound),
-    int cg_a1 = 0;                                     // exact sums of [ps, boundary)
-    double cg_a2 = 0.0;
     ent_t ring[BS_D];                                  // rows in flight
     // (a window with a coarse pass sweeps its live rows only, and the rows at its two ends practically always are -- the
     //  first and last groups cannot be bounded: they are requested here, with the rest of the setup, so that the sweep
     //  does not start with a round trip of its own; the other windows start with rows 0 .. 3)
     const bool edge_rows = PS_EDGE_PRELOAD && GROUPS && ngc >= 1;         // (uniform)
-    auto pre_row = [&](int i) { return !edge_rows ? i : i == 0 ? 0 : i == 1 ? nrows - 1 : i == 2 ? 1 : nrows - 2; };
+    auto pre_row = [&](int i) { return !edge_rows ? i : i == 0 ? 0 : i == 1 ? rows - 1 : i == 2 ? 1 : rows - 2; };
 #pragma unroll
     for (int i = 0; i < BS_D; ++i) ring[i] = row_load(pre_row(i));
     if (lane >= nch) ct = make_int4(0, 0, 0, 0);
@@ -1122,10 +1104,6 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const float GA = (eok && okF) ? e.g + A : INFINITY;             // (A itself is +inf when the expansion does not apply)
             ghb = fmaxf(GA, from_lane_below(GA));
             hitlike = true;
-            if constexpr (ALIGNED) {
-                cg_lgx = e.lg.x; cg_rrx = (bval && e.okL) ? e.r.x : -1.0f;
-                cg_a1 = a1i; cg_a2 = bs_d(a2);
-            }
             if constexpr (AUDIT) {
                 // lane L walks the 255 candidates inside its group (L-1, L) from the sums at the boundary below
                 const int a1b = from_lane_below(a1i);
@@ -1188,16 +1166,11 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 // row r holds the blocks 63 r + 1 .. min(63 r + 63, nblk) (block t lies left of boundary t); the group of a block
                 // is the group of its left boundary; bit L of `dead`: group (L-1, L) is below the pruning level
                 const unsigned long long dead = __ballot(lane >= 1 && lane <= ngc && ghb < Tprune);
-                int lo, hi;
-                if (al) {                              // aligned row r: the groups 2 (A0 + r) and 2 (A0 + r) + 1, i.e. lanes lo, lo + 1
-                    lo = static_cast<int>(2 * (A0 + lane) - G0) + 1; hi = lo + 1;
-                } else {
-                    const int tl = BS_STRIDE * lane, th = min(tl + BS_STRIDE, nblk) - 1;
-                    lo = static_cast<int>(((gb0 + tl) >> BS_GRP_LOG) - G0) + 1; hi = static_cast<int>(((gb0 + th) >> BS_GRP_LOG) - G0) + 1;
-                }
+                const int tl = BS_STRIDE * lane, th = min(tl + BS_STRIDE, nblk) - 1;
+                const int lo = static_cast<int>(((gb0 + tl) >> BS_GRP_LOG) - G0) + 1, hi = static_cast<int>(((gb0 + th) >> BS_GRP_LOG) - G0) + 1;
                 const unsigned long long span = ((2ull << (hi - lo)) - 1ull) << max(lo, 0);
-                live = __ballot(lane < nrows && !(lo >= 1 && hi <= ngc && (dead & span) == span));
-                if constexpr (AUDIT) live = __ballot(lane < nrows);
+                live = __ballot(lane < rows && !(lo >= 1 && hi <= ngc && (dead & span) == span));
+                if constexpr (AUDIT) live = __ballot(lane < rows);
             }
         } else if (hitlike) {
             const unsigned long long dead = __ballot(cbound < Tprune);
@@ -1334,12 +1307,11 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             wk.ph[8] += 1;                                                 // (diagnostic build) rows swept
 #endif
             const bool first_row = r == 0;
-            const int t0 = tbase(r);                                       // (uniform) boundary of lane 0
-            const int tb = gbl + t0;                                       // (uniform) chunk-relative index of the row's first boundary
+            const int tb = gbl + BS_STRIDE * r;                            // (uniform) chunk-relative index of the row's first boundary
 #if PS_ROW_OFFSETS_BPERMUTE
             // every lane fetches the offsets of ITS chunk from the lane that holds them (ds_bpermute: three or four LDS-pipe
             // instructions and the index) -- two v_readlane per value plus moves and selects were 22 instructions a row
-            const int cb = min(max(tb + lane, 0) >> BS_CHUNK_LOG, nch - 1) << 2;
+            const int cb = min((tb + lane) >> BS_CHUNK_LOG, nch - 1) << 2;
             const s1_t o1 = bs_from_lane(off1, cb);
             const o2_t o2 = bs_from_lane(off2, cb);
 #else
@@ -1351,7 +1323,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const s1_t o1 = second ? o1B : o1A;
             const o2_t o2 = second ? o2B : o2A;
 #endif
-            const int nl = nl0 + 8 * t0, J = ps + nl;                       // (aligned first row: negative for the lanes in front of the window)
+            const int nl = nl0 + 8 * BS_STRIDE * r, J = ps + nl;
             const float nlf = static_cast<float>(nl);
             const double nld = static_cast<double>(nl);
             const s1_t a1 = bs_a1(cur, o1);
@@ -1375,22 +1347,12 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const bool valid = static_cast<unsigned>(nl - 1) < static_cast<unsigned>(n - 1);    // 1 <= nl <= n-1 (false past the end)
             const bool okL = valid && u.x >= vfloor, okR = valid && u.y >= vfloor;
             // the boundary itself as a candidate (lane 0 of rows > 0 repeats a boundary already counted)
-            const bool inr = static_cast<unsigned>(J - cand_lo) <= crange && (al || lane != 0 || first_row) && nl >= 1;
+            const bool inr = static_cast<unsigned>(J - cand_lo) <= crange && (lane != 0 || first_row);
             const float ge = (inr && okL && okR) ? g : -INFINITY;
             // the block (J - 8, J): left side bounded from boundary t-1 (the lane below), right side from this one
-            float aL = from_lane_below(lg.x), rlb = from_lane_below(rr.x);
-            bool pokL = from_lane_below(static_cast<int>(okL)) != 0;
-            if constexpr (ALIGNED) {
-                if (al) {                              // lane 0: its left boundary is group boundary cgl of the coarse pass
-                    const int cgl = min(max(static_cast<int>(2 * (A0 + r) - G0), 0), 63);
-                    const float xl = __int_as_float(lane_get(__float_as_int(cg_lgx), cgl)), xr = __int_as_float(lane_get(__float_as_int(cg_rrx), cgl));
-                    aL = lane == 0 ? xl : aL;
-                    rlb = lane == 0 ? fabsf(xr) : rlb;
-                    pokL = lane == 0 ? xr > 0.0f : pokL;
-                }
-            }
-            // (a block: its left boundary lies in the window -- t >= 1 -- and it has interior candidates)
-            const bool blk = (al ? t0 + lane >= 1 : lane >= 1) && static_cast<unsigned>(J - 1 - cand_lo) <= crange + 6u;
+            const float aL = from_lane_below(lg.x), rlb = from_lane_below(rr.x);
+            const bool pokL = from_lane_below(static_cast<int>(okL)) != 0;
+            const bool blk = lane >= 1 && static_cast<unsigned>(J - 1 - cand_lo) <= crange + 6u;   // has interior candidates
             const float nl0f = nlf - 8.0f, nlef = nlf - 1.0f;
             const float nr0f = nrf + 8.0f, nref = nrf + 1.0f;
             const float bR = lg.y, rre = rr.y;
@@ -1404,29 +1366,13 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             return RowOut{a1, a2, nl, ge, fmaxf(h0, h1), blk, prunable, inr && !(okL && okR)};
         };
         // (the part with side effects, in row order: per-lane top-2, the block queue, the contender list)
-        // sums of [ps, left boundary of this lane's block): the lane below's -- aligned rows, lane 0: the coarse pass's
-        // (narrow digest only: the 64-bit one keeps no block sums next to its queue)
-        auto left_a1 = [&](int a1, int r) -> int {
-            int v = from_lane_below(a1);
-            if constexpr (ALIGNED) {
-                if (al) { const int x = lane_get(cg_a1, min(max(static_cast<int>(2 * (A0 + r) - G0), 0), 63)); v = lane == 0 ? x : v; }
-            }
-            return v;
-        };
-        auto left_a2 = [&](double a2, int r) -> double {
-            double v = __hiloint2double(from_lane_below(__double2hiint(a2)), from_lane_below(__double2loint(a2)));
-            if constexpr (ALIGNED) {
-                if (al) { const double x = lane_get(cg_a2, min(max(static_cast<int>(2 * (A0 + r) - G0), 0), 63)); v = lane == 0 ? x : v; }
-            }
-            return v;
-        };
-        auto row_commit = [&](const RowOut &o, int r) {
+        auto row_commit = [&](const RowOut &o) {
             PS_MARK(row_commit_begin);
             if constexpr (AUDIT && !WIDE) {
                 if (phase == 0) {
                     // the 7 candidates inside the block (J - 8, J), from the sums at the boundary below and the raw samples
-                    const int a1p = left_a1(o.a1, r);
-                    const double a2p = left_a2(o.a2, r);
+                    const int a1p = from_lane_below(o.a1);
+                    const double a2p = __hiloint2double(from_lane_below(__double2hiint(o.a2)), from_lane_below(__double2loint(o.a2)));
                     const int nlp = o.nl - 8;
                     if (o.blk && nlp >= 1 && o.nl <= n - 1) {
                         int x1 = a1p;
@@ -1467,8 +1413,8 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 int2 bsum = make_int2(0, 0);
                 if constexpr (!WIDE && PS_DRAIN_FILTER) {
                     // the block's own sums: this boundary's minus the one below (all lanes are here: the branch is the wave's)
-                    const double a2b = left_a2(o.a2, r);
-                    bsum = make_int2(o.a1 - left_a1(o.a1, r), static_cast<int>(static_cast<unsigned>(o.a2 - a2b)));
+                    const double a2b = __hiloint2double(from_lane_below(__double2hiint(o.a2)), from_lane_below(__double2loint(o.a2)));
+                    bsum = make_int2(o.a1 - from_lane_below(o.a1), static_cast<int>(static_cast<unsigned>(o.a2 - a2b)));
                 }
                 if (keep) {
                     BsQ_t q;
@@ -1482,7 +1428,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             if (phase) PS_COLLECT(o.ge >= Tc, o.ge, ps + o.nl, o.a1, o.a2)
             PS_MARK(row_commit_end);
         };
-        auto do_row = [&](int r, const ent_t &cur) { row_commit(row_eval(r, cur), r); };
+        auto do_row = [&](int r, const ent_t &cur) { row_commit(row_eval(r, cur)); };
         // One row at a time (no interleaving of rows: the four waves of the SIMD cover each other's latencies, and a row
         // evaluated alone keeps the kernel at 128 registers); its slot of the ring is refilled as soon as it is free.
         if (!hitlike) {
@@ -1509,7 +1455,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             for (int i = 0; i < BS_D; ++i) {
                 // (phase 0 of a window with a coarse pass: the slot already holds a row of the window's ends; taken if live)
                 const int pr = pre_row(i);
-                const bool have = GROUPS && phase == 0 && edge_rows && pr >= 0 && pr < nrows && ((live >> pr) & 1ull) != 0ull;
+                const bool have = GROUPS && phase == 0 && edge_rows && pr >= 0 && pr < rows && ((live >> pr) & 1ull) != 0ull;
                 if (have) { rr[i] = pr; live &= ~(1ull << pr); }
                 else { rr[i] = take_row(); ring[i] = row_load(rr[i]); }
             }
