@@ -1689,9 +1689,12 @@ __global__ __launch_bounds__(64 * PAR_W, 2) void tree_par_kernel(DevCfg c, const
                     const int o = atomicAdd(&Q.ocnt, 1);
                     if (o < PAR_ON) Q.out[o] = sp;
                     if (kind != KIND_EARLY) {          // HIT / LATE: rec(start, sp) goes to the queue (:203); EARLY has no left part (:189-191)
-                        atomicAdd(&Q.pending, 1);
+                        // (the slot first: an interval that found no slot -- impossible while boundaries are min_width apart,
+                        //  out_cap bounds their number -- must not be counted as unfinished, or nobody would ever see zero;
+                        //  this wave's own interval keeps `pending` above zero meanwhile)
                         const int i = atomicAdd(&Q.tail, 1);
                         if (i < PAR_QN) {
+                            atomicAdd(&Q.pending, 1);
                             Q.q[i] = make_int4(start, sp, left_child_j0(start, sp, c.W, c.half), 0);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             __hip_atomic_store(&Q.ready[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
