@@ -529,12 +529,7 @@ def main():
                     check["g7_sha256_equal"] = bool(hashlib.sha256(b0.tobytes()).hexdigest() == g7["sha256"] and len(b0) == g7["n_bounds"])
                 except (OSError, IndexError, KeyError):
                     check["g7_sha256_equal"] = None
-            # (PORESEG_BENCH_NOCHECK=1: instruction-count experiments with library variants that are wrong on purpose,
-            #  tools/gpu_r4_cut.sh; the line then says so)
-            if os.environ.get("PORESEG_BENCH_NOCHECK") == "1":
-                check["checks_enforced"] = False
-            else:
-                assert check["all_streams_equal_single_stream"] and check.get("g7_sha256_equal", True) is not False, check
+            assert check["all_streams_equal_single_stream"] and check.get("g7_sha256_equal", True) is not False, check
         if use_dist:
             n_bounds = jg.last_counts()                               # the last batch's boundaries, all ranks
             # (the last batch ran on stream (steps - 1) % T, i.e. on that stream's trace)

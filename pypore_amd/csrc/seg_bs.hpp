@@ -983,9 +983,6 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     }
     PS_STAMP_AT(wk, 5);                                // setup loads + head / tail / chunk scans
     PS_MARK(setup_done);
-#if defined(PS_CUT) && PS_CUT == 1
-    return uni(static_cast<int>(T1) == 0x7fffffff ? 0 : -1);       // (instruction-count experiment: WRONG results, never the product)
-#endif
     const double T1d = uni(bs_d(T1)), T2d = uni(bs_d(T2));                // window totals about m
     const double dn = static_cast<double>(n);
     const double Dtot = dn * T2d - T1d * T1d;
@@ -1130,9 +1127,6 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     }
     PS_STAMP_AT(wk, 0);                                // totals, pruning level from the sampled boundaries
     PS_MARK(coarse_done);
-#if defined(PS_CUT) && PS_CUT == 2
-    return uni(__ballot(ghb < Tprune) == 0x123456789ull ? 0 : -1);  // (instruction-count experiment: WRONG results, never the product)
-#endif
 #ifdef PS_STAMP
     wk.ph[11] += hitlike;
 #endif
@@ -1472,13 +1466,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                 }
             }
         }
-#if defined(PS_CUT) && PS_CUT == 3
-        return uni(__ballot(top.b > 1.0e30f) != 0ull ? 0 : -1);    // (instruction-count experiment: WRONG results, never the product)
-#endif
         drain();
-#if defined(PS_CUT) && PS_CUT == 4
-        return uni(__ballot(top.b > 1.0e30f) != 0ull ? 0 : -1);    // (instruction-count experiment: WRONG results, never the product)
-#endif
         if (phase == 1) break;
         // the wave maximum decides the common case; top-2 (DPP) only when something reaches the threshold band
         anyflag = __ballot(flag != 0) != 0ull;
