@@ -671,3 +671,39 @@ def test_large_dc_offset_on_a_fine_grid(ctx):
             ctx.set_option("mode", int(os.environ.get("PORESEG_MODE", "0")))
         np.testing.assert_array_equal(_bounds(segs), ref)
         assert ctx.timings()["wide_redo"] == 0
+
+
+@pytest.mark.parametrize("option,value,default", [("groups", 0, 1), ("tree_par", 0, 1), ("k0_waves", 2, 0), ("k0_waves", 1, 0)])
+def test_round4_options_change_no_result(ctx, option, value, default):
+    """The switches of round 4 -- the coarse pass over the group records, the deep subtree jobs shared by the waves of a
+    workgroup, K0's occupancy cap -- are tuning knobs: same boundaries with each of them off, on the narrow digest (dense
+    steps: many splits per window; long dwells: most windows hold none) and on the 64-bit digest (a filtered, re-quantised
+    event: few deep jobs, the case tree_par_kernel is chosen for on the device), also in verify mode."""
+    import torch
+    from pypore_amd import _lib, engine
+    p = _lib.split_params(prior_segments_per_second=10.)
+    cases = []
+    for seed, lo, hi in ((41, 150, 1500), (42, 3000, 60000)):
+        k = synth.random_dwell_counts(700000, seed, lo, hi)
+        cases.append((torch.from_numpy(synth.counts_to_pa(k, np.float32)).cuda(), synth.QUANTUM, 0))
+    k = synth.random_dwell_counts(400000, 43, 1000, 20000)
+    y = ctx.filter_bessel(torch.from_numpy(k.astype(np.int16)).cuda(), synth.QUANTUM)
+    z, _, step = ctx.requantise(y)
+    cases.append((z, step, 1))
+    want = []
+    for t, q, route in cases:
+        b, _, _ = ctx.segment_batch(t, np.array([0, t.numel()], dtype=np.int64), p, q, want_stats=False)
+        assert b.numel() > 20
+        if not (os.environ.get("PORESEG_SCAN_BS") or os.environ.get("PORESEG_WIDE_BS")):
+            assert ctx.timings()["wide_redo"] == route           # (0: 32-bit digest, 1: 64-bit digest)
+        want.append(b.cpu().numpy())
+    ctx.set_option(option, value)
+    try:
+        for mode in (0, 2):
+            ctx.set_option("mode", mode)
+            for (t, q, route), w in zip(cases, want):
+                b, _, _ = ctx.segment_batch(t, np.array([0, t.numel()], dtype=np.int64), p, q, want_stats=False)
+                np.testing.assert_array_equal(b.cpu().numpy(), w)
+    finally:
+        ctx.set_option(option, default)
+        ctx.set_option("mode", int(os.environ.get("PORESEG_MODE", "0")))
