@@ -725,6 +725,26 @@ def main():
                                     "pcie_GBps": round(4 * n / th / 1e9, 1),
                                     "boundaries_equal_resident_run": bool(np.array_equal(hb, bounds.cpu().numpy()))}
             del hbuf, dbuf
+            # the same trace as int16 ADC counts -- what a file holds (read_abf.py:208-210): half the bytes over PCIe
+            d16 = synth.dwell_table(seed, n, *args.dwell) if args.dwell else synth.dwell_table(seed, n)
+            t16 = ctx.synth_trace(n, seed, np.cumsum(d16), synth.LEVEL_COUNTS[np.arange(len(d16)) % 5].astype(np.int32), dtype=torch.int16)
+            hbuf = torch.empty(n, dtype=torch.int16, pin_memory=True)
+            hbuf.copy_(t16)
+            del t16
+            torch.cuda.synchronize()
+            dbuf = [torch.empty(plen, dtype=torch.int16, device=device) for _ in range(2)]
+            for _ in range(2):
+                hb16 = h2d_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                hb16 = h2d_step()
+            torch.cuda.synchronize()
+            th16 = (time.perf_counter() - t1) / reps
+            out["h2d_inclusive"]["int16"] = {"value": round(n / th16 / 1e6, 1), "unit": "Msamples/s", "ms_per_trace": round(th16 * 1e3, 3),
+                                             "pcie_GBps": round(2 * n / th16 / 1e9, 1),
+                                             "boundaries_equal_resident_run": bool(np.array_equal(hb16, bounds.cpu().numpy()))}
+            del hbuf, dbuf
         # ---- CPU baseline: the oracle on this host, one thread and one thread per core ------------------------
         if not args.no_cpu and wl in ("trace", "file"):
             import oracle
