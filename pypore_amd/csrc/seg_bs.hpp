@@ -157,9 +157,10 @@ __device__ __forceinline__ DevCfg bs_cold_cfg(const BsCold &k)
 // exact sums at the group's left boundary) and two amplitudes (D1, D2) as fp32, rounded up:
 //     D1 >= max_j | sum_{i<j} (y_i - mu_g) |,     D2 >= max_j | sum_{i<j} ((y_i - mu_g)^2 - v_g) |       (0 <= j <= 256)
 // -- how far the prefix sums of the group's centred samples and of their squares stray from their chords (mu_g, v_g:
-// the group's mean and variance).  Both are formed exactly at the 31 interior block boundaries from the block sums; inside
-// a block a centred partial sum of j of 8 values moves by at most 2 (max - min), so
-//     D1 = max over block boundaries + 2 (ymax_g - ymin_g),   D2 = max over block boundaries + 2 max|y - mu_g|^2.
+// the group's mean and variance).  Both are formed at the 31 interior block boundaries from the block sums; inside block b
+// the bridges leave the chord between its two boundaries by at most sqrt(2 q_b) and 7/8 q_b, q_b = sum over the block of
+// (y - mu_g)^2 (blocksum_kernel has the derivation), so
+//     D1 = max_b (max(|d1(8b)|, |d1(8b+8)|) + sqrt(2 q_b)),   D2 = max_b (max(|d2z(8b)|, |d2z(8b+8)|) + 7/8 q_b).
 // The gain of a candidate is a convex function of the left part's (k, S1, S2) (seg_bs.hpp: bs_group_slack), so these two
 // numbers bound the gain of all 255 candidates inside the group from the evaluations of its two boundaries.
 constexpr int BS_GRP_LOG = 5;                            // blocks per group: 32
@@ -220,6 +221,11 @@ __device__ __forceinline__ int oct_first(int x, int lane)
 // bs[gb]: prefix of the blocks of gb's chunk that precede gb (entries up to one past the last block are valid: the end
 // boundary of the last window; the arrays are padded to whole waves).  A chunk may straddle events (different m): only
 // differences inside one event are ever formed.
+#ifndef PS_K0_AMP
+#define PS_K0_AMP 2                                    // how K0 forms the group amplitudes: 2 (default) block sums of squares about the group mean, fp32 bridges at the
+#endif                                                 // block boundaries, slack inside a block from its own sum of squares; 1 (first form of round 4) bridges in fp64,
+                                                       // slack from the group's min / max -- looser (3.8 instead of 3.6 rows of a window without a split), 20 more fp64
+                                                       // instructions per lane: 0.2262 -> 0.2227 ms per step in five interleaved rounds (see blocksum_kernel)
 #ifndef PS_K0_MINW
 #define PS_K0_MINW 5                                   // waves per SIMD K0 is compiled for (the fp32 instance takes 82 registers: eight 16-byte loads in flight per lane)
 #endif
@@ -480,6 +486,58 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
         bs[0] = make_uint4(ent[0].x, ent[0].y, ent[1].x, ent[1].y);
         bs[1] = make_uint4(ent[2].x, ent[2].y, ent[3].x, ent[3].y);
         if (c.blk_mm) *reinterpret_cast<int4 *>(c.blk_mm + gb4) = make_int4(t[0].z, t[1].z, t[2].z, t[3].z);
+#if PS_K0_AMP == 2
+        if (grp_out) {
+            // group record (round 4, second form): the eight lanes 8 g .. 8 g + 7 hold the group's 32 blocks.  Per block b the sum of
+            // squares ABOUT THE GROUP'S MEAN, q_b = s2_b - mu_g (2 s1_b - 8 mu_g), is formed exactly (fp64: s2 < 2^31, the
+            // product a multiple of 2^-13 below 2^33) and rounded to fp32 once; everything after it is fp32 on small numbers:
+            //     d1 at the block boundaries: 32 d1 = 32 P1 - nb S1g in int32 (P1: sum of the group's first nb blocks),
+            //     d2z at the block boundaries: prefix of (q_b - SS_g / 32), lane-local plus an exclusive scan over the octet,
+            // and inside block b the bridges leave the chord between its two boundaries by at most
+            //     |w1| <= sqrt(2 q_b)     (Cauchy-Schwarz on the block-centred samples; q_b is at least their sum of squares)
+            //     |w2| <= 7/8 q_b         (the squares are non-negative: the partial sum of j of 8 lies in [-(j/8) q_b, (1 - j/8) q_b])
+            // so  D1 = max_b (max(|d1(8b)|, |d1(8b+8)|) + sqrt(2 q_b)),   D2 = max_b (max(|d2z(8b)|, |d2z(8b+8)|) + 7/8 q_b).
+            // Rounding: every q_b carries 2^-24 relative, the prefixes at most 2^-18 SS_g in all: D2 takes 1e-5 SS_g on top.
+            const int S1g = oct_allsum(r1);
+            const double mg = static_cast<double>(S1g) * (-1.0 / 8192.0);                       // -(mu_g / 32)
+            float qf[K0_BPT];
+#pragma unroll
+            for (int j = 0; j < K0_BPT; ++j) {
+                const int U = 64 * t[j].x - S1g;                                                // 32 (2 s1_b - 8 mu_g), |U| < 2^24
+                qf[j] = fmaxf(static_cast<float>(fma(mg, static_cast<double>(U), static_cast<double>(static_cast<unsigned>(t[j].y)))), 0.0f);
+            }
+            const float lq = (qf[0] + qf[1]) + (qf[2] + qf[3]);
+            float SSg = lq;
+#define PS_STEP(CTRL) { SSg += dpp_movf<CTRL, 0xf>(0.0f, SSg); }
+            PS_OCT_STEPS(PS_STEP)
+#undef PS_STEP
+            const float qbar = SSg * (1.0f / static_cast<float>(BS_GRP));
+            // exclusive scan of the lanes' (sum of q_b - qbar) over the octet: row_shr 1, 2, 4, lanes nearer than that to the octet's start masked
+            const float lw = fmaf(-static_cast<float>(K0_BPT), qbar, lq);
+            float inc = lw;
+            const int l7 = lane & 7;
+            { const float v = dpp_movf<0x111, 0xf>(0.0f, inc); inc += l7 >= 1 ? v : 0.0f; }
+            { const float v = dpp_movf<0x112, 0xf>(0.0f, inc); inc += l7 >= 2 ? v : 0.0f; }
+            { const float v = dpp_movf<0x114, 0xf>(0.0f, inc); inc += l7 >= 4 ? v : 0.0f; }
+            float d2 = inc - lw;                                                                // d2z at this lane's first block boundary
+            int p1 = x1 - oct_first(x1, lane);                                                  // P1 at this lane's first block
+            int nb = K0_BPT * l7;
+            float a1p = fabsf(static_cast<float>(32 * p1 - nb * S1g)), a2p = fabsf(d2);
+            float D1 = 0.0f, D2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < K0_BPT; ++j) {
+                p1 += t[j].x; nb += 1;
+                d2 += qf[j] - qbar;
+                const float a1n = fabsf(static_cast<float>(32 * p1 - nb * S1g)), a2n = fabsf(d2);
+                D1 = fmaxf(D1, fmaf(fmaxf(a1p, a1n), 1.0f / 32.0f, __builtin_amdgcn_sqrtf(2.0f * qf[j]) * 1.00001f));
+                D2 = fmaxf(D2, fmaf(0.875f, qf[j], fmaxf(a2p, a2n)));
+                a1p = a1n; a2p = a2n;
+            }
+            D1 = oct_allmaxf(D1) * 1.00001f;
+            D2 = fmaf(1.0e-5f, SSg, oct_allmaxf(D2) * 1.00001f);
+            if (l7 == 0) grp_out[gb4 >> BS_GRP_LOG] = make_uint4(ent[0].x, ent[0].y, __float_as_uint(D1), __float_as_uint(D2));
+        }
+#else
         if (grp_out) {
             // group record: the eight lanes 8 g .. 8 g + 7 hold the group's 32 blocks.  Totals by an all-reduce, the prefix
             // at the group's first block from its first lane; then every lane looks at the boundaries behind its four blocks:
@@ -516,6 +574,7 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
             const float D2 = fmaf(2.0f * Mg, Mg, m2f) * 1.000001f;
             if ((lane & 7) == 0) grp_out[gb4 >> BS_GRP_LOG] = make_uint4(ent[0].x, ent[0].y, __float_as_uint(D1), __float_as_uint(D2));
         }
+#endif
         yabs = half_max_i32(yabs);
         if ((lane & 31) == 31) {
             const unsigned long long tot2 = (static_cast<unsigned long long>(static_cast<unsigned>(ihi)) << 16) + static_cast<unsigned>(ilo);

@@ -54,7 +54,7 @@ def _windows(n, rng, W=10000, mw=100):
     return [(a, b) for a, b in w if b - a > 2 * mw]
 
 
-@pytest.mark.parametrize("gs,mode", [(256, "group"), (256, "sym"), (128, "sym")])
+@pytest.mark.parametrize("gs,mode", [(256, "group"), (256, "sym"), (256, "tight"), (256, "kernel"), (128, "kernel")])
 def test_numpy_group_bound_never_below_an_interior_gain(gs, mode, capsys):
     sys.argv = ["group_bound.py"]
     y = synth.random_dwell_counts(300000, 2024).astype(np.float64)

@@ -16,9 +16,14 @@ and with log(1 + t) >= t - 0.537 t^2 (|t| <= 0.1) the cost falls by at most
 tL = (D2 + 2 |mu_g-mu_L| D1 + D1^2/k) / SS_L  (tR alike).  Group bound = max over the two boundaries of gain + A (log2 e).
 The first-order term keeps the cancellation between the two sides (1/V_L - 1/V_R is ~ sqrt(2/k) / sigma^2 on noise).
 
-K0 cannot afford per-sample bridges; it has S1, S2, min, max per 8-sample block.  D1, D2 from those:
+K0 cannot afford per-sample bridges; it has S1, S2, min, max per 8-sample block.  D1, D2 from those, first form ("block",
+"group", and "sym" = "group" with one slack per boundary):
     D1 <= max over block boundaries |d1| + 2 max_b (ymax_b - ymin_b)         (a centred partial sum of j of 8 values)
     D2 <= max over block boundaries |d2z| + 2 max_b max(|ymax_b - mu_g|, |ymin_b - mu_g|)^2
+second form ("tight"; "kernel" = "tight" with one slack per boundary: what the kernels do), with q_b = sum over block b of
+(y - mu_g)^2 = s2_b - mu_g (2 s1_b - 8 mu_g):
+    D1 <= max_b (max(|d1(8b)|, |d1(8b+8)|) + sqrt(2 q_b))                   (Cauchy-Schwarz on the block-centred samples)
+    D2 <= max_b (max(|d2z(8b)|, |d2z(8b+8)|) + 7/8 q_b)                     (the squares are non-negative)
 The script runs the reference recursion on a synthetic trace, and for every window it scans: checks that the bound is
 never below the largest interior gain, and counts how many 63-block rows of the fine sweep stay live.
 usage: group_bound.py [n_samples] [seed]"""
@@ -94,6 +99,13 @@ def group_data(y, c1, c2, P, GS, mode):
     d2 = np.cumsum(z * z - vg)[:-1]
     if mode == "sample":
         return np.abs(d1).max(), np.abs(d2).max()
+    if mode == "tight":
+        # what K0 does (PS_K0_AMP = 2): bridges at the block boundaries, inside block b at most sqrt(2 q_b) / 7/8 q_b off the
+        # chord between its two boundaries, q_b = the block's sum of squares about the group's mean
+        e1 = np.abs(np.concatenate(([0.0], np.cumsum(z))))[::8]
+        e2 = np.abs(np.concatenate(([0.0], np.cumsum(z * z - vg))))[::8]
+        qb = (z.reshape(-1, 8) ** 2).sum(axis=1)
+        return (np.maximum(e1[:-1], e1[1:]) + np.sqrt(2.0 * qb)).max(), (np.maximum(e2[:-1], e2[1:]) + 0.875 * qb).max()
     # block mode: bridges at the block boundaries + slack from the blocks' min / max
     b = seg.reshape(-1, 8)
     d1b = np.abs(d1[7::8]).max() if GS > 8 else 0.0
@@ -175,10 +187,10 @@ def run(y, c1, c2, wins, GS, mode):
         first_cov, last_cov = kb[0], kb[-1]
         live[0: (first_cov // 8) // 63 + 1] = True
         live[min(rows - 1, (last_cov // 8) // 63):] = True
-        if mode == "sym":
+        if mode in ("sym", "kernel"):
             gd = []
             for P in Ps:
-                D1, D2 = group_data(y, c1, c2, P, GS, "group")
+                D1, D2 = group_data(y, c1, c2, P, GS, "tight" if mode == "kernel" else "group")
                 gd.append((D1, D2, (a1[P - ps + GS - 1] - a1[P - ps - 1]) / GS))
             GA = []
             for ci, k in enumerate(kb):
@@ -186,7 +198,7 @@ def run(y, c1, c2, wins, GS, mode):
                 GA.append(g[k - 1] + boundary_A(n, ssl, ssr, a1, T1, k, adj))
         for gi, P in enumerate(Ps):
             kP, kQ = P - ps, P - ps + GS
-            if mode == "sym":
+            if mode in ("sym", "kernel"):
                 hb = max(GA[gi], GA[gi + 1])
             else:
                 D1, D2 = group_data(y, c1, c2, P, GS, mode)
@@ -220,8 +232,8 @@ def main():
     c1, c2, wins, bounds = rec_windows(y)
     print("trace %d samples, %d windows scanned, %d boundaries" % (N, len(wins), len(bounds)))
     for GS in (64, 128, 256, 512):
-        for mode in ("sample", "block", "group", "sym"):
-            if mode == "sym" and GS == 64:
+        for mode in ("sample", "block", "group", "sym", "kernel"):
+            if mode in ("sym", "kernel") and GS == 64:
                 continue
             r = run(y, c1, c2, wins, GS, mode)
             lo = r["loose"]
