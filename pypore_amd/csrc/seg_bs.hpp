@@ -198,6 +198,7 @@ __device__ __forceinline__ float oct_allmaxf(float x)                       // x
 #undef PS_STEP
     return x;
 }
+__device__ __forceinline__ float pmaxf(float a, float b) { return __int_as_float(max(__float_as_int(a), __float_as_int(b))); }   // a, b >= 0, no NaN
 // value of the first lane of this lane's group of eight (quad broadcast, then row_shr:4 for the upper quad)
 __device__ __forceinline__ int oct_first(int x, int lane)
 {
@@ -226,6 +227,9 @@ __device__ __forceinline__ int oct_first(int x, int lane)
 #endif                                                 // block boundaries, slack inside a block from its own sum of squares; 1 (first form of round 4) bridges in fp64,
                                                        // slack from the group's min / max -- looser (3.8 instead of 3.6 rows of a window without a split), 20 more fp64
                                                        // instructions per lane: 0.2262 -> 0.2227 ms per step in five interleaved rounds (see blocksum_kernel)
+#ifndef PS_K0_TRIM
+#define PS_K0_TRIM 1                                   // instruction trims of the streaming route (second half of round 4): sums of squares as a multiply-add chain, one
+#endif                                                 // range check per lane instead of one per block, integer maxima of non-negative floats; 0 builds the code before them
 #ifndef PS_K0_MINW
 #define PS_K0_MINW 5                                   // waves per SIMD K0 is compiled for (the fp32 instance takes 82 registers: eight 16-byte loads in flight per lane)
 #endif
@@ -250,8 +254,19 @@ __device__ __forceinline__ void k0_block_sums(const int (&y)[8], K0Rec<DT> &r)
     for (int q = 0; q < 8; ++q) {
         r.s1 += y[q];
         if constexpr (WIDE) r.s2w += static_cast<unsigned long long>(static_cast<long long>(y[q]) * static_cast<long long>(y[q]));
+#if !PS_K0_TRIM
         else r.s2 += static_cast<unsigned>(__mul24(y[q], y[q]));           // |y| < BS_WIDE < 2^23, else the call is redone
+#endif
     }
+#if PS_K0_TRIM
+    if constexpr (!WIDE) {
+        // one multiply and seven multiply-adds (left to itself the compiler forms seven products and sums them in threes: 11)
+        unsigned acc = static_cast<unsigned>(__mul24(y[0], y[0]));         // |y| < BS_WIDE < 2^23, else the call is redone
+#pragma unroll
+        for (int q = 1; q < 8; ++q) asm("v_mad_i32_i24 %0, %1, %1, %2" : "=v"(acc) : "v"(y[q]), "v"(acc));
+        r.s2 = acc;
+    }
+#endif
     r.ymin = min(min(min(y[0], y[1]), min(y[2], y[3])), min(min(y[4], y[5]), min(y[6], y[7])));
     r.ymax = max(max(max(y[0], y[1]), max(y[2], y[3])), max(max(y[4], y[5]), max(y[6], y[7])));
 }
@@ -380,8 +395,10 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
         e_first = lo;
     }
     int4 *mine = tr[wave];
+    int ymn_all = 0x7fffffff, ymx_all = -0x7fffffff - 1;   // extremes over the lane's four blocks: the range is checked once
     auto put = [&](int k, const K0Rec<DT> &r) {        // record of block 64 k + lane, in load order
-        if (r.ymax >= LIM || r.ymin <= -LIM) bad |= ST_WIDE_RANGE;
+        if (PS_K0_TRIM) { ymn_all = min(ymn_all, r.ymin); ymx_all = max(ymx_all, r.ymax); }
+        else if (r.ymax >= LIM || r.ymin <= -LIM) bad |= ST_WIDE_RANGE;
         if constexpr (WIDE) mine[64 * k + lane] = make_int4(r.s1, max(-r.ymin, r.ymax), static_cast<int>(r.s2w), static_cast<int>(r.s2w >> 32));
         else mine[64 * k + lane] = make_int4(r.s1, static_cast<int>(r.s2), (r.ymin & 0xffff) | (r.ymax << 16), 0);
     };
@@ -408,11 +425,15 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
             K0Rec<DT> r;
             k0_offsets<DT>(c, raw[k], m, mf, nz, y);
             k0_block_sums<DT>(y, r);
-            if (look) {
+            if (!PS_K0_TRIM && look) {
                 const int ka = m + r.ymin, kb = m + r.ymax;
                 if (max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb) >= 8388608) bad |= ST_OFF_GRID;
             }
             put(k, r);
+        }
+        if (PS_K0_TRIM && look) {
+            const int ka = m + ymn_all, kb = m + ymx_all;
+            if (max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb) >= 8388608) bad |= ST_OFF_GRID;
         }
         if (nz) bad |= ST_OFF_GRID;
         if (b_first + lane == 0) ev_info[e_first] = make_int4(m, 0, static_cast<int>(ev_boff[e_first] & 0xffffffffLL), static_cast<int>(ev_boff[e_first] >> 32));
@@ -428,6 +449,7 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
             put(k, g.r);
         }
     }
+    if (PS_K0_TRIM && (ymx_all >= LIM || ymn_all <= -LIM)) bad |= ST_WIDE_RANGE;
     // the records went through LDS in load order (block 64 k + L); read back as blocks 4 L .. 4 L + 3
     ps_sync<64>();                                     // wave-local hand-over (the waves of the workgroup are independent)
     int4 t[K0_BPT];
@@ -504,7 +526,8 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
 #pragma unroll
             for (int j = 0; j < K0_BPT; ++j) {
                 const int U = 64 * t[j].x - S1g;                                                // 32 (2 s1_b - 8 mu_g), |U| < 2^24
-                qf[j] = fmaxf(static_cast<float>(fma(mg, static_cast<double>(U), static_cast<double>(static_cast<unsigned>(t[j].y)))), 0.0f);
+                const float qx = static_cast<float>(fma(mg, static_cast<double>(U), static_cast<double>(static_cast<unsigned>(t[j].y))));
+                qf[j] = PS_K0_TRIM ? __int_as_float(max(__float_as_int(qx), 0)) : fmaxf(qx, 0.0f);     // (a negative float is a negative integer)
             }
             const float lq = (qf[0] + qf[1]) + (qf[2] + qf[3]);
             float SSg = lq;
@@ -529,8 +552,15 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
                 p1 += t[j].x; nb += 1;
                 d2 += qf[j] - qbar;
                 const float a1n = fabsf(static_cast<float>(32 * p1 - nb * S1g)), a2n = fabsf(d2);
+#if PS_K0_TRIM
+                // (all operands are non-negative and finite: their maxima are integer maxima of the bit patterns -- no quieting
+                //  moves in front of v_max_f32; sqrt(2 q) 1.00001 = sqrt(q) * 1.4142278)
+                D1 = pmaxf(D1, fmaf(pmaxf(a1p, a1n), 1.0f / 32.0f, __builtin_amdgcn_sqrtf(qf[j]) * 1.4142278f));
+                D2 = pmaxf(D2, fmaf(0.875f, qf[j], pmaxf(a2p, a2n)));
+#else
                 D1 = fmaxf(D1, fmaf(fmaxf(a1p, a1n), 1.0f / 32.0f, __builtin_amdgcn_sqrtf(2.0f * qf[j]) * 1.00001f));
                 D2 = fmaxf(D2, fmaf(0.875f, qf[j], fmaxf(a2p, a2n)));
+#endif
                 a1p = a1n; a2p = a2n;
             }
             D1 = oct_allmaxf(D1) * 1.00001f;
@@ -661,9 +691,14 @@ __device__ __forceinline__ float bs_block_bound2(const BsEval &ep, const BsEval 
 // record), so the gain on the path is at most the largest gain at the vertices: k at one of the two boundaries, (d1, d2z) at
 // the corners of the box.  At a boundary the displacement changes the sums of squared deviations by
 //     dSS_L = d2z + 2 wL d1 - d1^2 / k,        dSS_R = -d2z - 2 wR d1 - d1^2 / (n-k),      wL = mu_g - mu_L,  wR = mu_g - mu_R,
-// and with log(1 + t) >= t - 0.54 t^2 for |t| <= 0.09 the cost k log(SS_L/k) + (n-k) log(SS_R/(n-k)) falls by at most
-//     D2 |1/V_L - 1/V_R| + 2 D1 |wL/V_L - wR/V_R| + D1^2 (1/SS_L + 1/SS_R) + 0.54 (k tL^2 + (n-k) tR^2),
+// and with log(1 + t) >= t - c(T) t^2 for |t| <= T the cost k log(SS_L/k) + (n-k) log(SS_R/(n-k)) falls by at most
+//     D2 |1/V_L - 1/V_R| + 2 D1 |wL/V_L - wR/V_R| + D1^2 (1/SS_L + 1/SS_R) + c(tL) k tL^2 + c(tR) (n-k) tR^2,
 //     tL = (D2 + 2 |wL| D1 + D1^2 / k) / SS_L,  tR alike.
+// c(T) = sup over |t| <= T of (t - log(1 + t)) / t^2 = (-T - log(1 - T)) / T^2 = 1/2 + T/3 + T^2/4 + ... is convex in T, so
+// on 0 <= T <= 0.3 it lies below its chord 0.5 + 0.4325 T (c(0.3) = 0.62973); the kernels take 0.5 + 0.44 T and give up
+// beyond T = 0.3.  (Until the middle of round 4: the constant 0.54 and T <= 0.09 -- which refused the first full group
+// at either end of nearly every window and the second one in half of them, k being a few hundred there: 3.6 live rows in a
+// window without a split, 2.4 with the wider range.)
 // The first-order terms keep the cancellation between the two sides (on noise 1/V_L - 1/V_R is ~ sqrt(2/k) / sigma^2).
 // wa, wb: mu_g - mu_L for the two neighbouring groups (the same value twice at the ends); dmu = mu_L - mu_R, so that
 // wR = wL + dmu and wL/V_L - wR/V_R = wL (1/V_L - 1/V_R) - dmu / V_R.  All inputs carry relative errors of a few 2^-24
@@ -680,9 +715,9 @@ __device__ __forceinline__ float bs_group_slack(const BsEval &e, float D1, float
     const float first = fmaf(D2, fabsf(gS), fmaf(2.0f * D1, c1, D11 * (iSL + iSR)));
     const float EL = fmaf(2.0f * wL, D1, fmaf(D11, e.r.x, D2)), ER = fmaf(2.0f * wR, D1, fmaf(D11, e.r.y, D2));
     const float tL = EL * iSL, tR = ER * iSR;
-    const float second = 0.54f * fmaf(EL * iVL, tL, ER * iVR * tR);         // k tL^2 = EL^2 / (k V_L^2)
+    const float second = fmaf(fmaf(0.44f, tL, 0.5f) * (EL * iVL), tL, fmaf(0.44f, tR, 0.5f) * (ER * iVR) * tR);   // k tL^2 = EL^2 / (k V_L^2)
     const float A = fmaf((LOG2E * 1.0001f), first + second, 1.0e-3f);
-    return (tL <= 0.09f && tR <= 0.09f) ? A : INFINITY;                     // (NaN compares false: +inf)
+    return (tL <= 0.3f && tR <= 0.3f) ? A : INFINITY;                       // (NaN compares false: +inf)
 }
 
 struct BsQ { int j, a1; double a2; };                     // queued block (J-8, J): its end J, sums of [ps, J)

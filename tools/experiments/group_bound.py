@@ -11,8 +11,9 @@ group lies in the parallelepiped  chord(k) + (0, d1, d2z + 2 mu_g d1),  |d1| <= 
 so the gain inside the group is at most the largest gain at the eight vertices: k in {P, Q}, d1 = +-D1, d2z = +-D2.  At a
 vertex everything is known from the boundary evaluation; the displacement changes
     SS_L by  d2z + 2 (mu_g - mu_L) d1 - d1^2 / k,       SS_R by  -d2z - 2 (mu_g - mu_R) d1 - d1^2 / (n-k),
-and with log(1 + t) >= t - 0.537 t^2 (|t| <= 0.1) the cost falls by at most
-    A = D2 |1/V_L - 1/V_R| + 2 D1 |(mu_g-mu_L)/V_L - (mu_g-mu_R)/V_R| + D1^2 (1/SS_L + 1/SS_R) + 0.537 (k tL^2 + (n-k) tR^2),
+and with log(1 + t) >= t - c(T) t^2 on |t| <= T, c(T) = (-T - log(1 - T)) / T^2 <= 0.5 + 0.44 T for T <= 0.3 (c is convex; the
+modes before "sym" keep the constant 0.537 and T <= 0.1), the cost falls by at most
+    A = D2 |1/V_L - 1/V_R| + 2 D1 |(mu_g-mu_L)/V_L - (mu_g-mu_R)/V_R| + D1^2 (1/SS_L + 1/SS_R) + c(tL) k tL^2 + c(tR) (n-k) tR^2,
 tL = (D2 + 2 |mu_g-mu_L| D1 + D1^2/k) / SS_L  (tR alike).  Group bound = max over the two boundaries of gain + A (log2 e).
 The first-order term keeps the cancellation between the two sides (1/V_L - 1/V_R is ~ sqrt(2/k) / sigma^2 on noise).
 
@@ -149,9 +150,10 @@ def boundary_A(n, ssl, ssr, a1, T1, k, groups):
     first = D2 * abs(1 / VL - 1 / VR) + 2 * D1 * c1 + D1 * D1 * (1 / ssl[i] + 1 / ssr[i])
     tL = (D2 + 2 * wL * D1 + D1 * D1 / k) / ssl[i]
     tR = (D2 + 2 * wR * D1 + D1 * D1 / (n - k)) / ssr[i]
-    if tL > 0.09 or tR > 0.09:
+    if tL > 0.3 or tR > 0.3:
         return np.inf
-    return LOG2E * (first + 0.54 * (k * tL * tL + (n - k) * tR * tR))
+    # (log(1 + t) >= t - c(T) t^2 on |t| <= T with c(T) = (-T - log(1 - T)) / T^2, convex: below 0.5 + 0.4325 T on [0, 0.3])
+    return LOG2E * (first + (0.5 + 0.44 * tL) * k * tL * tL + (0.5 + 0.44 * tR) * (n - k) * tR * tR)
 
 
 def run(y, c1, c2, wins, GS, mode):
