@@ -30,11 +30,12 @@ import sys
 import threading
 import time
 
-# HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Four contexts in flight need four
-# of their own: with RCCL initialised (N > 1, or one rank under torch.distributed) the communicator's streams take some,
-# the contexts share what is left and the step goes from 0.25 to 0.33 ms (tools/gpu_dist1.sh; with 8 queues 0.241 plain,
-# 0.255 with RCCL).  Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The contexts in flight need one
+# each: with RCCL initialised (N > 1, or one rank under torch.distributed) the communicator's streams take some, the
+# contexts share what is left and the step of four contexts goes from 0.25 to 0.33 ms (tools/gpu_dist1.sh; with 8 queues
+# 0.241 plain, 0.255 with RCCL).  Eight contexts (the default since the end of round 4) on 16 queues leave room for those.
+# Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 
@@ -245,7 +246,7 @@ def main():
     ap.add_argument("--stats", action="store_true", help="also run the per-segment statistics kernel in the step")
     ap.add_argument("--dwell", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="dwell range of the synthetic trace in samples (default: BASELINE's U[1000, 20000))")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="contexts (HIP streams) the K steps of the trace / file workloads are spread over: independent "
                          "batches overlap on the GPU (engine.StreamPool); 1 = one batch at a time")
     ap.add_argument("--workload", choices=["trace", "file", "sharded-trace", "files"], default="trace")
@@ -433,7 +434,7 @@ def main():
     torch.cuda.synchronize()
     # CPython's cyclic collector is stop-the-world: a full collection walks every object torch and numpy created at
     # import (40 ms here) while holding the GIL, and every host thread of the pool then waits for it on its way out of
-    # the C call (tools/pool_stalls.py: all four contexts stall together, the device sequences stay at 1.2 ms).  A
+    # the C call (tools/pool_stalls.py: all contexts stall together, the device sequences stay at 1.2 ms).  A
     # long-running host does what is done here: collect once, then move what is alive out of the collector's reach.
     # (Before the warm-up, not after it: the GPU drops its clocks during a pause of that length.)
     import gc
@@ -605,12 +606,12 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
                          # HBM bytes per launch (PMC): of one call at a time, and -- the headline configuration -- per call
-                         # with four calls in flight on four distinct traces
-                         "traffic": (traffic.get("total_4_streams") if T == 4 and traffic.get("total_4_streams") else traffic["total"]) if traffic else None,
+                         # with the default number of calls in flight, each on its own trace
+                         "traffic": (traffic.get("total_in_flight") if T == traffic.get("in_flight_streams") and traffic.get("total_in_flight") else traffic["total"]) if traffic else None,
                          "traffic_measured_in_run": False,       # read from the committed PMC summary of the same command (traffic_source)
                          "traffic_one_call_at_a_time": traffic["total"] if traffic else None,
-                         "traffic_source": ((traffic.get("source_4_streams") + "; " if T == 4 and traffic.get("total_4_streams") else "") + traffic["source"]) if traffic else None,
-                         "traffic_over_algorithmic": round((traffic.get("total_4_streams") if T == 4 and traffic.get("total_4_streams") else traffic["total"]) / per_gpu_bytes, 3) if traffic else None,
+                         "traffic_source": ((traffic.get("source_in_flight") + "; " if T == traffic.get("in_flight_streams") and traffic.get("total_in_flight") else "") + traffic["source"]) if traffic else None,
+                         "traffic_over_algorithmic": round((traffic.get("total_in_flight") if T == traffic.get("in_flight_streams") and traffic.get("total_in_flight") else traffic["total"]) / per_gpu_bytes, 3) if traffic else None,
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes),
                          "longest_kernel": dom.replace("_ms", "_kernel"),
                          "streaming_kernel": {"name": "blocksum_kernel", "ms": round(kern["blocksum_ms"], 4),

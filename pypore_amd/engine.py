@@ -306,7 +306,11 @@ class StreamPool(object):
     A host that keeps the pool busy for long should take CPython's cyclic collector out of the way (`gc.collect();
     gc.freeze()` once everything is set up): a full collection holds the GIL for tens of milliseconds and every worker
     then waits for it on its way out of the C call -- 0.33 instead of 0.35-0.43 ms per 1e8-sample batch over runs of
-    400-2000 batches (tools/pool_stalls.py)."""
+    400-2000 batches (tools/pool_stalls.py).
+
+    HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): set it to at least the number of
+    contexts before the runtime starts (bench.py: 16).  Round 4, 1e8-sample trace: 4 / 8 / 16 contexts in flight deliver a
+    batch every 0.216 / 0.202 / 0.189 ms."""
 
     def __init__(self, device=None, streams=2):
         import queue

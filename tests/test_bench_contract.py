@@ -63,7 +63,7 @@ def test_self_launch_command_line(monkeypatch):
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-5:] == [BENCH, "--gpus", "4", "--steps", "3"]
-    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["GPU_MAX_HW_QUEUES"] == os.environ.get("GPU_MAX_HW_QUEUES", "8")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["GPU_MAX_HW_QUEUES"] == os.environ.get("GPU_MAX_HW_QUEUES", "16")
     src = open(BENCH).read()
     assert "os.exec" not in src and "execv" not in src.replace("no exec", "")
 
@@ -90,4 +90,4 @@ def test_short_run_prints_the_contract_line():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
     assert d["value"] == pytest.approx(1e8 / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
     assert d["config"]["checks"]["g7_sha256_equal"] is True and d["config"]["checks"]["all_streams_equal_single_stream"] is True
-    assert d["host"]["gpu_max_hw_queues"] == os.environ.get("GPU_MAX_HW_QUEUES", "8")
+    assert d["host"]["gpu_max_hw_queues"] == os.environ.get("GPU_MAX_HW_QUEUES", "16")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # instruction-fetch counters of the scan kernels (one call at a time): is the 84 KB spine kernel thrashing the I-cache?
 ROOT=$PWD; export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
 mkdir -p $ROOT/gpurun_out; cd /tmp
 rocprofv3 --list-avail 2>/dev/null | grep -io "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_WAIT_IFETCH[A-Z_]*\|SQ_INST_LEVEL[A-Z_]*\|SQC_TC[A-Z_]*\|SQC_DCACHE[A-Z_]*\|SQ_WAVE_CYCLES\|SQ_BUSY_CU_CYCLES\|SQ_VALU_MFMA_BUSY_CYCLES\|SQ_ACTIVE_INST_[A-Z_]*\|SQ_INST_CYCLES_[A-Z_]*\|SQ_THREAD_CYCLES_VALU\|SQ_WAIT_INST_LDS\|SQ_LDS_[A-Z_]*" | sort -u | tr '\n' ' ' > $ROOT/gpurun_out/pmc_avail.txt
 echo >> $ROOT/gpurun_out/pmc_avail.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # average latency of the vector / scalar / LDS memory instructions of the scan kernels: SQ_INST_LEVEL_x / SQ_INSTS_x
 ROOT=$PWD; export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
 mkdir -p $ROOT/gpurun_out; cd /tmp
 run() { name=$1; shift
   rm -rf /tmp/prof_$name

@@ -3,7 +3,7 @@
 TAG=${1:-pmc2}
 ROOT=$PWD
 export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
 mkdir -p $ROOT/gpurun_out
 cd /tmp
 run() {

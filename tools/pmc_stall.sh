@@ -2,7 +2,7 @@
 # Where do the scan waves wait?  TCP / TA / UTCL1 / instruction-fetch counters of one call at a time, one pass per group
 # (a group with an unknown counter name is reported and skipped).  usage: bash tools/pmc_stall.sh [extra bench args]
 ROOT=$PWD; export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}     # as bench.py sets it (under rocprofv3 the runtime may start before bench.py does)
 mkdir -p $ROOT/gpurun_out; cd /tmp
 rocprofv3 -L 2>/dev/null | grep -o "^\s*[A-Za-z0-9_]*\s" | sort -u > /dev/null
 rocprofv3 --list-avail 2>/dev/null | grep -oE "(Name|name)[ :=]+[A-Za-z0-9_]+" | awk '{print $NF}' | sort -u | tr '\n' ' ' > $ROOT/gpurun_out/pmc_avail_names.txt
