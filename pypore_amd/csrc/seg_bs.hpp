@@ -756,8 +756,14 @@ __device__ __forceinline__ int bs_count(const DevCfg &c, int64_t gi)
     return bs_count_of<DT>(c, static_cast<const typename Raw<DT>::type *>(c.samples)[gi]);
 }
 constexpr int BS_NC = 64;                                 // contenders kept per window
+#ifndef PS_ONE_ROW_LOOP
+#define PS_ONE_ROW_LOOP 0                                 // 1: windows that sweep every row use the loop of the windows with a row mask (one copy of the row code)
+#endif
+#ifndef PS_RING_GUARD
+#define PS_RING_GUARD 0                                   // 1: a slot of the ring is refilled only when a live row is left (no request for row 0 that nobody reads)
+#endif
 #ifndef PS_BS_D
-#define PS_BS_D 4
+#define PS_BS_D 2
 #endif
 constexpr int BS_D = PS_BS_D;                             // rows in flight: a ring of digest entries in registers (8 bytes each), row r + BS_D
                                                           // is requested when row r has been evaluated -- the prefetch distance of a lone chain
@@ -1268,12 +1274,30 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             const unsigned long long span = (hi - lo >= 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
             live = __ballot(lane < rows && (dead & span) != span);
         }
+#if PS_ONE_ROW_LOOP
+        // Windows that sweep every row (no coarse pass, no hit-like sample) walk the same loop as the others: their mask is
+        // "all rows", 64 at a time (one copy of the row code instead of two: the scan kernels are 40 KB each, several of them
+        // run on a pair of CUs at once, and the instruction cache of the pair holds 64 KB).
+        int rbase = 0;                                 // (uniform) first row of the mask
+        if (!hitlike) live = rows >= 64 ? ~0ull : (1ull << rows) - 1ull;
+        auto take_row = [&]() {                        // next live row, -1: none left (uniform)
+            if (live == 0ull) {
+                if (hitlike || rbase + 64 >= rows) return -1;
+                rbase += 64;
+                live = rows - rbase >= 64 ? ~0ull : (1ull << (rows - rbase)) - 1ull;
+            }
+            const int r = __builtin_ctzll(live);
+            live &= live - 1ull;
+            return rbase + r;
+        };
+#else
         auto take_row = [&]() {                        // next live row, -1: none left (uniform)
             if (live == 0ull) return -1;
             const int r = __builtin_ctzll(live);
             live &= live - 1ull;
             return r;
         };
+#endif
         auto drain = [&]() {
             // drain: interior candidates of the queued blocks
             PS_MARK(drain_begin);
@@ -1519,7 +1543,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
         auto do_row = [&](int r, const ent_t &cur) { row_commit(row_eval(r, cur)); };
         // One row at a time (no interleaving of rows: the four waves of the SIMD cover each other's latencies, and a row
         // evaluated alone keeps the kernel at 128 registers); its slot of the ring is refilled as soon as it is free.
-        if (!hitlike) {
+        if (!PS_ONE_ROW_LOOP && !hitlike) {
             if (phase) {
 #pragma unroll
                 for (int i = 0; i < BS_D; ++i) ring[i] = row_load(i);
@@ -1543,9 +1567,11 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
             for (int i = 0; i < BS_D; ++i) {
                 // (phase 0 of a window with a coarse pass: the slot already holds a row of the window's ends; taken if live)
                 const int pr = pre_row(i);
-                const bool have = GROUPS && phase == 0 && edge_rows && pr >= 0 && pr < rows && ((live >> pr) & 1ull) != 0ull;
+                // (one loop for all windows: the rows requested with the setup are 0 .. BS_D - 1 when the window has no coarse pass)
+                const bool have = (PS_ONE_ROW_LOOP ? (hitlike ? GROUPS && edge_rows : true) : GROUPS && edge_rows) && phase == 0 &&
+                                  pr >= 0 && pr < min(rows, 64) && ((live >> pr) & 1ull) != 0ull;
                 if (have) { rr[i] = pr; live &= ~(1ull << pr); }
-                else { rr[i] = take_row(); ring[i] = row_load(rr[i]); }
+                else { rr[i] = take_row(); if (!PS_RING_GUARD || rr[i] >= 0) ring[i] = row_load(rr[i]); }
             }
             for (bool any = true; any;) {
                 any = false;
@@ -1556,7 +1582,7 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
                         do_row(rr[i], ring[i]);
                         any = true;
                     }
-                    if (any) { rr[i] = take_row(); ring[i] = row_load(rr[i]); }
+                    if (any) { rr[i] = take_row(); if (!PS_RING_GUARD || rr[i] >= 0) ring[i] = row_load(rr[i]); }
                 }
             }
         }
