@@ -33,7 +33,7 @@ import time
 # HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The contexts in flight need one
 # each: with RCCL initialised (N > 1, or one rank under torch.distributed) the communicator's streams take some, the
 # contexts share what is left and the step of four contexts goes from 0.25 to 0.33 ms (tools/gpu_dist1.sh; with 8 queues
-# 0.241 plain, 0.255 with RCCL).  Eight contexts (the default since the end of round 4) on 16 queues leave room for those.
+# 0.241 plain, 0.255 with RCCL).  The default since the end of round 4: sixteen contexts on 16 queues.
 # Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--stats", action="store_true", help="also run the per-segment statistics kernel in the step")
     ap.add_argument("--dwell", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="dwell range of the synthetic trace in samples (default: BASELINE's U[1000, 20000))")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=16,
                     help="contexts (HIP streams) the K steps of the trace / file workloads are spread over: independent "
                          "batches overlap on the GPU (engine.StreamPool); 1 = one batch at a time")
     ap.add_argument("--workload", choices=["trace", "file", "sharded-trace", "files"], default="trace")
@@ -442,15 +442,20 @@ def main():
     gc.freeze()
     # A fresh process starts cold (GPU clocks, pinned staging buffers, the allocator's pools): settle for a fixed
     # 0.2 s before the W warmup steps so that a small W does not leak start-up effects into the K timed steps.
+    # (With several contexts the settling runs on the pool, like the timed steps: every context sizes its scratch, every host
+    #  thread is awake and the GPU is under the load of the timed region when the clock starts.  Round 4: with the settling
+    #  and the W steps on one context only, one in six fresh processes with twelve contexts ran its 20 timed steps at twice
+    #  the usual time; 60 consecutive runs inside one process never did: tools/pool_short_runs.py.)
+    warm = (lambda m: pool.run(m, lambda cx, k, t: step(None, cx, t))) if T > 1 else (lambda m: [step() for _ in range(m)])
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < 0.2:
-        step()
-    for _ in range(warmup):
-        step()
+        warm(max(T, 1))
+    if warmup:
+        warm(warmup)                                     # the W untimed steps of the contract: the same steps as the timed ones
     kern = dict(blocksum_ms=0.0, spine_ms=0.0, bridge_ms=0.0, tree_ms=0.0, gather_ms=0.0, stitch_ms=0.0, seq_ms=0.0)
     seq_ms = 0.0
     if T > 1:
-        pool.run(2 * T, lambda cx, k, t: step(None, cx, t))    # every context has sized its scratch before the clock starts
+        warm(2 * T)                                      # every context has sized its scratch before the clock starts
     seq_acc = [0.0] * T
 
     def timed(cx, k, t):

@@ -2,12 +2,12 @@
 # Collects the evidence committed under profiles/ for one round.  Run on the GPU box:
 #   gpurun -- 'bash tools/profile_round.sh r02'
 # Outputs (gpurun_out/, copy to profiles/):
-#   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the DEFAULT bench command (eight contexts in flight: kernels
+#   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the DEFAULT bench command (sixteen contexts in flight: kernels
 #                               of different calls overlap, so single launches run longer than alone)
 #   <tag>_s1_kernel_stats.csv   the same with --streams 1 (one call at a time: the per-kernel durations of roofline.kernel_ms)
 #   <tag>_bench.json            the default bench line (incl. cpu_baseline, h2d_inclusive)
 #   <tag>_pmc_summary.txt       PMC passes (tools/pmc_run.sh, --streams 1: instruction counts, traffic of one call at a time)
-#   <tag>_pmc8_summary.txt      the same passes with eight calls in flight on eight DISTINCT traces (--streams 8, the bench's
+#   <tag>_pmc16_summary.txt     the same passes with sixteen calls in flight on sixteen DISTINCT traces (--streams 16, the bench's
 #                               default): what the headline configuration fetches; <tag>_pmc_traffic.json: HBM bytes per launch from both
 TAG=${1:-r04}
 ROOT=$PWD
@@ -18,7 +18,7 @@ mkdir -p $ROOT/gpurun_out
 export GPU_MAX_HW_QUEUES=16
 echo "GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES" > $ROOT/gpurun_out/${TAG}_profile_env.txt
 cd /tmp
-for s in 8 1; do
+for s in 16 1; do
   rm -rf /tmp/kstats
   rocprofv3 --kernel-trace --stats -d /tmp/kstats -o out --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-h2d --streams $s > /tmp/kstats_$s.log 2>&1
   out=$ROOT/gpurun_out/${TAG}_kernel_stats.csv
@@ -29,7 +29,7 @@ done
 cd $ROOT
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 bash tools/pmc_run.sh ${TAG}_pmc 1 > /dev/null 2>&1
-bash tools/pmc_run.sh ${TAG}_pmc8 8 > /dev/null 2>&1
+bash tools/pmc_run.sh ${TAG}_pmc16 16 > /dev/null 2>&1
 python3 - $TAG <<'PY'
 import sys, re, json, ast
 tag = sys.argv[1]
@@ -45,7 +45,7 @@ def read(name):
         elif m.group(1) == 'write': per[k]['write_kib'] = d['WRITE_SIZE']
         elif 'SQ_INSTS_VALU' in d: per[k]['valu'] = d['SQ_INSTS_VALU']
     return per
-per4 = read(tag + '_pmc8')
+per4 = read(tag + '_pmc16')
 per = {}
 for line in open('gpurun_out/%s_pmc_summary.txt' % tag):
     m = re.match(r'(fetch|write|sq) (?:void )?ps::(\w+)(?:<[^>]*>)? (\{.*\})', line.strip())
@@ -63,8 +63,8 @@ pk4 = {k: (2 * per4[k].get('fetch_kib', 0) + per4[k].get('write_kib', 0)) * 1024
 json.dump({"source": "profiles/%s_pmc_summary.txt: FETCH_SIZE (KiB) x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE (KiB) per "
                      "launch, rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --streams 1`" % tag,
            "total": sum(pk.values()), "per_kernel": pk,
-           "in_flight_streams": 8, "total_in_flight": sum(pk4.values()), "per_kernel_in_flight": pk4,
-           "source_in_flight": "profiles/%s_pmc8_summary.txt: the same passes with --streams 8 (eight calls in flight, one trace each)" % tag,
+           "in_flight_streams": 16, "total_in_flight": sum(pk4.values()), "per_kernel_in_flight": pk4,
+           "source_in_flight": "profiles/%s_pmc16_summary.txt: the same passes with --streams 16 (sixteen calls in flight, one trace each)" % tag,
            "valu_source": "profiles/%s_pmc_summary.txt: SQ_INSTS_VALU (wave-level vector instructions) per launch, same passes" % tag,
            "valu_per_kernel": {k: per[k]['valu'] for k in names if k in per and 'valu' in per[k]}},
           open('gpurun_out/%s_pmc_traffic.json' % tag, 'w'), indent=1)
