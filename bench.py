@@ -35,7 +35,10 @@ import time
 # contexts share what is left and the step of four contexts goes from 0.25 to 0.33 ms (tools/gpu_dist1.sh; with 8 queues
 # 0.241 plain, 0.255 with RCCL).  The default since the end of round 4: sixteen contexts on 16 queues.
 # Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (a rank of an N > 1 job: RCCL's streams take about four queues -- sixteen contexts under an initialised communicator ran at
+#  0.197 / 0.184 / 0.184 ms per step on 16 / 20 / 24 queues, tools/gpu_r4_rccl_queues.sh; without RCCL 16 is the steadier choice)
+_QUEUES_FROM_CALLER = "GPU_MAX_HW_QUEUES" in os.environ
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20" if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 else "16")
 
 import numpy as np
 
@@ -179,6 +182,8 @@ def self_launch(argv, n):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not _QUEUES_FROM_CALLER:
+        env.pop("GPU_MAX_HW_QUEUES", None)               # the ranks choose for themselves (N > 1: room for RCCL's streams)
     return subprocess.run(cmd, env=env).returncode
 
 
