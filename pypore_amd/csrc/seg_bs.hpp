@@ -15,6 +15,12 @@
 // constants passed in by the caller (no per-window load of the event table), a scan body written for 128 registers
 // (four waves per SIMD instead of two) with its cold paths out of line.
 //
+// Round 4: one record per group of 32 blocks from K0 (the exact sums at the group's first boundary and
+// two amplitudes of its prefix path about its chord); every window scan of the narrow digest starts with a COARSE PASS over
+// those records -- the gain is convex in (k, S1, S2), so a whole group is bounded from its two boundaries -- and sweeps only
+// the rows that hold a group it could not discard (3 of a window's 16); the bounds are audited on the device (AUDIT
+// instance, audit_kernel).  A ring of two digest rows instead of four.
+//
 // Reference functions restated here: cparsers.pyx:157-178 (_best_split_stepwise) through scan_window_bs,
 // core.py:209-223 (Segment statistics) through segstat_bs_kernel.
 //
