@@ -102,7 +102,14 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * every window scan starts with the coarse pass over them (whole groups of 32 blocks are bounded, rows of the sweep
  * that lie in pruned groups are skipped), 0 every row is swept; "wide_bs" 1 (default) counts too wide for the 32-bit
  * digest are retried on the 64-bit one, 0 straight to the LDS-window scan; "spine_nt" 256/512/1024, "tree_nt" 256/512
- * workgroup sizes of the LDS-window kernels.  Unknown names return PS_ERR_ARG. */
+ * workgroup sizes of the LDS-window kernels; "tree_par" 1 (default) the deep subtree jobs of a call on the 64-bit digest
+ * (a filtered event) are shared by the four waves of a workgroup when the call has few jobs, 0 one wave per job;
+ * "k0_waves" n (default 2): the block-prefix kernel K0 is persistent -- n waves per SIMD stride over the call, each with
+ * its next 8 KB of samples in flight -- 0: one wave per 2 048 samples, as many as fit the chip (rounds 3 and 4);
+ * "k0_shared" 1: this context queues its upload + K0 launches on the device's shared front stream, where the K0
+ * kernels of all such contexts run back to back (they are bound by HBM: side by side they only share it) and the
+ * context's own stream takes over behind an event; 0 (default) everything on the context's stream -- a host that keeps
+ * several contexts busy (engine.StreamPool) sets it for the duration of its runs.  Unknown names return PS_ERR_ARG. */
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);
 /* Blocks until all work submitted on the context's stream has finished. */
 int ps_synchronize(ps_ctx *ctx);
@@ -193,10 +200,11 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
 
 /* Replaces Event.filter (DataTypes.py:258-274): scipy.signal.bessel(order, cutoff / (sampling_freq / 2), btype='low',
  * analog=0) applied with scipy.signal.filtfilt (forward and backward, odd extension by padlen = 3 (order + 1), initial
- * state lfilter_zi * first value).  order 1 (the reference's default): the scan / fused-halo kernels; orders 2..4: one
+ * state lfilter_zi * first value).  order 1 (the reference's default): the scan / fused-halo kernels; orders 2..8: one
  * thread per segment with a halo (seg_filter.hpp).  Input as for the segmenter (fp32 on the grid or int16 counts,
- * n samples), output d_out[n] in pA as fp64 (the reference replaces Event.current by the float64 result).
- * PS_ERR_ARG for order outside 1..4, n <= padlen (scipy raises ValueError), a cutoff outside (0, Nyquist), and for a
+ * n samples) or -- this entry only -- PS_DTYPE_F64, the float64 current itself; output d_out[n] in pA as fp64 (the
+ * reference replaces Event.current by the float64 result).
+ * PS_ERR_ARG for order outside 1..8, n <= padlen (scipy raises ValueError), a cutoff outside (0, Nyquist), and for a
  * filter of order >= 2 whose state needs more than 8192 samples to forget (cutoffs below ~0.2 % of Nyquist). */
 int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n, int32_t order,
                      double cutoff, double sampling_freq, double *d_out);

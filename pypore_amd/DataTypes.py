@@ -91,13 +91,19 @@ class Event(Segment):
         else:
             # no grid: the float64 values themselves (a current still parked on the device stays there)
             t = getattr(cur, "tensor", None)
+            off = 0.0
             if t is None or not t.is_cuda:
                 a = np.ascontiguousarray(np.asarray(self.current), dtype=np.float64)
                 if a.ndim != 1:
                     raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % a.ndim)
                 t = torch.from_numpy(a).cuda()
+            else:
+                # a parked tensor holds the current WITHOUT the file's offset (grid.Deferred.from_tensor(y, off), what
+                # parse_events leaves behind): a unit-gain low-pass passes a constant unchanged, so it goes back on afterwards
+                off = float(getattr(cur, "offset", 0.0) or 0.0)
             ctx = engine.context(t.device.index)
-            self.current = ctx.filter_bessel(t.contiguous(), 1.0, cutoff=cutoff, sampling_freq=float(self.second), order=order).cpu().numpy()
+            out = ctx.filter_bessel(t.contiguous(), 1.0, cutoff=cutoff, sampling_freq=float(self.second), order=order).cpu().numpy()
+            self.current = out + off if off else out
         self.filtered, self.filter_order, self.filter_cutoff = True, order, cutoff
 
     # ---- Event.parse (DataTypes.py:276-289, :333) -----------------------------------------------------------

@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -94,7 +96,17 @@ struct ps_ctx {
     int tree_mw = 0;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list (round 3: single-wave workgroups are faster at four waves per SIMD and need no spills)
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
-    int k0_waves = 0;         // > 0: at most this many K0 waves per SIMD (LDS padding), 0: whatever the registers allow (five)
+    int k0_waves = 2;         // K0 is persistent: this many waves per SIMD stride over the call (round 5); 0: one wave per wave block, as many as the registers allow
+    int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
+    bool gate_held = false;
+    int dbg_phase = 0;        // diagnostics (PORESEG_DBG_PHASE; WRONG or stale results, never set by the product): 1 a call that repeats the previous
+                              // one's layout skips K0 (the digest is still there: what the scan kernels cost on their own), 2 K0 only
+    int k0_shared = 0;        // 1: upload + K0 of this context run on the device's shared FRONT stream (round 5): the K0 launches of all contexts that
+                              // ask for it are serialised there, back to back, and the context's own stream takes over behind an event.  K0 is the
+                              // one kernel of a call that is bound by HBM; several of them at once only share the same bytes per second while the
+                              // scan kernels behind each of them wait -- in a row, call i's scans run under call i+1's K0.  engine.StreamPool sets it.
+    hipEvent_t ev_front[2] = {};   // hand-over events (no timing): [0] context stream -> front stream, [1] front stream -> context stream
+    bool stream_idle = true;  // the context's stream had nothing queued when the current call began (no hand-over to the front stream needed)
     int tree_par = 1;         // 1: subtree jobs on the 64-bit digest (filtered events: deep recursions) are shared by the waves of a workgroup (tree_par_kernel), 0: one wave per job
     int groups = 1;           // 1: K0 writes group records and the window scans start with the coarse pass over them (narrow digest), 0: every row is swept
     int scan_bs = 1;          // 1: block-sum scan with single-wave workgroups (seg_bs.hpp), 0: LDS-window scan
@@ -156,6 +168,46 @@ int fail(ps_ctx *ctx, int code, const char *fmt, ...)
         if (e_ != hipSuccess)                                                                     \
             return fail(ctx, PS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// The front stream of a device (ps_ctx::k0_shared): one stream per device and process on which the upload + K0 launches of
+// all contexts are queued back to back (the mutex keeps one call's pair of launches and its event together).
+struct FrontStream { std::mutex mu; hipStream_t s = nullptr; };
+FrontStream g_front[16];
+FrontStream *front_for(ps_ctx *ctx)
+{
+    if (ctx->device < 0 || ctx->device >= 16) return nullptr;
+    FrontStream *f = &g_front[ctx->device];
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (!f->s) {
+        int lo = 0, hi = 0;
+        const char *pr = std::getenv("PORESEG_FRONT_PRIORITY");         // 1: highest priority the device offers (experiments)
+        if (pr && std::atoi(pr) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
+            if (hipStreamCreateWithPriority(&f->s, hipStreamNonBlocking, hi) != hipSuccess) { f->s = nullptr; (void)hipGetLastError(); }
+        }
+        if (!f->s && hipStreamCreateWithFlags(&f->s, hipStreamNonBlocking) != hipSuccess) { f->s = nullptr; (void)hipGetLastError(); return nullptr; }
+    }
+    return f;
+}
+
+// K0 admission (ps_ctx::k0_admit, experiments): at most PORESEG_K0_MAX calls of a device have their K0 in flight at a time; a call
+// takes a permit before it queues K0 and gives it back when K0's event has completed (the host thread waits for that event after
+// it has queued the rest of the call).  K0 is bound by HBM: T of them side by side only share the same bytes per second, and all
+// of them -- with every call's scan kernels behind them -- finish late together.
+struct K0Gate { std::mutex mu; std::condition_variable cv; int in_flight = 0; };
+K0Gate g_gate[16];
+void gate_enter(int device, int max_in_flight)
+{
+    K0Gate &g = g_gate[device & 15];
+    std::unique_lock<std::mutex> lk(g.mu);
+    g.cv.wait(lk, [&] { return g.in_flight < max_in_flight; });
+    ++g.in_flight;
+}
+void gate_leave(int device)
+{
+    K0Gate &g = g_gate[device & 15];
+    { std::lock_guard<std::mutex> lk(g.mu); --g.in_flight; }
+    g.cv.notify_one();
+}
 
 // status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..3] work, [4] dense count
 // (hdr: the stitch header lives behind the counters so that one copy brings both back)
@@ -471,6 +523,12 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     }
     if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[9], ctx->stream));
+    if (ctx->gate_held) {                              // the whole call is queued: K0's permit goes back when K0 is through
+        const hipError_t ge = hipEventSynchronize(ctx->ev_front[1]);
+        ctx->gate_held = false;
+        gate_leave(ctx->device);
+        HIP_TRY(ctx, ge);
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     {
         float seq = 0;                                 // the call's device work, upload to result copies, by HIP events
@@ -569,7 +627,7 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
 // tree jobs, items) -- no host round trip before the final synchronisation.
 // Returns RC_FALLBACK when a seam could not be bridged on the device (rare); the caller then runs
 // the host-stitch pipeline, which repairs seams one by one.
-int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
+int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
                         std::chrono::steady_clock::time_point t_begin)
 {
@@ -673,6 +731,18 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
     else HIP_TRY(ctx, ctx->bounds_off.reserve(evb));
     ctx->asm_hdr.alias(&ctx->small.as<SmallLayout>()->hdr);
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    // Where upload + K0 are queued: the context's own stream, or the device's front stream (k0_shared) -- then under the front
+    // stream's mutex until K0's event is recorded, and the context's stream continues behind that event.
+    FrontStream *front = (ctx->k0_shared && use_bs && tc.nj) ? front_for(ctx) : nullptr;
+    hipStream_t fs = front ? front->s : ctx->stream;
+    std::unique_lock<std::mutex> front_lock;
+    if (front) {
+        front_lock = std::unique_lock<std::mutex>(front->mu);
+        if (!ctx->stream_idle) {                       // (work the caller left on the context's stream -- a filter, a re-quantisation -- comes first)
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_front[0], ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(fs, ctx->ev_front[0], 0));
+        }
+    }
     {
         const char *up = ctx->h_up.as<char>();
         void *up_devptr = nullptr;                     // the pinned blob as the device sees it (else: plain copy)
@@ -681,13 +751,13 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
             // (tables still on the device from the previous call: the kernel only clears the status block)
             const long long n16 = reuse ? 0 : static_cast<long long>((up_bytes + 15) / 16);
             const unsigned ug = static_cast<unsigned>(std::max<long long>(1, std::min<long long>((n16 + 255) / 256, 1024)));
-            hipLaunchKernelGGL(upload_kernel, dim3(ug), dim3(256), 0, ctx->stream, static_cast<const int4 *>(up_devptr),
+            hipLaunchKernelGGL(upload_kernel, dim3(ug), dim3(256), 0, fs, static_cast<const int4 *>(up_devptr),
                                ctx->up_dev.as<int4>(), n16, ctx->small.as<unsigned long long>(),
                                static_cast<int>(sizeof(SmallLayout) / sizeof(unsigned long long)));
             HIP_TRY(ctx, hipGetLastError());
         } else {
-            HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
-            if (!reuse) HIP_TRY(ctx, hipMemcpyAsync(ctx->up_dev.p, up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), fs));
+            if (!reuse) HIP_TRY(ctx, hipMemcpyAsync(ctx->up_dev.p, up, up_bytes, hipMemcpyHostToDevice, fs));
         }
         tc.valid = true;
     }
@@ -700,14 +770,14 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
 
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
-    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[7], fs));
     if (use_bs && nj) {
         // K0: chunk-prefixed block sums (one streaming pass), per-event centre m, totals + max|k| per 256 blocks
         const int64_t nb_total = tc.nb_total;
         // (a wave of K0 takes 256 blocks; the digest arrays are padded to whole waves, +1: the end boundary)
         const int64_t nb_pad = k0_padded_blocks(nb_total);
-        const unsigned k0_grid = static_cast<unsigned>((nb_pad / K0_WB + K0_WAVES - 1) / K0_WAVES);
-        HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_pad) * (wide ? sizeof(int4) : sizeof(uint2))));
+        // (at least 16 KB: a wave block of K0's general route fetches -- and ignores -- the head of this buffer, seg_bs.hpp)
+        HIP_TRY(ctx, ctx->bsum.reserve(std::max<size_t>(16384, static_cast<size_t>(nb_pad) * (wide ? sizeof(int4) : sizeof(uint2)))));
         HIP_TRY(ctx, ctx->ev_info.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
         HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(nb_pad / BS_CHUNK + 1) * (wide ? 2 : 1) * sizeof(int4)));
         if (!wide && ctx->groups) {                    // group records of the coarse pass (16 B per 32 blocks; +1: the end boundary's)
@@ -718,28 +788,44 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
             HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_pad) * sizeof(int)));
             cfg.blk_mm = ctx->blk_mm.as<int>();
         }
-        // K0 streams: a few waves per SIMD saturate HBM, and at full occupancy (five waves of 82 registers) it leaves no
-        // room on a SIMD for a 128-register scan wave of another call in flight.  Option "k0_waves" caps its waves per SIMD
-        // by giving every workgroup (K0_WAVES waves, one per SIMD of its CU) a share of the CU's 160 KB of LDS it never touches.
-        size_t k0_lds = 0;
-        if (ctx->k0_waves > 0) {
-            const size_t per_wg = (160 * 1024) / static_cast<size_t>(ctx->k0_waves) - 256;
-            const size_t stat = sizeof(int4) * K0_WAVES * K0_WB;
-            k0_lds = per_wg > stat ? std::min<size_t>(per_wg - stat, 64 * 1024 - stat - 256) : 0;
+        // K0 is persistent (round 5): k0_waves workgroups per CU (K0_WAVES waves each, i.e. that many waves per SIMD), every
+        // wave striding over the wave blocks of the call with its next block's samples in flight.  One or two waves per SIMD
+        // saturate HBM; the rest of the SIMD stays free for the scan waves of the other calls in flight.  k0_waves = 0: one wave
+        // per wave block as in rounds 3 and 4 (the launch then fills every slot the registers allow).
+        if (ctx->n_cu <= 0) {
+            hipDeviceProp_t prop;
+            ctx->n_cu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
         }
-#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), k0_lds, ctx->stream, cfg,       \
+        const unsigned k0_full = static_cast<unsigned>((nb_pad / K0_WB + K0_WAVES - 1) / K0_WAVES);
+        const unsigned k0_grid = ctx->k0_waves > 0 ? std::min(k0_full, static_cast<unsigned>(ctx->k0_waves) * static_cast<unsigned>(ctx->n_cu) * (4u / K0_WAVES)) : k0_full;
+        const size_t k0_lds = 0;
+#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), k0_lds, fs, cfg,       \
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
                                     reinterpret_cast<unsigned *>(&sm->status), const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp)))
-        if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
-        else      { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
+        if (ctx->k0_admit > 0 && !front) { gate_enter(ctx->device, ctx->k0_admit); ctx->gate_held = true; }
+        if (ctx->dbg_phase == 1 && reuse) { /* diagnostics: the previous call's digest */ }
+        else if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
+        else           { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
 #undef PS_K0
         HIP_TRY(ctx, hipGetLastError());
         cfg.bsum = ctx->bsum.p;
         cfg.ev_info = ctx->ev_info.as<int4>();
         cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
     }
-    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], fs));
+    if (ctx->gate_held) HIP_TRY(ctx, hipEventRecord(ctx->ev_front[1], fs));       // (K0 is behind this event)
+    if (ctx->dbg_phase == 2) {                           // diagnostics: K0 only
+        if (front) front_lock.unlock();
+        HIP_TRY(ctx, hipStreamSynchronize(fs));
+        for (int e = 0; e <= n_ev; ++e) h_bounds_off[e] = 0;
+        return PS_OK;
+    }
+    if (front) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_front[1], fs));
+        front_lock.unlock();
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_front[1], 0));
+    }
     if (nj && wide) {
         // (the 64-bit digest: same kernels, compiled for it)
         const unsigned g = static_cast<unsigned>(nj);
@@ -812,6 +898,15 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
     if (ctx->timing >= 2 && hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]) == hipSuccess) ctx->ms[4] = ms;     // device stitch incl. header sync
     return rc;
 }
+// (whatever way the call ends: a K0 permit that is still held goes back)
+int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
+                        int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
+                        std::chrono::steady_clock::time_point t_begin)
+{
+    const int rc = device_stitch_batch_(ctx, cfg_in, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+    if (ctx->gate_held) { ctx->gate_held = false; gate_leave(ctx->device); }
+    return rc;
+}
 }  // namespace
 
 extern "C" {
@@ -842,6 +937,8 @@ int ps_create(int device, void *stream, ps_ctx **out)
     }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
+    for (auto &e : ctx->ev_front)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     if (ctx->small.reserve(sizeof(SmallLayout) + SMALL_TAIL) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     ctx->lds_max_samples = (LDS_BYTES_MAX - 1024 * 8 - 256) / (static_cast<int>(sizeof(lds_t)) + 1);   // samples + block sums
     if (const char *e = std::getenv("PORESEG_MODE")) ctx->mode = std::atoi(e);
@@ -855,6 +952,9 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_GROUPS")) ctx->groups = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_TREE_PAR")) ctx->tree_par = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_K0_WAVES")) ctx->k0_waves = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_K0_SHARED")) ctx->k0_shared = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_DBG_PHASE")) ctx->dbg_phase = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_K0_MAX")) ctx->k0_admit = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
@@ -886,6 +986,7 @@ void ps_destroy(ps_ctx *ctx)
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_front) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -910,7 +1011,9 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "scan_bs") ctx->scan_bs = value != 0;
     else if (n == "groups") ctx->groups = value != 0;
     else if (n == "tree_par") ctx->tree_par = value != 0;
-    else if (n == "k0_waves" && value >= 0 && value <= 8) ctx->k0_waves = static_cast<int>(value);
+    else if (n == "k0_waves" && value >= 0 && value <= 16) ctx->k0_waves = static_cast<int>(value);
+    else if (n == "k0_shared") ctx->k0_shared = value != 0;
+    else if (n == "k0_admit" && value >= 0) ctx->k0_admit = static_cast<int>(value);
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
     else if (n == "tree_tail_pct" && value >= 0 && value <= 100) ctx->tree_tail_pct = static_cast<int>(value);
@@ -1012,6 +1115,8 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (double &m : ctx->ms) m = 0;
     for (int64_t &c : ctx->counters) c = 0;
+    ctx->stream_idle = true;
+    if (ctx->k0_shared && hipStreamQuery(ctx->stream) != hipSuccess) { ctx->stream_idle = false; (void)hipGetLastError(); }
     if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
     if (ctx->stitch_host) HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));   // (the device-stitch path clears it with its upload)
 
@@ -1034,6 +1139,7 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
             for (double &m : ctx->ms) m = 0;
             for (int64_t &c : ctx->counters) c = 0;
             HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+            ctx->stream_idle = false;                  // (the front stream, if used, waits for this memset)
             rc = device_stitch_batch(ctx, cfg, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
         }
         if (redo) ctx->counters[7] = redo;
@@ -1293,7 +1399,7 @@ int ps_audit_bounds(ps_ctx *ctx, const void *d_samples, const ps_sample_format *
     const int64_t nb_total = (n + 7) / 8, nb_pad = k0_padded_blocks(nb_total);
     const int64_t tab[4] = {0, n, 0, nb_total};                            // ev_start | ev_len | ev_boff[0..1]
     const size_t win_bytes = static_cast<size_t>(n_win) * 2 * sizeof(int32_t);
-    HIP_TRY(ctx, ctx->bsum.reserve(static_cast<size_t>(nb_pad) * sizeof(uint2)));
+    HIP_TRY(ctx, ctx->bsum.reserve(std::max<size_t>(16384, static_cast<size_t>(nb_pad) * sizeof(uint2))));
     HIP_TRY(ctx, ctx->ev_info.reserve(sizeof(int4)));
     HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(nb_pad / BS_CHUNK + 1) * sizeof(int4)));
     HIP_TRY(ctx, ctx->grp.reserve(static_cast<size_t>(nb_pad / BS_GRP + 1) * sizeof(uint4)));
@@ -1580,6 +1686,7 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
         // float64 input (this entry only): the values are the current itself
         const ps_sample_format f32 = {PS_DTYPE_F32, 0, 1.0};
         rc = make_cfg(ctx, d_samples, &f32, 1, 1, 2, 0.0, &cfg);
+        if (rc) return rc;
         cfg.dtype = PS_DTYPE_F64; cfg.q = 1.0; cfg.q2 = 1.0; cfg.inv_q = 1.0f;
     } else {
         rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);

@@ -26,6 +26,7 @@
 //
 // Included by seg_device.hpp after the common helpers (screen arithmetic, DPP primitives, scan_exact).
 #pragma once
+#include <type_traits>
 
 namespace ps {
 
@@ -237,15 +238,24 @@ __device__ __forceinline__ int oct_first(int x, int lane)
 #define PS_K0_TRIM 1                                   // instruction trims of the streaming route (second half of round 4): sums of squares as a multiply-add chain, one
 #endif                                                 // range check per lane instead of one per block, integer maxima of non-negative floats; 0 builds the code before them
 #ifndef PS_K0_MINW
-#define PS_K0_MINW 5                                   // waves per SIMD K0 is compiled for (the fp32 instance takes 82 registers: eight 16-byte loads in flight per lane)
+#define PS_K0_MINW 4                                   // waves per SIMD K0 is compiled for: two sets of eight 16-byte loads per lane (round 5: persistent, one or two waves per SIMD are launched)
 #endif
 constexpr int K0_BPT = 4;                              // consecutive blocks per thread after the transposition
 constexpr int K0_WB = 64 * K0_BPT;                     // blocks per wave
 #ifndef PS_K0_WAVES
 #define PS_K0_WAVES 4
 #endif
+#ifndef PS_K0_PRIO
+#define PS_K0_PRIO 0                                   // s_setprio of K0's waves (0: none)
+#endif
 constexpr int K0_WAVES = PS_K0_WAVES;                  // waves per workgroup (independent of each other)
 __host__ __device__ inline long long k0_padded_blocks(long long nb_total) { return (nb_total + 1 + K0_WB - 1) / K0_WB * K0_WB; }
+
+// Wave-local hand-over through LDS: the lanes of a wave run in lockstep and its LDS operations complete in order, so the
+// exchange only needs the writes to be complete (lgkmcnt) -- NOT the vector-memory counter: a workgroup-scope fence would also
+// wait for the samples of the next wave block, which are in flight on purpose.
+__device__ __forceinline__ void k0_lds_ready() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void k0_lds_done() { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 
 template <int DT> struct K0Rec { int s1; unsigned s2; unsigned long long s2w; int ymin, ymax; };
 template <int DT> struct K0Gen { K0Rec<DT> r; int m; unsigned bad; };     // what the general route returns (by value: no stack objects)
@@ -373,9 +383,18 @@ __device__ __attribute__((noinline)) K0Gen<DT> k0_block_general(BsCold k, const 
     return out;
 }
 
+// Round 5: the kernel is PERSISTENT.  A launch holds a fixed number of waves (host: k0_grid workgroups, one or two waves per
+// SIMD) and every wave strides over the wave blocks (256 blocks = 2 048 samples each) of the call; the samples of its NEXT wave
+// block are requested before the current one is worked on (a second set of load registers), so that one wave keeps 8 KB in
+// flight all the time.  K0 is the only kernel that streams the samples and it is bound by HBM: a few waves per SIMD saturate
+// the memory, and everything beyond that only keeps the scan waves of the other calls in flight off the SIMD (round 4: five
+// 82-register waves per SIMD were 54 % of all wave residency while issuing 12 % of the time).  A launch that covers every wave
+// block with a wave of its own (gridDim.x * K0_WAVES >= wave blocks) degenerates to the one-shot kernel of rounds 3 and 4.
+struct K0Src { int e; int fast; long long b_first; int64_t base; };
+
 template <int DT>
-__global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(DevCfg c, const int64_t *ev_start, const int64_t *ev_len,
-                                                                const int64_t *ev_boff, int n_ev, int64_t n_samples, void *bs_out,
+__global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(DevCfg c, const int64_t *__restrict__ ev_start, const int64_t *__restrict__ ev_len,
+                                                                const int64_t *__restrict__ ev_boff, int n_ev, int64_t n_samples, void *bs_out,
                                                                 int4 *ev_info, int4 *chunk_tot, unsigned *status, uint4 *grp_out)
 {
     constexpr bool WIDE = bs_wide<DT>();
@@ -385,22 +404,54 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
     __shared__ int4 tr[K0_WAVES][K0_WB];               // per wave: the records of its 256 blocks (transposition)
     const int lane = threadIdx.x & 63;
     const int wave = uni(static_cast<int>(threadIdx.x >> 6));
-    const long long wb0 = (static_cast<long long>(blockIdx.x) * K0_WAVES + wave) * K0_WB;
+    const long long nwv = static_cast<long long>(gridDim.x) * K0_WAVES;      // waves of the launch
+    long long wv = static_cast<long long>(blockIdx.x) * K0_WAVES + wave;      // this wave's first wave block
     const long long nb_total = ev_boff[n_ev];
-    if (wb0 > nb_total) return;                        // (waves are independent: no barrier in this kernel)
+    const long long n_wb = nb_total / K0_WB + 1;       // wave blocks with wb0 <= nb_total (the last one holds the end boundary's entry)
+    if (wv >= n_wb) return;                            // (waves are independent: no barrier in this kernel)
+#if PS_K0_PRIO
+    // K0 is the memory-bound kernel of a call: its waves go first when a SIMD arbitrates its vector issue (priority, then age --
+    // MI355X_MICROARCH.md), so that what they do between two requests does not queue behind the scan waves of other calls
+    __builtin_amdgcn_s_setprio(PS_K0_PRIO);
+#endif
     unsigned bad = 0;
-    // event of the wave's first block (uniform search)
-    int e_first = 0;
-    {
+    int4 *mine = tr[wave];
+    // where a wave block's samples come from (uniform): its event, and whether its 256 blocks are full blocks of that one
+    // event, 16-byte aligned (the fast route)
+    auto classify = [&](long long wb0, int e_lo) -> K0Src {
+        K0Src s;
         const long long gfirst = min(wb0, nb_total - 1);
-        int lo = 0, hi = n_ev - 1;                     // event e: ev_boff[e] <= gb < ev_boff[e+1]
+        int lo = e_lo, hi = n_ev - 1;                  // event e: ev_boff[e] <= gb < ev_boff[e+1]  (wave blocks ascend: e_lo = the previous one's event)
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (ev_boff[mid] <= gfirst) lo = mid; else hi = mid - 1;
         }
-        e_first = lo;
-    }
-    int4 *mine = tr[wave];
+        s.e = lo;
+        s.b_first = wb0 - ev_boff[lo];
+        s.base = ev_start[lo];
+        const int64_t len_f = ev_len[lo];
+        s.fast = wb0 + K0_WB <= ev_boff[lo + 1] && 8 * (s.b_first + K0_WB) <= len_f &&
+                 (((s.base + 8 * s.b_first) * ES) & 15) == 0 && nb_total > 0;
+        return s;
+    };
+    // the loads of a wave block: issued unconditionally -- a wave block of the general route fetches (and ignores) the first
+    // 8 KB of the digest buffer instead -- so that the compiler's count of the loads in flight is the same on every path
+    using raw_t = typename Raw<DT>::type;
+    auto issue = [&](const K0Src &s, int4 (&raw)[K0_BPT][NV], raw_t &first) {
+        // (uniform base + one 32-bit lane offset: the scalar-base form of the loads needs no address registers per row)
+        const char *pb = s.fast ? static_cast<const char *>(c.samples) + (s.base + 8 * s.b_first) * ES : static_cast<const char *>(bs_out);
+        // (the event's first sample -- the centre m of its sums -- ahead of the block loads: loads return in order, and a load
+        //  issued behind them would make the wave wait for the NEXT wave block's samples)
+        first = *reinterpret_cast<const raw_t *>(s.fast ? static_cast<const char *>(c.samples) + s.base * ES : static_cast<const char *>(bs_out));
+        const unsigned lo = static_cast<unsigned>(lane) * (8u * ES);
+#pragma unroll
+        for (int k = 0; k < K0_BPT; ++k)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) raw[k][v] = *reinterpret_cast<const int4 *>(pb + (lo + static_cast<unsigned>(k * 64 * 8 * ES + 16 * v)));
+    };
+    auto process = [&](auto fast_tag, const long long wb0, const K0Src &src, const int4 (&raw)[K0_BPT][NV], const raw_t first) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int e_first = src.e;
     int ymn_all = 0x7fffffff, ymx_all = -0x7fffffff - 1;   // extremes over the lane's four blocks: the range is checked once
     auto put = [&](int k, const K0Rec<DT> &r) {        // record of block 64 k + lane, in load order
         if (PS_K0_TRIM) { ymn_all = min(ymn_all, r.ymin); ymx_all = max(ymx_all, r.ymax); }
@@ -408,19 +459,8 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
         if constexpr (WIDE) mine[64 * k + lane] = make_int4(r.s1, max(-r.ymin, r.ymax), static_cast<int>(r.s2w), static_cast<int>(r.s2w >> 32));
         else mine[64 * k + lane] = make_int4(r.s1, static_cast<int>(r.s2), (r.ymin & 0xffff) | (r.ymax << 16), 0);
     };
-    // fast route (uniform): the wave's 256 blocks are full blocks of one event, 16-byte aligned
-    const long long b_first = wb0 - ev_boff[e_first];
-    const int64_t len_f = ev_len[e_first], base_f = ev_start[e_first];
-    const bool fast = wb0 + K0_WB <= ev_boff[e_first + 1] && 8 * (b_first + K0_WB) <= len_f &&
-                      (((base_f + 8 * b_first) * ES) & 15) == 0 && nb_total > 0;
-    if (fast) {
-        const char *p0 = static_cast<const char *>(c.samples) + (base_f + 8 * (b_first + lane)) * ES;
-        int4 raw[K0_BPT][NV];
-#pragma unroll
-        for (int k = 0; k < K0_BPT; ++k)
-#pragma unroll
-            for (int v = 0; v < NV; ++v) raw[k][v] = reinterpret_cast<const int4 *>(p0 + static_cast<long long>(k) * 64 * 8 * ES)[v];
-        const int m = load_count<DT>(c, base_f, bad);
+    if constexpr (FAST) {
+        const int m = to_count<DT>(c, first, bad);
         const float mf = static_cast<float>(m);        // |m| < 2^23: exact
         unsigned nz = 0;
         // |count| < 2^23 for fp32 input: |k - m| < LIM is checked for every block, so only an m near the limit needs a look
@@ -430,19 +470,21 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
             int y[8];
             K0Rec<DT> r;
             k0_offsets<DT>(c, raw[k], m, mf, nz, y);
+            asm volatile("" : "+v"(nz));               // (the integrality word is complete here: left alone, the compiler keeps x/q and its rounding of all 32 samples for one OR tree at the end)
             k0_block_sums<DT>(y, r);
             if (!PS_K0_TRIM && look) {
                 const int ka = m + r.ymin, kb = m + r.ymax;
                 if (max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb) >= 8388608) bad |= ST_OFF_GRID;
             }
             put(k, r);
+            __builtin_amdgcn_sched_barrier(0);         // one block after the other: interleaved, the four blocks and the second set of loads do not fit 128 registers
         }
         if (PS_K0_TRIM && look) {
             const int ka = m + ymn_all, kb = m + ymx_all;
             if (max(ka < 0 ? -ka : ka, kb < 0 ? -kb : kb) >= 8388608) bad |= ST_OFF_GRID;
         }
         if (nz) bad |= ST_OFF_GRID;
-        if (b_first + lane == 0) ev_info[e_first] = make_int4(m, 0, static_cast<int>(ev_boff[e_first] & 0xffffffffLL), static_cast<int>(ev_boff[e_first] >> 32));
+        if (src.b_first + lane == 0) ev_info[e_first] = make_int4(m, 0, static_cast<int>(ev_boff[e_first] & 0xffffffffLL), static_cast<int>(ev_boff[e_first] >> 32));
     } else {
 #pragma unroll 1
         for (int k = 0; k < K0_BPT; ++k) {
@@ -457,7 +499,7 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
     }
     if (PS_K0_TRIM && (ymx_all >= LIM || ymn_all <= -LIM)) bad |= ST_WIDE_RANGE;
     // the records went through LDS in load order (block 64 k + L); read back as blocks 4 L .. 4 L + 3
-    ps_sync<64>();                                     // wave-local hand-over (the waves of the workgroup are independent)
+    k0_lds_ready();                                    // wave-local hand-over (the waves of the workgroup are independent)
     int4 t[K0_BPT];
 #pragma unroll
     for (int j = 0; j < K0_BPT; ++j) t[j] = mine[K0_BPT * lane + j];
@@ -615,6 +657,56 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
         if ((lane & 31) == 31) {
             const unsigned long long tot2 = (static_cast<unsigned long long>(static_cast<unsigned>(ihi)) << 16) + static_cast<unsigned>(ilo);
             chunk_tot[chunk] = make_int4(i1, yabs, static_cast<int>(tot2), static_cast<int>(tot2 >> 32));
+        }
+    }
+    k0_lds_done();                                     // the next wave block's records may overwrite the transposition buffer
+    };
+    // Pass 1, the wave blocks of the fast route: two sets of load registers, used in turn -- the next wave block's samples
+    // travel while this one is worked on.  Wave blocks of the general route (an out-of-line call: registers that are live
+    // across it would be spilled, and the compiler then parks the whole second set on the stack) are left to pass 2.
+    int4 rawA[K0_BPT][NV], rawB[K0_BPT][NV];
+    raw_t firstA, firstB;
+    unsigned long long general = 0;                    // iterations of this wave that were not fast (uniform; from the 64th on: looked at again)
+    int it = 0;
+    const long long wv0 = wv;
+    // (a wave block that is skipped here still "reads" its registers: on every path the loads of a set are then known to be
+    //  complete before the set is requested again -- otherwise the compiler waits in the middle of the next request)
+    auto retire = [&](const int4 (&raw)[K0_BPT][NV], const raw_t first) {
+#pragma unroll
+        for (int k = 0; k < K0_BPT; ++k)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) asm volatile("" :: "v"(raw[k][v].x), "v"(raw[k][v].y), "v"(raw[k][v].z), "v"(raw[k][v].w));
+        asm volatile("" :: "v"(first));
+    };
+    K0Src sA = classify(wv * K0_WB, 0), sB = sA;
+    issue(sA, rawA, firstA);
+#pragma unroll 1
+    for (;;) {
+        const bool moreB = wv + nwv < n_wb;
+        if (moreB) sB = classify((wv + nwv) * K0_WB, sA.e); else sB.fast = 0;
+        issue(sB, rawB, firstB);                       // (unconditional, like the loads inside: a last wave block requests the dummy lines)
+        if (sA.fast) process(std::true_type{}, wv * K0_WB, sA, rawA, firstA);
+        else { general |= 1ull << min(it, 63); retire(rawA, firstA); }
+        if (!moreB) break;
+        wv += nwv; ++it;
+        const bool moreA = wv + nwv < n_wb;
+        if (moreA) sA = classify((wv + nwv) * K0_WB, sB.e); else sA.fast = 0;
+        issue(sA, rawA, firstA);
+        if (sB.fast) process(std::true_type{}, wv * K0_WB, sB, rawB, firstB);
+        else { general |= 1ull << min(it, 63); retire(rawB, firstB); }
+        if (!moreA) break;
+        wv += nwv; ++it;
+    }
+    // Pass 2, the general route: the wave blocks at the ends of events, unaligned events, the last wave block of the call
+    if (general) {
+        int e_lo = 0;
+        it = 0;
+#pragma unroll 1
+        for (wv = wv0; wv < n_wb; wv += nwv, ++it) {
+            if (it < 63 && !((general >> it) & 1ull)) continue;
+            const K0Src sg = classify(wv * K0_WB, e_lo);
+            e_lo = sg.e;
+            if (!sg.fast) process(std::false_type{}, wv * K0_WB, sg, rawA, firstA);
         }
     }
     if (bad) atomicOr(status, bad);

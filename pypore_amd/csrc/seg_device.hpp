@@ -159,9 +159,10 @@ struct Work {
 #endif
 
 // ---- sample access --------------------------------------------------------------------------
-// DT of the kernel templates: bit 0 = sample type (PS_DTYPE_F32 / PS_DTYPE_I16), bit 1 = wide K0 digest (seg_bs.hpp:
+// DT of the kernel templates: bit 0 = sample type (PS_DTYPE_F32 / PS_DTYPE_I16), bit 2 = wide K0 digest (seg_bs.hpp:
 // 64-bit integer block sums for counts up to 2^23 from the event's first sample; block-sum scan kernels only)
-constexpr int DT_WIDE = 2;
+constexpr int DT_WIDE = 4;                           // (a flag bit outside the public dtype values: PS_DTYPE_F64 == 2 is a sample type of the filter kernels)
+static_assert((PS_DTYPE_F32 & DT_WIDE) == 0 && (PS_DTYPE_I16 & DT_WIDE) == 0 && (PS_DTYPE_F64 & DT_WIDE) == 0, "DT_WIDE must not collide with a sample type");
 constexpr int sdt(int DT) { return DT & 1; }
 template <int DT> struct Raw { typedef float type; };
 template <> struct Raw<PS_DTYPE_I16> { typedef int16_t type; };

@@ -4,6 +4,7 @@ compute is in the HIP kernels behind the C ABI.
 """
 import collections
 import ctypes
+import os
 import threading
 import warnings
 
@@ -357,6 +358,11 @@ class StreamPool(object):
             self._inbox[t].put(None)
         self._threads = []
 
+    @staticmethod
+    def _front_stream(cx, on):
+        if hasattr(cx, "set_option"):
+            cx.set_option("k0_shared", on)
+
     def run(self, n_jobs, job, dynamic=False):
         """Runs job(ctx, k, t) for k = 0 .. n_jobs-1 and returns the results in job order.  Job k runs on context
         t = k % T, or -- dynamic=True -- on whichever context is free next (jobs of unequal length)."""
@@ -364,6 +370,26 @@ class StreamPool(object):
         T = len(self.contexts)
         results = [None] * n_jobs
         errors = []
+        # Round 5: while the pool runs, the contexts queue their upload + K0 launches on the device's shared front stream
+        # (ps_set_option "k0_shared"): K0 is the one HBM-bound kernel of a call, and T of them at once only share the same
+        # bytes per second while every call's scan kernels wait -- in a row, call i's scans run under call i+1's K0.
+        # The caller's own context (contexts[0]) goes back to its private stream afterwards: a lone call saves the hand-over.
+        # (measured, round 5: the front stream LOSES -- 0.26-0.30 ms per step against 0.175 -- a lone K0 competes for wave slots with
+        #  the scan kernels of fifteen other calls and gets a sixteenth of what frees up; PORESEG_POOL_SHARED=1 keeps the experiment)
+        shared = T > 1 and n_jobs > 1 and os.environ.get("PORESEG_POOL_SHARED", "0") == "1"
+        if shared:
+            for cx in self.contexts:
+                self._front_stream(cx, 1)
+        # What does pay is a limit on the K0 kernels in flight: at most three calls of the pool stream their samples at a time
+        # ("k0_admit": a call waits for a permit before it queues K0 and returns it when K0's event has completed).  K0 is
+        # bound by HBM; sixteen of them at once finish late together, with every call's scan kernels behind them.
+        # 16 contexts, 100 steps: 0.188 -> 0.175 ms per step; the driver's 20 steps: 0.208 -> 0.197 (profiles/r05_experiments).
+        admit = int(os.environ.get("PORESEG_POOL_K0_MAX", "3")) if T > 3 else 0
+        if admit != getattr(self, "_admit", 0):
+            for cx in self.contexts:
+                if hasattr(cx, "set_option"):
+                    cx.set_option("k0_admit", admit)
+            self._admit = admit
         ticket = itertools.count() if dynamic else None
         busy = [t for t in range(1, T) if t < n_jobs]
         for t in busy:
@@ -371,6 +397,8 @@ class StreamPool(object):
         self._share(0, n_jobs, job, results, errors, ticket)
         for _ in busy:
             self._done.get()
+        if shared:
+            self._front_stream(self.contexts[0], 0)
         if errors:
             raise errors[0]
         return results

@@ -113,25 +113,43 @@ class Deferred(object):
 
     live_device_bytes = 0                                # bytes parked on GPUs, all devices (see from_tensor, device_counts)
     DEVICE_BYTES_MAX = 16 << 30                          # per device, and never more than a quarter of its memory
-    _lock = threading.Lock()                             # the accounting is shared by the host threads of a process
+    _lock = threading.RLock()                            # the accounting is shared by the host threads of a process.  Re-entrant: a
+                                                         # Deferred sits in event <-> segment cycles, so the cyclic collector may run its
+                                                         # __del__ -> _unpark on THIS thread at any allocation inside _park
     _by_device = {}                                      # device index -> bytes parked there
+    _cap_cache = {}                                      # device index -> [calls until the next look at the device, cap]
+    CAP_REFRESH = 64                                     # _park asks the driver for the free memory once per this many calls
+
+    @classmethod
+    def _device_cap(cls, dev_key, refresh=False):
+        """DEVICE_BYTES_MAX, at most a quarter of the device's memory, and nothing while less than a tenth of the device is
+        free.  Memory that torch's caching allocator holds but has not handed out counts as free (it is: the next tensor
+        comes out of it).  The driver is asked once per CAP_REFRESH calls, and again whenever a request was refused."""
+        ent = cls._cap_cache.get(dev_key)
+        if ent is not None and ent[0] > 0 and not refresh:
+            ent[0] -= 1
+            return min(cls.DEVICE_BYTES_MAX, ent[1])
+        limit = cls.DEVICE_BYTES_MAX
+        try:
+            import torch
+            free, total = torch.cuda.mem_get_info(dev_key)
+            free += max(0, torch.cuda.memory_reserved(dev_key) - torch.cuda.memory_allocated(dev_key))
+            limit = 0 if free < total // 10 else total // 4
+        except Exception:
+            pass
+        cls._cap_cache[dev_key] = [cls.CAP_REFRESH, limit]
+        return min(cls.DEVICE_BYTES_MAX, limit)
 
     @classmethod
     def _park(cls, dev_key, nbytes):
         """Reserve `nbytes` of the budget of parked tensors on device `dev_key` (None: no device, the accounting only).
-        The budget is DEVICE_BYTES_MAX, at most a quarter of the device's memory, and nothing at all while less than a
-        tenth of the device is free -- an Experiment over many files, or several ranks on one GPU, must not run the
+        The budget is _device_cap -- an Experiment over many files, or several ranks on one GPU, must not run the
         allocator dry where the eager route (copy to the host at once) would have worked."""
         with cls._lock:
-            cap = cls.DEVICE_BYTES_MAX
-            if dev_key is not None:
-                try:
-                    import torch
-                    free, total = torch.cuda.mem_get_info(dev_key)
-                    cap = 0 if free < total // 10 else min(cap, total // 4)
-                except Exception:
-                    pass
-            used = cls._by_device.get(dev_key, 0)
+            cap = cls.DEVICE_BYTES_MAX if dev_key is None else cls._device_cap(dev_key)
+            if cls._by_device.get(dev_key, 0) + nbytes > cap and dev_key is not None:
+                cap = cls._device_cap(dev_key, refresh=True)     # a refusal is decided on fresh numbers
+            used = cls._by_device.get(dev_key, 0)        # (read after the driver calls: a collection inside them may have unparked)
             if used + nbytes > cap:
                 return False
             cls._by_device[dev_key] = used + nbytes

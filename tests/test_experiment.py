@@ -140,6 +140,36 @@ def test_filtered_batch_on_a_real_header_scale_with_offset(tmp_path):
 
 
 @pytest.mark.gpu
+def test_filter_again_on_a_parked_current_keeps_the_files_offset(tmp_path):
+    """parse_events(filter_params) leaves the filtered current of every event parked on the device WITHOUT the
+    file's offset (grid.Deferred.from_tensor(y, off)).  event.filter() right after it -- before anybody read
+    event.current -- must filter that tensor and put the offset back, like the same two filters on the host values."""
+    counts, _ = synth.file_trace_counts(900_000, 78)
+    path = os.path.join(str(tmp_path), "offset2.abf")
+    abf.write_abf(path, counts.astype(np.int16), adc_range=10.0, adc_resolution=32768, instrument_scale=0.0005,
+                  signal_gain=20.0, instrument_offset=1.25, signal_offset=0.5)
+    exp = Experiment([path])
+    exp.parse(verbose=False)
+    file = exp.files[0]
+    from pypore_amd.grid import Deferred, grid_of
+    assert file.n >= 1 and grid_of(file.current)[2] != 0.0
+    was_parked = []
+    for ev in file.events:
+        cur = ev.__dict__.get("current")
+        a = int(round(ev.start * file.second)); n = int(round(ev.duration * file.second))
+        parked = isinstance(cur, Deferred) and cur.tensor is not None
+        was_parked.append(parked)
+        ev.filter(1, 2000)                                           # second pass, straight from the parked tensor
+        ref = Event(current=file.current[a:a + n], start=ev.start, end=ev.end, duration=ev.duration, second=file.second, file=file)
+        ref.filter(1, 2000)
+        _ = ref.current                                              # (read: written out, no longer parked)
+        ref.filter(1, 2000)
+        np.testing.assert_allclose(ev.current, ref.current, rtol=0, atol=1e-9)
+        assert abs(float(np.mean(ev.current)) - float(np.mean(file.current[a:a + n]))) < 1.0, parked
+    assert any(was_parked)                                           # the path this test is about was taken
+
+
+@pytest.mark.gpu
 def test_experiment_currents_are_written_out_only_when_read(tmp_path):
     """Experiment.parse never builds the file's float64 array nor copies a filtered current back (grid.Deferred behind the
     `current` attribute); reading them afterwards gives what the eager route gives, and the file's counts went up once."""
