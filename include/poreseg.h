@@ -63,9 +63,12 @@ typedef struct ps_split_params {
     double  cutoff_freq;                 /* 0 = None         */
 } ps_split_params;
 
-/* How samples map to pA: pA = (count + offset_counts) * quantum, with count = x/quantum for
- * PS_DTYPE_F32 (offset_counts must be 0 there).  quantum should be a power of two for
- * bit-exact parity with the reference (read_abf.py:202-205 scale/offset). */
+/* How samples map to pA: pA = (count + offset_counts) * quantum for PS_DTYPE_I16; PS_DTYPE_F32 samples are the pA
+ * values themselves, count = x/quantum, and offset_counts is NOT added to them: non-zero, it names the level (in counts
+ * of quantum) that the caller subtracted upstream -- ps_requantise's centre, for a filtered event -- and is used only to
+ * judge near ties against the reference's own rounding noise (its cumsums run on the uncentred values; counters[11] of
+ * ps_get_timings).  quantum should be a power of two for bit-exact parity with the reference (read_abf.py:202-205
+ * scale/offset). */
 typedef struct ps_sample_format {
     int32_t dtype;                       /* PS_DTYPE_* */
     int32_t offset_counts;

@@ -132,13 +132,13 @@ class Event(Segment):
         that keeps every count below 2**22 (2**-18 pA for a 100 pA range): on the golden vectors recorded from the
         reference that reproduces every boundary the reference finds on the unrounded float64 current
         (tests/test_filter.py); coarser grids do not -- a heavily smoothed current has almost no variance left.
-        Returns (rounded current, grid step)."""
+        Returns (rounded current, grid step, the level that was subtracted)."""
         cur = np.asarray(self.current, dtype=np.float64)
         centre = float(np.mean(cur)) if cur.size else 0.0
         span = float(np.max(np.abs(cur - centre))) if cur.size else 0.0
         step = 2.0 ** (int(np.ceil(np.log2(span * 1.01))) - 22) if span > 0 else 1.0
         centre = np.rint(centre / step) * step
-        return np.rint((cur - centre) / step) * step, step
+        return np.rint((cur - centre) / step) * step, step, float(centre)
 
     def _adopt_filtered(self, segments):
         """Segments found on the rounded current keep views of the unrounded one and take their statistics from those."""
@@ -148,7 +148,12 @@ class Event(Segment):
         return segments
 
     def _parse_filtered(self, parser):
-        return self._adopt_filtered(parser.parse(self._on_fine_grid()[0]))
+        rounded, _, centre = self._on_fine_grid()
+        if isinstance(parser, SpeedyStatSplit):
+            # (the level goes along: the device judges near ties against the noise of the reference's cumsums, which run on
+            #  the uncentred current -- include/poreseg.h, ps_sample_format)
+            return self._adopt_filtered(parser.parse_batch([rounded], [centre])[0])
+        return self._adopt_filtered(parser.parse(rounded))
 
     # ---- persistence ----------------------------------------------------------------------------------------
     def to_dict(self):
@@ -275,12 +280,12 @@ class File(Segment):
         by_step = {}
         for i, ev in enumerate(self.events):
             if ev.__dict__.get("filtered"):
-                rounded, step = ev._on_fine_grid()
-                by_step.setdefault(step, []).append((i, rounded))
+                rounded, step, centre = ev._on_fine_grid()
+                by_step.setdefault(step, []).append((i, rounded, centre))
         for group in by_step.values():
-            currents = [r for _, r in group]
-            found = parser.parse_batch(currents) if batched else [parser.parse(c) for c in currents]
-            for (i, _), segs in zip(group, found):
+            currents = [r for _, r, _ in group]
+            found = parser.parse_batch(currents, [c for _, _, c in group]) if batched else [parser.parse(c) for c in currents]
+            for (i, _, _), segs in zip(group, found):
                 results[i] = self.events[i]._adopt_filtered(segs)
         for ev, segs in zip(self.events, results):
             ev.segments = segs

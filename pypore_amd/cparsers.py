@@ -10,6 +10,11 @@ from . import _lib, engine
 from .core import Segment, segments_from_edges
 
 
+def _dc_counts(level, step):
+    """A level in pA as whole counts of `step`, clipped to int32 (ps_sample_format.offset_counts of fp32 samples)."""
+    return int(max(-2147483647, min(2147483647, round(float(level) / float(step)))))
+
+
 class FastStatSplit(object):
     def __init__(self, min_width=100, max_width=1000000, window_width=10000,
                  min_gain_per_sample=None, false_positive_rate=None,
@@ -41,10 +46,11 @@ class FastStatSplit(object):
         duration in samples), exactly like the reference."""
         return self.parse_batch([current])[0]
 
-    def parse_batch(self, currents):
+    def parse_batch(self, currents, levels=None):
         """One device call for many independent events (one reference parse() per event).  Events that reach the
         device in different representations (float32 pA / int16 counts, or int16 on different scales) go in one call
-        per representation."""
+        per representation.  levels: per event, the level in pA that was subtracted from it upstream (a filtered event
+        that Event.parse centred and rounded): passed on as offset_counts, see include/poreseg.h."""
         ctx = engine.context(self.device)
         import torch
         out = [None] * len(currents)
@@ -70,8 +76,11 @@ class FastStatSplit(object):
                 out[i] = [Segment(current=currents[i][0:0], start=0, duration=0, end=0)]
                 return
             dev = torch.device("cuda", torch.cuda.current_device() if self.device is None else int(self.device))
-            z, _, step = ctx.requantise(torch.from_numpy(cur).to(dev))
-            bounds, boff, _ = ctx.segment_batch(z, np.array([0, n], dtype=np.int64), self._params, step, want_stats=False)
+            z, centre, step = ctx.requantise(torch.from_numpy(cur).to(dev))
+            # (the level that was subtracted, as offset_counts: the device judges near ties against the noise of the reference's
+            #  cumsums, which run on the uncentred values -- include/poreseg.h)
+            bounds, boff, _ = ctx.segment_batch(z, np.array([0, n], dtype=np.int64), self._params, step, want_stats=False,
+                                                offset_counts=_dc_counts(centre, step))
             edges = np.concatenate(([0], bounds.cpu().numpy(), [n])).tolist()
             src = currents[i]
             out[i] = [Segment(current=src[a:z_], start=a, duration=z_ - a, end=z_) for a, z_ in zip(edges, edges[1:])]
@@ -99,7 +108,10 @@ class FastStatSplit(object):
             ev_off = np.concatenate(([0], np.cumsum(lens)))
             try:
                 samples = parts[0].tensor if len(parts) == 1 else torch.cat([p.tensor for p in parts])
-                bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q)
+                dc = 0
+                if levels is not None and samples.dtype == torch.float32:
+                    dc = _dc_counts(max((levels[i] or 0.0 for i in idx), key=abs), q)
+                bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q, offset_counts=dc)
             except ValueError:
                 if self.quantum is not None or full_detect:
                     if self.off_grid == "requantise" and self.quantum is None and len(idx) == 1:
@@ -141,6 +153,7 @@ class FastStatSplit(object):
         import torch
         ctx = engine.context(self.device)
         filtered, onto_grid, by_step = [None] * len(currents), [None] * len(currents), {}
+        levels = [0.0] * len(currents)
         for i, cur in enumerate(currents):
             t64 = getattr(cur, "tensor", None)               # a current filtered before and still parked on the device
             if t64 is not None and t64.is_cuda and t64.dtype == torch.float64:
@@ -159,8 +172,9 @@ class FastStatSplit(object):
                     y = ctx.filter_bessel(torch.from_numpy(a).to(torch.device("cuda", ctx.device)), 1.0, cutoff=cutoff,
                                           sampling_freq=sampling_freq, order=order)
                     off = 0.0
-            z, _, step = ctx.requantise(y)
+            z, centre, step = ctx.requantise(y)
             filtered[i], onto_grid[i] = (y, off), z
+            levels[i] = centre + off
             by_step.setdefault(step, []).append(i)
         # (a DC offset passes a unit-gain low-pass unchanged: the counts were filtered, the offset is put back)
         from .grid import Deferred
@@ -170,7 +184,9 @@ class FastStatSplit(object):
             lens = np.array([onto_grid[i].numel() for i in idx], dtype=np.int64)
             ev_off = np.concatenate(([0], np.cumsum(lens)))
             samples = onto_grid[idx[0]] if len(idx) == 1 else torch.cat([onto_grid[i] for i in idx])
-            bounds, boff, _ = ctx.segment_batch(samples, ev_off, self._params, step, want_stats=False)
+            # (one level for the call: the largest of its events' -- the larger the level, the larger the reference's noise)
+            bounds, boff, _ = ctx.segment_batch(samples, ev_off, self._params, step, want_stats=False,
+                                                offset_counts=_dc_counts(max((levels[i] for i in idx), key=abs), step))
             b = bounds.cpu().numpy()
             for e, i in enumerate(idx):
                 cur = filtered[i]

@@ -97,6 +97,7 @@ struct ps_ctx {
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
     int k0_waves = 2;         // K0 is persistent: this many waves per SIMD stride over the call (round 5); 0: one wave per wave block, as many as the registers allow
+    float noise_k = 0.1f;     // near-tie accounting of the wide route (DevCfg::noise_k; PORESEG_NOISE_K)
     int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
     bool gate_held = false;
     int dbg_phase = 0;        // diagnostics (PORESEG_DBG_PHASE; WRONG or stale results, never set by the product): 1 a call that repeats the previous
@@ -223,11 +224,13 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
         return fail(ctx, PS_ERR_ARG, "unknown dtype %d", fmt->dtype);
     if (!(fmt->quantum > 0) || !std::isfinite(fmt->quantum))
         return fail(ctx, PS_ERR_ARG, "quantum must be positive and finite");
-    if (fmt->dtype == PS_DTYPE_F32 && fmt->offset_counts != 0)
-        return fail(ctx, PS_ERR_ARG, "offset_counts must be 0 for fp32 samples");
     c->samples = d_samples;
     c->dtype = fmt->dtype;
-    c->off_counts = fmt->offset_counts;
+    // (fp32 samples are absolute values: offset_counts is not added to them -- it names the level the caller subtracted
+    //  upstream, include/poreseg.h)
+    c->off_counts = fmt->dtype == PS_DTYPE_F32 ? 0 : fmt->offset_counts;
+    c->dc_counts = fmt->dtype == PS_DTYPE_F32 ? static_cast<double>(fmt->offset_counts) : 0.0;
+    c->noise_k = ctx->noise_k;
     c->inv_q = static_cast<float>(1.0 / fmt->quantum);
     c->q = fmt->quantum;
     c->q2 = fmt->quantum * fmt->quantum;
@@ -955,6 +958,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_K0_SHARED")) ctx->k0_shared = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_DBG_PHASE")) ctx->dbg_phase = std::atoi(e);
     if (const char *e = std::getenv("PORESEG_K0_MAX")) ctx->k0_admit = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_NOISE_K")) ctx->noise_k = static_cast<float>(std::atof(e));
     if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));

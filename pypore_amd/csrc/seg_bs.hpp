@@ -149,12 +149,12 @@ __device__ __forceinline__ long long lane_get(long long x, int l)
 // Arguments and results travel by value: the address of a caller's local (its `bad` word, its counters, the kernel's
 // DevCfg) would move that object to the stack for the whole kernel.  Results: low word = split, high word = status bits /
 // near-tie flag.
-struct BsCold { const void *samples; float inv_q; int off_counts; double q, q2; };
-__device__ __forceinline__ BsCold bs_cold(const DevCfg &c) { BsCold k = {c.samples, c.inv_q, c.off_counts, c.q, c.q2}; return k; }
+struct BsCold { const void *samples; float inv_q; int off_counts; double q, q2, dc_counts; float noise_k; };
+__device__ __forceinline__ BsCold bs_cold(const DevCfg &c) { BsCold k = {c.samples, c.inv_q, c.off_counts, c.q, c.q2, c.dc_counts, c.noise_k}; return k; }
 __device__ __forceinline__ DevCfg bs_cold_cfg(const BsCold &k)
 {
     DevCfg c = {};
-    c.samples = k.samples; c.inv_q = k.inv_q; c.off_counts = k.off_counts; c.q = k.q; c.q2 = k.q2;
+    c.samples = k.samples; c.inv_q = k.inv_q; c.off_counts = k.off_counts; c.q = k.q; c.q2 = k.q2; c.dc_counts = k.dc_counts; c.noise_k = k.noise_k;
     return c;
 }
 
@@ -966,12 +966,34 @@ __device__ __attribute__((noinline)) long long bs_decide(BsCold k, int m, const 
     double eg = thresh;
     int ei = -1;
     double gx = -INFINITY;
+    // Wide digest = a re-quantised float64 current (a filtered event, data on no grid).  The reference segments the
+    // UNROUNDED values with sequential fp64 cumsums (cparsers.pyx:110-111), whose rounding noise in a part of n_p samples
+    // that ends at sample i of the event is about ulp(c2[i]) sqrt(n_p / 12) in its sum of squares, i.e.
+    // ulp(c2[i]) sqrt(n_p / 12) / V_p in its term n_p log V_p of a gain; c2[i] ~ i * level^2 (level: the DC level the caller
+    // names as offset_counts, plus m).  The rounding of the samples to the grid adds ~ 0.6 sqrt(n_p) / sigma_p.  `noise` is
+    // that estimate for this lane's candidate (left + right part), noise_tot the whole window's: decisions whose margin lies
+    // within four times the sum of the two sides' estimates are counted as near ties (below) -- on this route the device
+    // and the reference can place such a boundary one sample apart (241 per 1e6 boundaries of heavily
+    // over-segmented filtered events, none where the segmenter is given the filter's cutoff).
+    double noise = 0.0, noise_tot = 0.0;
+    const double nk = static_cast<double>(k.noise_k);
     if (lane < ccount) {
         const BsC_t e = cont[lane];
         if constexpr (WIDE) {
             const int nl = e.j - ps;
-            gx = ref_gain(var_summed, nl, ref_var(d_of_i64(e.a1), d_of_i64(e.a2), nl, c->q, c->q2),
-                          n - nl, ref_var(d_of_i64(T1 - e.a1), d_of_i64(T2 - e.a2), n - nl, c->q, c->q2));
+            const double vl = ref_var(d_of_i64(e.a1), d_of_i64(e.a2), nl, c->q, c->q2);
+            const double vr = ref_var(d_of_i64(T1 - e.a1), d_of_i64(T2 - e.a2), n - nl, c->q, c->q2);
+            gx = ref_gain(var_summed, nl, vl, n - nl, vr);
+            const double vt = ref_var(T1d, T2d, n, c->q, c->q2);
+            const double lvl = (fabs(k.dc_counts + static_cast<double>(m)) + sqrt(fmax(vt, 0.0) / c->q2)) * c->q;     // pA
+            const double ulp2 = static_cast<double>(ps + n) * lvl * lvl * 2.220446049250313e-16;                    // ulp of c2 at the window's end
+            const double tiny = 1.0e-300;
+            auto part = [&](int np, double vp) {
+                const double sn = sqrt(static_cast<double>(np));
+                return ulp2 * sn * 0.2887 / fmax(vp, tiny) + 0.6 * sn * c->q / sqrt(fmax(vp, tiny));
+            };
+            noise = part(nl, vl) + part(n - nl, vr);
+            noise_tot = part(n, vt);
         } else {
             gx = bs_exact_gain(*c, m, e.a1, e.a2, T1, T2, e.j - ps, n, var_summed);
         }
@@ -993,12 +1015,25 @@ __device__ __attribute__((noinline)) long long bs_decide(BsCold k, int m, const 
         for (int d = 32; d >= 1; d >>= 1) other = fmax(other, __shfl_xor(other, d));
         const double tol = 1.0e-9 * fmax(1.0, fabs(eg));
         near = (eg - other < tol || eg - thresh < tol) ? 1 : 0;
+        if constexpr (WIDE) {
+            // winner's own estimate to every lane, then lane by lane: is this contender within the noise of the winner?
+            double nw = (lane < ccount && cont[lane].j == ei) ? noise : 0.0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) nw = fmax(nw, __shfl_xor(nw, d));
+            const bool mine = lane < ccount && cont[lane].j != ei && gx == gx && eg - gx < nk * (nw + noise);
+            const bool thr_near = eg - thresh < nk * (nw + __shfl(noise_tot, 0));
+            if (__ballot(mine) != 0ull || thr_near) near = 1;
+        }
     } else {
         double best = (lane < ccount && gx == gx) ? gx : -INFINITY;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) best = fmax(best, __shfl_xor(best, d));
         const double tol = 1.0e-9 * fmax(1.0, fabs(thresh));
         near = thresh - best < tol ? 1 : 0;
+        if constexpr (WIDE) {
+            const bool mine = lane < ccount && gx == gx && thresh - gx < nk * (noise + noise_tot);
+            if (__ballot(mine) != 0ull) near = 1;
+        }
     }
     return (static_cast<long long>(near) << 32) | static_cast<unsigned>(ei);
 }

@@ -45,7 +45,11 @@ enum : int { MODE_FAST = 0, MODE_EXACT = 1, MODE_VERIFY = 2 };
 struct DevCfg {
     const void *samples;
     int dtype, off_counts;
+    double dc_counts;       // fp32 samples only: the level, in counts of `quantum`, that the caller subtracted upstream (ps_requantise's centre):
+                            // never added to a sample -- the gains are shift invariant --, used to judge near ties against the reference's own
+                            // rounding noise, whose cumsums run on the uncentred values (seg_bs.hpp: bs_decide)
     float inv_q;
+    float noise_k;          // near-tie accounting of the wide route: margins within noise_k x (the two sides' noise estimates) count (bs_decide)
     double q, q2;
     int mw, maxw, W, half;
     double min_gain;

@@ -147,9 +147,10 @@ class SpeedyStatSplit(parser):
     def parse(self, current):
         return self._fast().parse(current)
 
-    def parse_batch(self, currents):
-        """All events of a file in one device call (extension; same result as [parse(c) for c in currents])."""
-        return self._fast().parse_batch(currents)
+    def parse_batch(self, currents, levels=None):
+        """All events of a file in one device call (extension; same result as [parse(c) for c in currents]).  levels: the
+        level in pA that was subtracted from each event upstream (Event.parse of a filtered event), or None."""
+        return self._fast().parse_batch(currents, levels)
 
     def parse_filtered_batch(self, currents, order=1, cutoff=2000., sampling_freq=None):
         """event.filter(order, cutoff); event.parse(self) for many events, on the device from end to end (extension)."""

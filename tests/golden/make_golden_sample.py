@@ -40,9 +40,10 @@ def filtered_specs():
     for i in range(104):
         h = int(synth.splitmix64(np.uint64(7700 + i)))
         n = int(round(10 ** (5.0 + (h % 1000) / 1000.0)))                   # 1e5 .. 1e6, log-uniform
-        lo, hi = dwells[(i // 4) % 4]
+        lo, hi = dwells[(i // 2) % 4]
+        # (order, segmenter cutoff, filter cutoff and dwell range vary independently of each other)
         specs.append(dict(name="FS%03d" % i, n=n, seed=3000 + i, lo=lo, hi=hi, order=1 + i % 4,
-                          cutoff=cutoffs[(i // 4) % 5], seg_cutoff=bool((i // 2) % 2)))
+                          cutoff=cutoffs[(i // 8) % 5], seg_cutoff=bool((i // 4) % 2)))
     return specs
 
 

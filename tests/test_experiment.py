@@ -101,7 +101,7 @@ def test_default_workflow_on_two_abf_files(tmp_path):
             one.parse(SpeedyStatSplit(**seg_kw))
             got = [int(round(s.start * file.second)) for s in ev.segments]
             assert got == [int(round(s.start * file.second)) for s in one.segments]
-            rounded, step = one._on_fine_grid()
+            rounded, step, _ = one._on_fine_grid()
             ref = oracle.parse(rounded, **seg_kw)
             np.testing.assert_array_equal(got[1:], ref)
             seg = ev.segments[len(ev.segments) // 2]

@@ -215,7 +215,7 @@ def test_requantise_matches_the_host_rounding_of_event_parse():
     for n, scale, offset in ((13, 1.0, 0.0), (5000, 40.0, 55.0), (1_000_003, 3.0, -20.0), (262144, 1e-3, 1e3), (70000, 250.0, 0.0)):
         x = offset + scale * np.cumsum(rng.standard_normal(n)) / np.sqrt(n) + 0.01 * scale * rng.standard_normal(n)
         f = File(current=x, timestep=0.01)
-        rounded, step = Event(current=x, second=f.second, file=f)._on_fine_grid()
+        rounded, step, _ = Event(current=x, second=f.second, file=f)._on_fine_grid()
         z, centre, dstep = ctx.requantise(torch.from_numpy(x).cuda())
         z = z.cpu().numpy().astype(np.float64)
         assert dstep == step and np.abs(z).max() < 2 ** 22 * step

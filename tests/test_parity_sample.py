@@ -1,0 +1,130 @@
+"""The two routes on which parity with the reference is empirical, on a sample large enough to quote a rate (VERDICT r4
+next #6): 104 filtered events (orders 1-4, cutoffs 500-5000 Hz, 1e5-1e6 samples) and 52 float64 traces on no ADC grid,
+every boundary against what the compiled, unmodified reference found (tests/golden/make_golden_sample.py;
+cparsers.pyx:53,103-118 takes any double[:], DataTypes.py:258-289 is the default workflow).
+
+The device segments such input on exact integer sums of a re-quantised copy, so equality is not a
+theorem here.  The tests count: boundaries compared, boundaries that differ, cases that differ, and which of the
+differing cases raised engine.NearTieWarning; the report goes to gpurun_out/parity_sample_report.json (and the counts of
+the last recorded run are in DESIGN.md section 2).  CPU side: the manifest and the arrays are consistent."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from pypore_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+MAN = json.load(open(os.path.join(HERE, "golden", "manifest_sample.json")))
+NPZ = np.load(os.path.join(HERE, "golden", "golden_sample.npz"))
+SECOND = 1.e5
+# What the recorded run of the final build found (tools/parity_sample_report.py prints the same numbers): the bar of the
+# GPU tests is "no worse than that" -- a new mismatch fails.
+# Round 5, final build: 0 of 6 807 boundaries differ on the 52 off-grid traces; 0 of 8 435 on the 52 filtered events whose
+# segmenter is given the filter's cutoff (Experiment.parse's default passes cutoff_freq); 102 of 152 351 boundaries (670 per
+# 1e6) of the 52 filtered events segmented WITHOUT cutoff_freq -- a smooth current cut every ~130 samples -- lie one sample
+# (rarely a few) beside the reference's, in these 15 events, the same ones whether the device or scipy filtered, and every
+# one of them raises NearTieWarning (the windows in question are decided within the noise of the reference's own cumsums).
+_D = {"FS001", "FS002", "FS003", "FS018", "FS019", "FS041", "FS042", "FS043", "FS049", "FS051", "FS065", "FS080", "FS081",
+      "FS082", "FS083"}
+KNOWN_DIFFERING = {"filtered": _D, "filtered_scipy": _D, "offgrid": set()}
+
+
+def _seg_params(case):
+    p = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=SECOND)
+    if case.get("seg_cutoff"):
+        p["cutoff_freq"] = case["cutoff"]
+    p.update(case.get("params", {}))
+    return p
+
+
+def _event_current(case):
+    return synth.random_dwell_counts(case["n"], case["seed"], case["lo"], case["hi"]).astype(np.float64) * synth.QUANTUM
+
+
+def test_sample_manifest_is_consistent():
+    cases = MAN["cases"]
+    assert sum(c["op"] == "filtered" for c in cases) >= 100 and sum(c["op"] == "offgrid" for c in cases) >= 50
+    for c in cases:
+        b = NPZ[c["name"]]
+        assert b.dtype == np.int32 and b.size == c["n_bounds"]
+        assert b.size == 0 or (np.all(np.diff(b) >= _seg_params(c)["min_width"]) and 0 < b[0] and b[-1] < c["n"])
+    f = [c for c in cases if c["op"] == "filtered"]
+    assert {c["order"] for c in f} == {1, 2, 3, 4} and min(c["cutoff"] for c in f) == 500. and max(c["cutoff"] for c in f) == 5000.
+    assert min(c["n"] for c in f) >= 100000 and max(c["n"] for c in f) <= 1000000
+
+
+def run_case(case, route):
+    """Boundaries the device finds for one case; (bounds, near_tie_warned)."""
+    from pypore_amd import engine
+    from pypore_amd.DataTypes import Event, File
+    from pypore_amd.parsers import SpeedyStatSplit
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        if case["op"] == "offgrid":
+            x = synth.offgrid_trace(case["n"], case["seed"], case["sigma"], case["lo"], case["hi"])
+            segs = SpeedyStatSplit(off_grid="requantise", **_seg_params(case)).parse(x)
+            got = np.array([s.start for s in segs[1:]], dtype=np.int64)
+        elif route == "filtered":
+            # the product's workflow: the device filters (Event.filter), then Event.parse of the filtered event
+            x = _event_current(case)
+            f = File(current=x, timestep=1000. / SECOND)
+            ev = Event(current=x, start=0., end=len(x) / SECOND, duration=len(x) / SECOND, second=SECOND, file=f)
+            ev.filter(order=case["order"], cutoff=case["cutoff"])
+            ev.parse(SpeedyStatSplit(**_seg_params(case)))
+            got = np.array([int(round(s.start * SECOND)) for s in ev.segments[1:]], dtype=np.int64)
+        else:
+            # the reference's own input: scipy's filtfilt on the host, segmented as float64 on no grid
+            import scipy.signal as signal
+            (b, a) = signal.bessel(case["order"], case["cutoff"] / (SECOND / 2.), btype='low', analog=0, output='ba')
+            y = signal.filtfilt(b, a, _event_current(case))
+            segs = SpeedyStatSplit(off_grid="requantise", **_seg_params(case)).parse(y)
+            got = np.array([s.start for s in segs[1:]], dtype=np.int64)
+    near = any(issubclass(m.category, engine.NearTieWarning) for m in w)
+    return got, near
+
+
+def compare(route):
+    op = "offgrid" if route == "offgrid" else "filtered"
+    rep = dict(route=route, cases=0, boundaries=0, differing_boundaries=0, differing_cases=[], near_tie_cases=[])
+    for case in MAN["cases"]:
+        if case["op"] != op:
+            continue
+        ref = NPZ[case["name"]].astype(np.int64)
+        got, near = run_case(case, route)
+        rep["cases"] += 1
+        rep["boundaries"] += int(ref.size)
+        if near:
+            rep["near_tie_cases"].append(case["name"])
+        if not np.array_equal(got, ref):
+            d = int(np.setxor1d(got, ref).size)
+            rep["differing_boundaries"] += d
+            rep["differing_cases"].append(dict(name=case["name"], ref=int(ref.size), got=int(got.size), xor=d, near_tie_warned=near,
+                                               first_ref_only=[int(v) for v in np.setdiff1d(ref, got)[:4]],
+                                               first_got_only=[int(v) for v in np.setdiff1d(got, ref)[:4]]))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_sample_report.json")
+        allrep = json.load(open(path)) if os.path.exists(path) else {}
+        allrep[route] = rep
+        json.dump(allrep, open(path, "w"), indent=1)
+    except OSError:
+        pass
+    return rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["filtered", "filtered_scipy", "offgrid"])
+def test_sample_against_the_compiled_reference(route):
+    rep = compare(route)
+    assert rep["cases"] >= 50
+    new = {c["name"] for c in rep["differing_cases"]} - KNOWN_DIFFERING[route]
+    assert not new, (rep["differing_boundaries"], rep["boundaries"], rep["differing_cases"][:5])
+    # every case that differs raised engine.NearTieWarning: the device says where a decision lies within the noise of the
+    # reference's own sums
+    silent = [c["name"] for c in rep["differing_cases"] if not c["near_tie_warned"]]
+    assert not silent, silent
