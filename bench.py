@@ -208,7 +208,7 @@ def selftest_dist(args):
     ok["job_gather"] = all(torch.equal(jg.row(r, k), mk(r, k)) for r in range(world) for k in range(K)) \
         and jg.last_counts() == [3 + 2 * r + K - 1 for r in range(world)]
     # sharded trace: boundaries every 700 samples, every one a spine anchor; a piece reports those inside it
-    n, W, mw = 200000, 2000, 100
+    n, W, mw = 200000 if world <= 4 else 480000, 2000, 100
     halo = 8 * W
     ranges = pdist.shard_ranges(n, world, halo)
     truth = np.arange(700, n, 700, dtype=np.int64)
@@ -222,17 +222,43 @@ def selftest_dist(args):
     got = sharded_trace_join(b, sp, ranges, n, W, mw, halo,
                              lambda r_up, lo2, hi2: sharded_trace_repair(rank, r_up, lambda: piece(lo2, hi2), dev))
     ok["sharded_trace_join"] = bool(np.array_equal(np.asarray(got, dtype=np.int64), truth[truth < n - mw]))
-    # files gather
-    mine = pdist.shard_units([1000 + 10 * f for f in range(7)], world)[rank]
-    cnts, cat = files_job_gather([torch.full((f + 1,), f, dtype=torch.int32) for f in mine], dev)
-    shards = pdist.shard_units([1000 + 10 * f for f in range(7)], world)
-    ok["files_gather"] = all([int(c) for c in cnts[r]] == [f + 1 for f in shards[r]] and
-                             [int(x) for x in cat[r]] == [f for f in shards[r] for _ in range(f + 1)] for r in range(world))
+    # the same with a FORCED seam repair (round 5): no boundary from 3 000 samples before the second piece's start to 3 000
+    # behind the end of its upstream neighbour's halo -- the two pieces share no anchor, the upstream rank re-segments a
+    # longer stretch until it meets a downstream chain (dist.stitch_pieces: extend and re-run that seam only)
+    if world > 1:
+        s1 = ranges[1][0]
+        truth2 = truth[(truth < s1 - 3000) | (truth > s1 + halo + 3000)]
+        repairs = [0]
+
+        def piece2(lo_, hi_):
+            b_ = truth2[(truth2 >= lo_ + 1) & (truth2 < hi_ - mw)] - lo_
+            return torch.from_numpy(b_.astype(np.int32)), torch.ones(b_.size, dtype=torch.uint8)
+
+        def repair2(r_up, lo2, hi2):
+            repairs[0] += 1
+            return sharded_trace_repair(rank, r_up, lambda: piece2(lo2, hi2), dev)
+
+        b2, sp2 = piece2(lo, hi)
+        got2 = sharded_trace_join(b2, sp2, ranges, n, W, mw, halo, repair2)
+        ok["sharded_trace_join_with_seam_repair"] = bool(np.array_equal(np.asarray(got2, dtype=np.int64), truth2[truth2 < n - mw])) \
+            and repairs[0] >= 1
+    # files gather; BASELINE config 4's shard: 64 files over the ranks (shard_units, longest first), every file exactly once
+    n_units = 64 if world >= 8 else 7
+    unit_len = [1000 + 10 * ((7 * f) % n_units) for f in range(n_units)]
+    shards = pdist.shard_units(unit_len, world)
+    mine = shards[rank]
+    cnts, cat = files_job_gather([torch.full((f % 9 + 1,), f, dtype=torch.int32) for f in mine], dev)
+    ok["files_gather"] = all([int(c) for c in cnts[r]] == [f % 9 + 1 for f in shards[r]] and
+                             [int(x) for x in cat[r]] == [f for f in shards[r] for _ in range(f % 9 + 1)] for r in range(world))
+    loads = [sum(unit_len[f] for f in sh) for sh in shards]
+    ok["files_shard_covers_every_unit_once"] = sorted(f for sh in shards for f in sh) == list(range(n_units))
+    ok["files_shard_balanced"] = max(loads) <= 1.1 * (sum(loads) / world) + max(unit_len)
     tmax, every = max_over_ranks(0.001 * (rank + 1), dev)
     ok["clock"] = abs(tmax - 0.001 * world) < 1e-12 and len(every) == world
     if rank == 0:
         print(json.dumps({"selftest": "dist", "ok": bool(all(ok.values())), "checks": ok, "ranks_seen": dist.get_world_size(),
-                          "backend": dist.get_backend()}))
+                          "backend": dist.get_backend(), "files_units": n_units,
+                          "shard_imbalance": round(max(loads) / (sum(loads) / world), 4)}))
     dist.destroy_process_group()
     return 0 if all(ok.values()) else 1
 
@@ -435,6 +461,10 @@ def main():
         samples_per_step = n * n_files
         bytes_per_sample = 2
         scaling = "strong"
+        # how evenly shard_units dealt the files (longest-first greedy, DataTypes.py:968-984 is the shard axis)
+        loads = [sum(lens[f] for f in sh) for sh in shards]
+        check["files_per_rank"] = [len(sh) for sh in shards]
+        check["shard_imbalance"] = round(max(loads) / (sum(loads) / len(loads)), 4) if sum(loads) else 1.0
 
     torch.cuda.synchronize()
     # CPython's cyclic collector is stop-the-world: a full collection walks every object torch and numpy created at
@@ -570,6 +600,35 @@ def main():
             assert all(v for v in check.values() if isinstance(v, bool)), check
     else:
         n_bounds = [int(sum(r[2].numel() for r in result))]
+        if rank == 0 and mine:
+            # every distinct table the step segmented == the same file segmented on its own (fresh upload, one call, outside
+            # the timed region); the first events of the first table also against the CPU restatement of the reference
+            from pypore_amd import pipeline as _pl
+            ok_tables = {}
+            for j, f in enumerate(mine):
+                tb = f % n_tables
+                if tb in ok_tables:
+                    continue
+                one = torch.empty(n, dtype=torch.int16, device=device)
+                one.copy_(host[tb])
+                st1, ln1, b1, o1, _ = _pl.segment_file_trace(one, synth.QUANTUM, params, threshold=90.0)
+                st0, ln0, b0, o0 = result[j]
+                ok_tables[tb] = bool(np.array_equal(st0, st1) and np.array_equal(ln0, ln1) and torch.equal(b0, b1) and np.array_equal(o0, o1))
+                if tb == mine[0] % n_tables and not args.no_cpu:
+                    import oracle
+                    x0 = host[tb].numpy()
+                    okc, took = True, 0
+                    for e in range(min(3, len(st1))):
+                        a_, l_ = int(st1[e]), int(ln1[e])
+                        ref = oracle.parse(x0[a_:a_ + l_].astype(np.float64) * synth.QUANTUM, **PARAMS)
+                        okc = okc and bool(np.array_equal(ref, b1[int(o1[e]):int(o1[e + 1])].cpu().numpy()))
+                        took += 1
+                    check["first_events_equal_cpu_oracle"] = okc
+                    check["events_checked_against_cpu_oracle"] = took
+                del one
+            check["tables_equal_standalone_segmentation"] = ok_tables
+            check["events_per_table"] = {int(f % n_tables): int(len(result[j][0])) for j, f in enumerate(mine)}
+            assert all(ok_tables.values()) and check.get("first_events_equal_cpu_oracle", True), check
 
     if rank == 0:
         # (files: many calls per step, PCIe-inclusive; several streams: calls overlap, the job's clock is the measure)
@@ -606,6 +665,8 @@ def main():
                        "segment_stats_in_step": bool(args.stats), "checks": check, "streams": T,
                        # what torch.distributed (RCCL on the GPU box) itself reports, and every rank's own clock
                        "ranks_seen": dist.get_world_size() if use_dist else 1,
+                       # every rank's boundary count of its last batch (the gathered counts when N > 1)
+                       "per_rank_boundaries": [int(x_) for x_ in n_bounds],
                        "ms_per_step_per_rank": [round(x_, 4) for x_ in per_rank_ms],
                        "streams_note": ("step k runs on context k %% %d (own HIP stream and scratch, one host thread each): "
                                         "independent batches overlap on the GPU; every step is a complete, synchronised "
@@ -693,6 +754,34 @@ def main():
                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": 2 * n, "achieved": round(2 * n / tf / 1e9, 2),
                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(2 * n / tf / HBM_PEAK, 5)}}
             del ftraces
+        # ---- BASELINE config 2: 1 024 events x 50 000 samples in ONE call -----------------------
+        if wl == "trace" and not args.no_detail and world == 1 and n == 100_000_000 and not args.dwell:
+            n_ev2, ln2 = 1024, 50000
+            e2, l2 = [], []
+            for e_ in range(n_ev2):
+                for k_ in range(5):
+                    e2.append(e_ * ln2 + (k_ + 1) * 10000)
+                    l2.append(int(synth.LEVEL_COUNTS[k_]))
+            t2_ = ctx.synth_trace(n_ev2 * ln2, 7, np.array(e2), np.array(l2, dtype=np.int32), dtype=torch.float32)
+            off2 = np.arange(n_ev2 + 1, dtype=np.int64) * ln2
+            for _ in range(3):
+                b2, o2, _ = ctx.segment_batch(t2_, off2, params, synth.QUANTUM, want_stats=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            s2 = 0.0
+            for _ in range(20):
+                b2, o2, _ = ctx.segment_batch(t2_, off2, params, synth.QUANTUM, want_stats=False)
+                s2 += ctx.seq_ms()
+            torch.cuda.synchronize()
+            tc2 = (time.perf_counter() - t1) / 20
+            out["config2"] = {
+                "workload": "BASELINE config 2: %d events x %d samples (5 levels x 10 000 each), one ps_segment_batch, one call at a time" % (n_ev2, ln2),
+                "ms_per_step": round(tc2 * 1e3, 4), "sequence_ms": round(s2 / 20, 4), "value": round(n_ev2 * ln2 / tc2 / 1e6, 2),
+                "unit": "Msamples/s", "steps": 20, "boundaries": int(b2.numel()),
+                "events_with_exactly_their_four_steps": int(np.sum(np.diff(o2) == 4)),
+                "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": 4 * n_ev2 * ln2, "achieved": round(4 * n_ev2 * ln2 / tc2 / 1e9, 2),
+                             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(4 * n_ev2 * ln2 / tc2 / HBM_PEAK, 5)}}
+            del t2_
         # ---- PCIe-inclusive rate (report H2D-inclusive separately; never `value`) ------------------
         if wl == "trace" and not args.no_h2d and world == 1:
             P = 8

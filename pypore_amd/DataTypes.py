@@ -373,32 +373,60 @@ class Experiment(object):
 
     _DEFAULT = object()
 
-    def parse(self, event_detector=None, segmenter=_DEFAULT, filter_params=(1, 2000), verbose=True, meta=False):
+    def parse(self, event_detector=None, segmenter=_DEFAULT, filter_params=(1, 2000), verbose=True, meta=False, workers=None):
         """Defaults as in the reference (:956-960): lambda_event_parser(threshold=90), SpeedyStatSplit with
         prior_segments_per_second=10 and cutoff_freq=2000, a first-order 2 kHz Bessel filter.  segmenter=None: events
-        are detected (and filtered) only; filter_params=None: no filter; meta=True: the currents are dropped afterwards."""
+        are detected (and filtered) only; filter_params=None: no filter; meta=True: the currents are dropped afterwards.
+
+        The reference takes one file after the other (:968-984).  Files are independent, so here up to `workers` of them
+        are in flight (default: 4 when detector and segmenter are this package's own device classes, else 1): while file
+        k is segmented, file k+1 is read, uploaded and searched for events on another host thread -- every thread has
+        its own device context (engine.context), its kernels overlap with the others' like the contexts of a StreamPool.
+        `files`, and the lines printed with verbose=True, keep the order of `filenames` whatever finishes first."""
         if event_detector is None:
             event_detector = lambda_event_parser(threshold=90)
         if segmenter is Experiment._DEFAULT:
             segmenter = SpeedyStatSplit(prior_segments_per_second=10, cutoff_freq=2000.)
-        for entry in self.filenames:
+        entries = list(self.filenames)
+        if workers is None:
+            ours = isinstance(event_detector, lambda_event_parser) and getattr(event_detector, "_builtin", False) and \
+                (segmenter is None or isinstance(segmenter, SpeedyStatSplit))
+            workers = 4 if ours else 1
+        workers = max(1, min(int(workers), len(entries)))
+
+        def one(entry, say=None):
+            lines = []
+            say = say or lines.append                    # (one file at a time: the lines appear as the reference prints them)
             file = entry if isinstance(entry, File) else File(entry)
-            if verbose:
-                print("Opening {}".format(file.filename))
+            say("Opening {}".format(file.filename))
             file.parse(parser=event_detector)
-            if verbose:
-                print("\tDetected {} Events".format(file.n))
+            say("\tDetected {} Events".format(file.n))
             if segmenter is not None:
                 file.parse_events(segmenter, filter_params)
-                if verbose:
-                    for i, event in enumerate(file.events):
-                        print("\t\tEvent {} has {} segments".format(i + 1, event.n))
+                for i, event in enumerate(file.events):
+                    say("\t\tEvent {} has {} segments".format(i + 1, event.n))
             elif filter_params is not None:
                 for event in file.events:
                     event.filter(*filter_params)
             if meta:
                 file.to_meta()
+            return file, lines
+
+        def take(done):
+            file, lines = done
+            if verbose:
+                for line in lines:
+                    print(line)
             self.files.append(file)
+
+        if workers == 1:
+            for entry in entries:
+                take(one(entry, print if verbose else (lambda line: None)))
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="pypore-file") as pool:
+            for fut in [pool.submit(one, entry) for entry in entries]:
+                take(fut.result())
 
     def apply_hmm(self, hmm, filter=None, indices=None):
         raise NotImplementedError("HMM decoding needs yahmm (out of scope)")

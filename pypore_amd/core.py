@@ -147,18 +147,29 @@ class _Record(object):
         return MetaSegment(**d)
 
 
+_gc_lock = __import__("threading").Lock()
+_gc_state = [0, True]                                  # [nesting count over all threads, was the collector enabled]
+
+
 @contextmanager
 def gc_paused():
     """No cyclic collections while a result list is built: tens of thousands of small objects trigger several full
     collections, each of which walks everything torch and numpy created at import (3 of 6 us per Segment)."""
     import gc
-    was = gc.isenabled()
-    gc.disable()
+    # (counted: several host threads build result lists at once -- Experiment.parse with workers -- and the collector
+    #  comes back on when the last of them is done)
+    with _gc_lock:
+        if _gc_state[0] == 0:
+            _gc_state[1] = gc.isenabled()
+            gc.disable()
+        _gc_state[0] += 1
     try:
         yield
     finally:
-        if was:
-            gc.enable()
+        with _gc_lock:
+            _gc_state[0] -= 1
+            if _gc_state[0] == 0 and _gc_state[1]:
+                gc.enable()
 
 
 def segments_from_edges(current, edges, stats=None):

@@ -16,6 +16,17 @@ from . import _lib
 _contexts = {}
 
 
+def _serialised(method):
+    """The method runs under its Context's lock."""
+    import functools
+
+    @functools.wraps(method)
+    def call(self, *a, **kw):
+        with self.lock:
+            return method(self, *a, **kw)
+    return call
+
+
 class Context(object):
     """Owns a ps_ctx bound to GPU `device` (one process per GPU; one host thread at a time)."""
 
@@ -28,6 +39,7 @@ class Context(object):
         _lib.check(L.ps_create(self.device, None, ctypes.byref(h)))
         self.handle = h
         self.L = L
+        self.lock = threading.RLock()                   # one call at a time per ps_ctx (see engine.context)
 
     def close(self):
         if self.handle:
@@ -72,6 +84,7 @@ class Context(object):
         return int(self._cnt[11])
 
     # ---- the hot path ---------------------------------------------------------------------------
+    @_serialised
     def segment_batch(self, samples, ev_off, params, quantum, offset_counts=0, want_stats=True, cap=None,
                       want_spine=False, lead=0, out=None):
         """ps_segment_batch on device-resident `samples` (torch float32 or int16 CUDA tensor).
@@ -128,6 +141,7 @@ class Context(object):
             return _lib.SampleFormat(_lib.PS_DTYPE_I16, int(offset_counts), float(quantum))
         raise ValueError("samples must be float32 or int16, got %s" % samples.dtype)
 
+    @_serialised
     def detect_events(self, samples, quantum, threshold=90.0, min_duration=100000, min_current=-0.5,
                       offset_counts=0):
         """ps_detect_events on a device-resident trace: (starts, lengths) int64 numpy arrays of the
@@ -147,6 +161,7 @@ class Context(object):
                    self.handle)
         return st[:cnt.value].copy(), ln[:cnt.value].copy()
 
+    @_serialised
     def segment_events(self, samples, ev_start, ev_len, params, quantum, offset_counts=0, want_stats=False):
         """ps_segment_events: events are sub-ranges [start, start+len) of one device-resident trace."""
         assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
@@ -170,6 +185,7 @@ class Context(object):
         total = int(boff[-1])
         return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None)
 
+    @_serialised
     def best_single_split(self, samples, quantum, offset_counts=0):
         fmt = _lib.SampleFormat(_lib.PS_DTYPE_F32 if samples.dtype == torch.float32 else _lib.PS_DTYPE_I16,
                                 int(offset_counts), float(quantum))
@@ -180,6 +196,7 @@ class Context(object):
                                                samples.numel(), ctypes.byref(g), ctypes.byref(i)), self.handle)
         return g.value, i.value
 
+    @_serialised
     def audit_bounds(self, samples, quantum, params, windows, offset_counts=0):
         """ps_audit_bounds (diagnostic): the pruning bounds of the block-sum scan -- corner, two-boundary, group -- against
         the gains they cover, evaluated on the device from the raw samples, for the given windows [(ps, pe), ...] of the
@@ -197,6 +214,7 @@ class Context(object):
                 "group": {"groups": int(o[4]), "violations": int(o[5]), "min_margin": o[8]},
                 "windows_with_coarse_pass": int(o[9])}
 
+    @_serialised
     def score_window(self, samples, quantum, min_width, min_gain, offset_counts=0):
         fmt = _lib.SampleFormat(_lib.PS_DTYPE_F32 if samples.dtype == torch.float32 else _lib.PS_DTYPE_I16,
                                 int(offset_counts), float(quantum))
@@ -208,6 +226,7 @@ class Context(object):
                                           ctypes.c_void_p(scores.data_ptr()), ctypes.byref(i)), self.handle)
         return i.value, scores[:samples.numel()]
 
+    @_serialised
     def filter_bessel(self, samples, quantum, cutoff=2000., sampling_freq=1.e5, order=1, offset_counts=0):
         """ps_filter_bessel: Event.filter (DataTypes.py:258-274) -- Bessel low-pass of order 1..8, forward and backward
         (scipy filtfilt semantics); returns the filtered current in pA as a float64 CUDA tensor.  `samples`: float32 pA on
@@ -225,6 +244,7 @@ class Context(object):
                                            ctypes.c_void_p(out.data_ptr())), self.handle)
         return out[:samples.numel()]
 
+    @_serialised
     def requantise(self, current):
         """ps_requantise: a filtered current (float64 CUDA tensor, pA) centred and rounded to the finest power-of-two
         grid that keeps its counts below 2**22.  Returns (float32 CUDA tensor on that grid, centre, step): segment it
@@ -237,6 +257,7 @@ class Context(object):
                                         ctypes.c_void_p(out.data_ptr()), ctypes.byref(centre), ctypes.byref(step)), self.handle)
         return out[:current.numel()], centre.value, step.value
 
+    @_serialised
     def align_batch(self, model_means, model_stds, model_durs, skip_penalty, backslip_penalty,
                     seq_means, seq_stds, seq_durs, seq_off):
         """ps_align_batch: cSegmentAligner.align (calignment.pyx:20-100) for a batch of sequences.  Model arrays: host
@@ -264,6 +285,7 @@ class Context(object):
                                          ctypes.c_void_p(status.data_ptr())), self.handle)
         return scores[:n_seq], paths[:int(off[-1])], status[:n_seq]
 
+    @_serialised
     def synth_trace(self, n, seed, seg_end, level_counts, dtype=torch.float32, start=0):
         """Synthetic step trace generated directly in HBM (csrc synth_kernel == pypore_amd.synth).  start > 0: the
         samples [start, start + n) of the trace the table describes (a rank's piece of one long trace): the noise hash
@@ -410,14 +432,33 @@ class StreamPool(object):
                                                                           offset_counts=offset_counts, want_stats=want_stats))
 
 
+_thread_contexts = threading.local()
+_contexts_lock = threading.Lock()
+
+
 def context(device=None):
-    """The process-wide Context of `device` (default: torch's current device)."""
+    """The Context of `device` (default: torch's current device) that belongs to the CALLING THREAD.
+
+    A ps_ctx serves one call at a time (its stream, its scratch, its status block).  The reference is safe under the GIL
+    (a new FastStatSplit per parse()); here ctypes drops the GIL for the duration of a call, so two threads that call
+    SpeedyStatSplit.parse at once must not meet in one ps_ctx.  The main thread keeps the process-wide context of the
+    device; every other thread gets one of its own on first use (its own HIP stream and scratch: calls of different threads
+    overlap on the GPU like the contexts of a StreamPool) and gives it back when the thread ends.  Each Context also
+    carries a lock that its calls take, for code that hands ONE Context to several threads."""
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     device = int(device)
-    if device not in _contexts:
-        _contexts[device] = Context(device)
-    return _contexts[device]
+    if threading.current_thread() is threading.main_thread():
+        with _contexts_lock:
+            if device not in _contexts:
+                _contexts[device] = Context(device)
+            return _contexts[device]
+    mine = getattr(_thread_contexts, "by_device", None)
+    if mine is None:
+        mine = _thread_contexts.by_device = {}
+    if device not in mine:
+        mine[device] = Context(device)
+    return mine[device]
 
 
 # ---- host-side input normalisation -------------------------------------------------------------

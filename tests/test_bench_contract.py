@@ -41,6 +41,23 @@ def test_gpus_n_starts_by_itself_and_relays_rank0_line():
     assert d["ok"] is True and d["ranks_seen"] == 2 and all(d["checks"].values()), d
 
 
+def test_world_of_eight_over_gloo_incl_a_forced_seam_repair_and_the_64_file_shard():
+    """The first SCALE run must not die on plumbing: `bench.py --gpus 8 --selftest-dist` -- eight ranks
+    through the real launcher path on CPU tensors over gloo: the job gather, the sharded-trace join, the same join with a
+    seam that shares no anchor (the upstream rank re-segments, dist.stitch_pieces' repair), BASELINE config 4's shard of 64
+    files (every file once, balanced), the max-over-ranks clock."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--selftest-dist"], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["ok"] is True and d["ranks_seen"] == 8 and all(d["checks"].values()), d
+    assert d["files_units"] == 64 and d["checks"]["sharded_trace_join_with_seam_repair"] and d["shard_imbalance"] < 1.1
+
+
 def test_self_launch_command_line(monkeypatch):
     """the launcher's command: one node, N processes, rendezvous on 127.0.0.1, this file with the caller's arguments; no exec"""
     import importlib.util

@@ -1,0 +1,72 @@
+"""Two host threads in the segmenter at once.  The reference is safe under the GIL -- a new FastStatSplit
+per parse(), nothing shared (parsers.py:524-528); here ctypes drops the GIL during a call, so the threads must not meet
+in one ps_ctx: engine.context() hands every thread its own, and a Context that IS shared serialises its calls."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from pypore_amd import synth
+
+
+def test_every_thread_gets_its_own_context_handle(monkeypatch):
+    """engine.context(): the main thread keeps the process-wide context of a device, another thread gets its own."""
+    from pypore_amd import engine
+
+    class Fake(object):
+        def __init__(self, device):
+            self.device = device
+    monkeypatch.setattr(engine, "Context", Fake)
+    monkeypatch.setattr(engine, "_contexts", {})
+    a = engine.context(0)
+    assert engine.context(0) is a
+    seen = []
+    th = threading.Thread(target=lambda: seen.extend([engine.context(0), engine.context(0)]))
+    th.start(); th.join()
+    assert seen[0] is seen[1] and seen[0] is not a
+
+
+@pytest.mark.gpu
+def test_two_threads_parse_concurrently():
+    from pypore_amd.parsers import SpeedyStatSplit
+    traces = [np.asarray(synth.counts_to_pa(synth.random_dwell_counts(400_000 + 1000 * t, 40 + t)), dtype=np.float64) for t in range(4)]
+    refs = [oracle.parse(x, prior_segments_per_second=10.) for x in traces]
+    errors = []
+
+    def work(t):
+        try:
+            p = SpeedyStatSplit(prior_segments_per_second=10., quantum=synth.QUANTUM)
+            for rep in range(12):
+                x = traces[(t + rep) % 4]
+                got = np.array([s.start for s in p.parse(x)[1:]], dtype=np.int32)
+                if not np.array_equal(got, refs[(t + rep) % 4]):
+                    errors.append((t, rep, got.size))
+        except Exception as e:                                        # noqa: BLE001 -- reported on the main thread
+            errors.append((t, repr(e)))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+def test_one_context_shared_by_two_threads_serialises_its_calls():
+    import torch
+    from pypore_amd import _lib, engine
+    ctx = engine.context(0)
+    params = _lib.split_params(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    ks = [synth.random_dwell_counts(600_000, 70 + t) for t in range(2)]
+    dev = [torch.from_numpy(synth.counts_to_pa(k, np.float32)).cuda() for k in ks]
+    refs = [oracle.parse(synth.counts_to_pa(k, np.float64), prior_segments_per_second=10.) for k in ks]
+    errors = []
+
+    def work(t):
+        for rep in range(10):
+            b, _, _ = ctx.segment_batch(dev[t], np.array([0, dev[t].numel()], dtype=np.int64), params, synth.QUANTUM, want_stats=False)
+            if not np.array_equal(b.cpu().numpy(), refs[t]):
+                errors.append((t, rep))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert not errors, errors[:3]

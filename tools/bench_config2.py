@@ -20,4 +20,11 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10):
     b, boff, _ = ctx.segment_batch(t, off, params, synth.QUANTUM, want_stats=False)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print("config2: %d events x %d: %.3f ms/step, %.1f Msamples/s, %d boundaries" % (n_ev, ln, dt * 1e3, n_ev * ln / dt / 1e6, b.numel()), ctx.timings())
+print("config2: %d events x %d: %.3f ms/step, %.1f Msamples/s, %d boundaries" % (n_ev, ln, dt * 1e3, n_ev * ln / dt / 1e6, b.numel()))
+ctx.set_option("timing", 2)
+acc = {}
+for _ in range(10):
+    ctx.segment_batch(t, off, params, synth.QUANTUM, want_stats=False)
+    for k, v in ctx.timings().items():
+        acc[k] = acc.get(k, 0) + v / 10
+print({k: round(v, 4) for k, v in acc.items() if k.endswith("_ms")}, {k: int(v) for k, v in acc.items() if not k.endswith("_ms")})

@@ -2,6 +2,8 @@
 read, detect events at 90 pA, first-order 2 kHz Bessel filtfilt of every event, SpeedyStatSplit(prior_segments_per_second
 =10, cutoff_freq=2000) on every filtered event -- wall clock on the host, everything included.  Beside it the same steps
 on the CPU for the first events (scipy-equivalent filter and segmenter of oracle/, one core), scaled to the file.
+Round 5: then EIGHT files of half that length through Experiment.parse with workers=1 (the reference's loop, one file
+after the other) and with the default workers (files in flight on their own host threads and device contexts).
 usage: bench_experiment.py [samples, default 1e8]"""
 import os, sys, time, tempfile
 import numpy as np
@@ -50,3 +52,24 @@ cpu = time.perf_counter() - t0
 t0 = time.perf_counter(); oracle.lambda_events(x[:20_000_000], threshold=90.0); det = (time.perf_counter() - t0) * n / 20_000_000
 print("CPU (oracle, one core): filter + segmentation of %d events (%d samples) %.2f s -> %.1f s for the file's events, "
       "+ detection %.1f s: %.1f Msamples/s of file" % (k, done, cpu, cpu * ns / done, det, n / (cpu * ns / done + det) / 1e6))
+
+# ---- round 5: eight files, one after the other vs. in flight ----------------------------------------------------------
+m = n // 2
+paths = []
+for f in range(8):
+    c8, _ = synth.file_trace_counts(m, 100 + f)
+    p8 = os.path.join(os.path.dirname(path), "f%d.abf" % f)
+    abf.write_abf(p8, c8.astype(np.int16))
+    paths.append(p8)
+res = {}
+for w in (1, None, 1, None, 1, None):
+    e8 = None
+    e8 = Experiment(paths)
+    t0 = time.perf_counter()
+    e8.parse(verbose=False, workers=w)
+    res.setdefault(w, []).append(time.perf_counter() - t0)
+    key = (len(e8.events), len(e8.segments), [f.filename for f in e8.files])
+    assert res.setdefault("key", key) == key                       # same events, segments and file order either way
+seq, par = sorted(res[1])[1], sorted(res[None])[1]
+print("Experiment.parse over 8 files of %.1e samples (%d events, %d segments): workers=1 %s s, default workers %s s: %.2f x"
+      % (m, key[0], key[1], " ".join("%.3f" % t for t in res[1]), " ".join("%.3f" % t for t in res[None]), par / seq))
