@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 PARAMS = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10.,
               sampling_freq=1e5)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")     # written by tools/profile_round.sh from the PMC passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")     # written by tools/profile_round.sh from the PMC passes
 METRIC = "Msamples/sec segmented (SpeedyStatSplit, 10^8-sample trace); %HBM roofline"
 
 

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "poreseg.h"
@@ -100,6 +101,7 @@ struct ps_ctx {
     float noise_k = 0.1f;     // near-tie accounting of the wide route (DevCfg::noise_k; PORESEG_NOISE_K)
     int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
     bool gate_held = false;
+    int scan_lds_pad = 0;     // diagnostics (PORESEG_SCAN_LDS_PAD): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
     int dbg_phase = 0;        // diagnostics (PORESEG_DBG_PHASE; WRONG or stale results, never set by the product): 1 a call that repeats the previous
                               // one's layout skips K0 (the digest is still there: what the scan kernels cost on their own), 2 K0 only
     int k0_shared = 0;        // 1: upload + K0 of this context run on the device's shared FRONT stream (round 5): the K0 launches of all contexts that
@@ -190,24 +192,53 @@ FrontStream *front_for(ps_ctx *ctx)
     return f;
 }
 
-// K0 admission (ps_ctx::k0_admit, experiments): at most PORESEG_K0_MAX calls of a device have their K0 in flight at a time; a call
-// takes a permit before it queues K0 and gives it back when K0's event has completed (the host thread waits for that event after
-// it has queued the rest of the call).  K0 is bound by HBM: T of them side by side only share the same bytes per second, and all
-// of them -- with every call's scan kernels behind them -- finish late together.
-struct K0Gate { std::mutex mu; std::condition_variable cv; int in_flight = 0; };
+// K0 admission (ps_ctx::k0_admit): at most that many calls of a device have their K0 in flight at a time.  K0 is bound by HBM:
+// T of them side by side only share the same bytes per second, and all of them -- with every call's scan kernels behind
+// them -- finish late together.  A call reserves a slot before it queues K0 and publishes the event it records behind K0; the
+// slot comes back when that event has completed, which ANY thread that waits at the gate finds out (hipEventQuery) -- not the
+// holder: a holder that the host's scheduler parks between two launches must not keep the others out (the first version,
+// where the holder waited for its own event and then gave the slot back, produced a run at twice the usual time now and then).
+struct K0Gate {
+    struct Slot { const ps_ctx *owner; hipEvent_t ev; bool recorded; };
+    std::mutex mu;
+    std::vector<Slot> slots;
+};
 K0Gate g_gate[16];
-void gate_enter(int device, int max_in_flight)
+void gate_drop(K0Gate &g, const ps_ctx *owner)
 {
-    K0Gate &g = g_gate[device & 15];
-    std::unique_lock<std::mutex> lk(g.mu);
-    g.cv.wait(lk, [&] { return g.in_flight < max_in_flight; });
-    ++g.in_flight;
+    for (size_t i = 0; i < g.slots.size();)
+        if (g.slots[i].owner == owner) g.slots.erase(g.slots.begin() + static_cast<long>(i)); else ++i;
 }
-void gate_leave(int device)
+void gate_enter(ps_ctx *ctx, int device, int max_in_flight, hipEvent_t ev)
 {
     K0Gate &g = g_gate[device & 15];
-    { std::lock_guard<std::mutex> lk(g.mu); --g.in_flight; }
-    g.cv.notify_one();
+    for (unsigned spin = 0;; ++spin) {
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            if (spin == 0) gate_drop(g, ctx);          // (a slot of this context's previous call: that call has ended)
+            for (size_t i = 0; i < g.slots.size();) {
+                if (g.slots[i].recorded && hipEventQuery(g.slots[i].ev) == hipSuccess) g.slots.erase(g.slots.begin() + static_cast<long>(i));
+                else ++i;
+            }
+            (void)hipGetLastError();                   // (hipErrorNotReady of the queries)
+            if (static_cast<int>(g.slots.size()) < max_in_flight) { g.slots.push_back({ctx, ev, false}); return; }
+        }
+        // (a K0 takes 100-300 us: a look every few tens of microseconds is plenty, and thirteen waiting threads that hammer
+        //  the runtime with queries get in the way of the three that are launching)
+        std::this_thread::sleep_for(std::chrono::microseconds(25));
+    }
+}
+void gate_publish(const ps_ctx *ctx, int device)     // K0's event has been recorded
+{
+    K0Gate &g = g_gate[device & 15];
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (auto &sl : g.slots) if (sl.owner == ctx) sl.recorded = true;
+}
+void gate_leave(const ps_ctx *ctx, int device)       // the call has ended (or failed): whatever it still holds goes back
+{
+    K0Gate &g = g_gate[device & 15];
+    std::lock_guard<std::mutex> lk(g.mu);
+    gate_drop(g, ctx);
 }
 
 // status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..3] work, [4] dense count
@@ -294,7 +325,7 @@ hipError_t set_dyn_lds(ps_ctx *ctx, const void *fn, int lds)
 
 template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, bool list_mode = false)
 {
-    const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
+    const size_t lds = NT == 64 ? static_cast<size_t>(ctx->scan_lds_pad) : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(spine_kernel<NT, DT>), static_cast<int>(lds)));
     const unsigned grid = std::min(nj, resident_slots(ctx, spine_kernel<NT, DT>, NT, lds));
     hipLaunchKernelGGL((spine_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
@@ -308,7 +339,7 @@ template <int NT, int DT> int launch_spine(ps_ctx *ctx, const DevCfg &cfg, unsig
 template <int NT, int DT> int launch_tree(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm, size_t n_jobs,
                                           const AsmHeader *d_hdr, int par_max_jobs = 0)
 {
-    const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
+    const size_t lds = NT == 64 ? static_cast<size_t>(ctx->scan_lds_pad) : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(tree_kernel<NT, DT>), static_cast<int>(lds)));
     const unsigned grid = std::min(nj, resident_slots(ctx, tree_kernel<NT, DT>, NT, lds));
     hipLaunchKernelGGL((tree_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
@@ -526,12 +557,6 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     }
     if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[9], ctx->stream));
-    if (ctx->gate_held) {                              // the whole call is queued: K0's permit goes back when K0 is through
-        const hipError_t ge = hipEventSynchronize(ctx->ev_front[1]);
-        ctx->gate_held = false;
-        gate_leave(ctx->device);
-        HIP_TRY(ctx, ge);
-    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     {
         float seq = 0;                                 // the call's device work, upload to result copies, by HIP events
@@ -615,7 +640,7 @@ template <int DT> int launch_bridge_la(ps_ctx *ctx, const DevCfg &cfg, unsigned 
 
 template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
-    const size_t lds = NT == 64 ? 0 : lds_bytes_for(cfg.lds_cap, NT);
+    const size_t lds = NT == 64 ? static_cast<size_t>(ctx->scan_lds_pad) : lds_bytes_for(cfg.lds_cap, NT);
     HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(bridge_kernel<NT, DT>), static_cast<int>(lds)));
     const unsigned grid = std::min(nj, resident_slots(ctx, bridge_kernel<NT, DT>, NT, lds));
     hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
@@ -806,7 +831,7 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
                                     reinterpret_cast<unsigned *>(&sm->status), const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp)))
-        if (ctx->k0_admit > 0 && !front) { gate_enter(ctx->device, ctx->k0_admit); ctx->gate_held = true; }
+        if (ctx->k0_admit > 0 && !front) { gate_enter(ctx, ctx->device, ctx->k0_admit, ctx->ev_front[1]); ctx->gate_held = true; }
         if (ctx->dbg_phase == 1 && reuse) { /* diagnostics: the previous call's digest */ }
         else if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
         else           { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
@@ -817,7 +842,10 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
         cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
     }
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], fs));
-    if (ctx->gate_held) HIP_TRY(ctx, hipEventRecord(ctx->ev_front[1], fs));       // (K0 is behind this event)
+    if (ctx->gate_held) {                              // K0 is behind this event: whoever waits at the gate sees it complete
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_front[1], fs));
+        gate_publish(ctx, ctx->device);
+    }
     if (ctx->dbg_phase == 2) {                           // diagnostics: K0 only
         if (front) front_lock.unlock();
         HIP_TRY(ctx, hipStreamSynchronize(fs));
@@ -907,7 +935,7 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
                         std::chrono::steady_clock::time_point t_begin)
 {
     const int rc = device_stitch_batch_(ctx, cfg_in, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
-    if (ctx->gate_held) { ctx->gate_held = false; gate_leave(ctx->device); }
+    if (ctx->gate_held) { ctx->gate_held = false; gate_leave(ctx, ctx->device); }
     return rc;
 }
 }  // namespace
@@ -957,6 +985,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_K0_WAVES")) ctx->k0_waves = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_K0_SHARED")) ctx->k0_shared = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_DBG_PHASE")) ctx->dbg_phase = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_SCAN_LDS_PAD")) ctx->scan_lds_pad = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_K0_MAX")) ctx->k0_admit = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PORESEG_NOISE_K")) ctx->noise_k = static_cast<float>(std::atof(e));
     if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;

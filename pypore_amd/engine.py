@@ -103,7 +103,7 @@ class Context(object):
         n_ev = ev_off.size - 1
         fmt = _lib.SampleFormat(dtype, int(offset_counts), float(quantum))
         off_p = ev_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
-        if cap is None:
+        if cap is None and out is None:
             cap = int(self.L.ps_bounds_capacity(off_p, n_ev, int(params.min_width)))
             if cap < 0:
                 raise ValueError("min_width must be >= 1")

@@ -17,6 +17,29 @@ SCALE = int(os.environ.get("FUZZ_SCALE", "1"))
 Q = synth.QUANTUM / SCALE
 routes = {}
 shifted = unchecked = cross = same_route = verify_outside = 0
+def near_threshold_outside_domain(msg, evs, params):
+    """a verify-mode disagreement is downgraded to a note only when it can be the reference's own rounding --
+    the window the message names, taken from an event OUTSIDE the reference's exact domain, has an exact best gain (oracle
+    on the shifted event, whose sums are exact) within 1e-4 relative of the threshold, or its two best gains that close to
+    each other.  Anything else stays an error: a pruning mistake on the 64-bit digest must not hide behind the domain."""
+    import re
+    m = re.search(r"window \[(\d+),(\d+)\)", msg)
+    if not m:
+        return False
+    ps, pe = int(m.group(1)), int(m.group(2))
+    thr = oracle.min_gain(**{k_: v_ for k_, v_ in params.items()})
+    for k in evs:
+        if len(k) * float(np.abs(k).max()) ** 2 < 2.0 ** 53 or pe > len(k):
+            continue
+        if (pe - ps) * float(np.abs(k[ps:pe] - k[ps]).max()) ** 2 >= 2.0 ** 53:
+            return True                                  # not even the window's own sums are exact: nothing to compare with
+        _, sc = oracle.score_window((k[ps:pe] - k[ps]).astype(np.float64) * Q, params["min_width"], 0.0)
+        top = np.sort(sc[np.isfinite(sc)])[-2:] if np.isfinite(sc).any() else np.zeros(0)
+        if top.size and (abs(top[-1] - thr) <= 1e-4 * max(1.0, abs(thr)) or (top.size == 2 and top[-1] - top[-2] <= 1e-4 * max(1.0, abs(top[-1])))):
+            return True
+    return False
+
+
 for seed in range(n_seeds):
     rng = np.random.RandomState(10_000 + seed + int(os.environ.get("FUZZ_BASE", "0")))
     mw = int(rng.choice([8, 20, 100, 250]))
@@ -86,7 +109,7 @@ for seed in range(n_seeds):
             # a gain, decides a window whose best gain lies that close to the threshold; the two then disagree although the
             # default-mode result equals the oracle on the shifted event (checked above).  Noted, not a problem; round 4's
             # validation found one such window in 5 000 seeds (gain 13.813478 exact / 13.813740 in raw fp64 / threshold 13.813510).
-            if mode == 2 and "verify mode" in repr(ex) and any(len(k) * float(np.abs(k).max()) ** 2 >= 2.0 ** 53 for k in evs):
+            if mode == 2 and "verify mode" in repr(ex) and near_threshold_outside_domain(repr(ex), evs, params):
                 verify_outside += 1
                 print("NOTE seed", seed, "verify-mode disagreement on a call with an event outside the reference's exact sums:", repr(ex)[60:230])
             else:

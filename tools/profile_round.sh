@@ -9,7 +9,7 @@
 #   <tag>_pmc_summary.txt       PMC passes (tools/pmc_run.sh, --streams 1: instruction counts, traffic of one call at a time)
 #   <tag>_pmc16_summary.txt     the same passes with sixteen calls in flight on sixteen DISTINCT traces (--streams 16, the bench's
 #                               default): what the headline configuration fetches; <tag>_pmc_traffic.json: HBM bytes per launch from both
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$PWD
 export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out
