@@ -107,8 +107,10 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * digest are retried on the 64-bit one, 0 straight to the LDS-window scan; "spine_nt" 256/512/1024, "tree_nt" 256/512
  * workgroup sizes of the LDS-window kernels; "tree_par" 1 (default) the deep subtree jobs of a call on the 64-bit digest
  * (a filtered event) are shared by the four waves of a workgroup when the call has few jobs, 0 one wave per job;
- * "k0_waves" n (default 2): the block-prefix kernel K0 is persistent -- n waves per SIMD stride over the call, each with
- * its next 8 KB of samples in flight -- 0: one wave per 2 048 samples, as many as fit the chip (rounds 3 and 4);
+ * "k0_waves" n > 0: the block-prefix kernel K0 is persistent -- n waves per SIMD (twice that for int16 samples) stride
+ * over the call, each with its next wave block's samples in flight: what a context that shares the chip with other calls
+ * wants (engine.StreamPool sets 1) --, 0 (default): one wave per 2 048 samples, as many as fit the chip: faster for a
+ * call that has the chip to itself;
  * "k0_shared" 1: this context queues its upload + K0 launches on the device's shared front stream, where the K0
  * kernels of all such contexts run back to back (they are bound by HBM: side by side they only share it) and the
  * context's own stream takes over behind an event; 0 (default) everything on the context's stream -- a host that keeps

@@ -97,7 +97,10 @@ struct ps_ctx {
     int tree_mw = 0;          // 1: block-sum tree kernel with TREE_W waves per workgroup sharing their job list (round 3: single-wave workgroups are faster at four waves per SIMD and need no spills)
     int upload_by_kernel = 1; // 1: the call's host tables are fetched by a kernel (no SDMA hand-over), 0: hipMemcpyAsync
     int filter_fused = 1;     // 1: fast filters run both directions in one kernel over tiles with halos, 0: always the exact three-pass scan
-    int k0_waves = 2;         // K0 is persistent: this many waves per SIMD stride over the call (round 5); 0: one wave per wave block, as many as the registers allow
+    int k0_waves = 0;         // > 0: K0 runs as a persistent kernel, this many waves per SIMD (twice that for int16 samples) striding over the call with
+                              // their next wave block's samples in flight (round 5) -- what a context that shares the chip wants (engine.StreamPool
+                              // sets 1: 0.193 -> 0.170 ms per step with sixteen calls in flight); 0: one wave per wave block, as many as the registers
+                              // allow -- faster for a call that has the chip to itself (1e9 samples: K0 0.91 against 0.98 ms)
     float noise_k = 0.1f;     // near-tie accounting of the wide route (DevCfg::noise_k; PORESEG_NOISE_K)
     int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
     bool gate_held = false;
@@ -825,7 +828,9 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
             ctx->n_cu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
         }
         const unsigned k0_full = static_cast<unsigned>((nb_pad / K0_WB + K0_WAVES - 1) / K0_WAVES);
-        const unsigned k0_grid = ctx->k0_waves > 0 ? std::min(k0_full, static_cast<unsigned>(ctx->k0_waves) * static_cast<unsigned>(ctx->n_cu) * (4u / K0_WAVES)) : k0_full;
+        // (a wave block of int16 samples is half the bytes: twice the waves keep the same bytes in flight)
+        const unsigned k0_per_cu = static_cast<unsigned>(ctx->k0_waves) * (f32 ? 1u : 2u);
+        const unsigned k0_grid = ctx->k0_waves > 0 ? std::min(k0_full, k0_per_cu * static_cast<unsigned>(ctx->n_cu) * (4u / K0_WAVES)) : k0_full;
         const size_t k0_lds = 0;
 #define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), k0_lds, fs, cfg,       \
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \

@@ -406,6 +406,19 @@ class StreamPool(object):
         # ("k0_admit": a call waits for a permit before it queues K0 and returns it when K0's event has completed).  K0 is
         # bound by HBM; sixteen of them at once finish late together, with every call's scan kernels behind them.
         # 16 contexts, 100 steps: 0.188 -> 0.175 ms per step; the driver's 20 steps: 0.208 -> 0.197 (profiles/r05_experiments).
+        # ... and K0 as a persistent kernel at one wave per SIMD ("k0_waves"): beside the scan waves of other calls a K0 that takes
+        # every wave slot it can get is in the way (sixteen in flight: 0.193 -> 0.170 ms per step); a lone call is faster
+        # with the one-shot K0, so the caller's own context goes back to it afterwards
+        k0w = int(os.environ.get("PORESEG_POOL_K0_WAVES", "1")) if T > 1 and n_jobs > 1 else 0
+        if "PORESEG_K0_WAVES" in os.environ:
+            k0w = None                                   # (the environment decides: experiments)
+        if k0w is not None and k0w != getattr(self, "_k0w", 0):
+            for cx in self.contexts:
+                if hasattr(cx, "set_option"):
+                    cx.set_option("k0_waves", k0w)
+            self._k0w = k0w
+        elif k0w and hasattr(self.contexts[0], "set_option"):
+            self.contexts[0].set_option("k0_waves", k0w)
         admit = int(os.environ.get("PORESEG_POOL_K0_MAX", "3")) if T > 3 else 0
         if admit != getattr(self, "_admit", 0):
             for cx in self.contexts:
@@ -421,6 +434,8 @@ class StreamPool(object):
             self._done.get()
         if shared:
             self._front_stream(self.contexts[0], 0)
+        if getattr(self, "_k0w", 0) and hasattr(self.contexts[0], "set_option"):
+            self.contexts[0].set_option("k0_waves", 0)   # (set again for contexts[0] at the next run)
         if errors:
             raise errors[0]
         return results
