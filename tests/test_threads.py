@@ -70,3 +70,51 @@ def test_one_context_shared_by_two_threads_serialises_its_calls():
     for x in th: x.start()
     for x in th: x.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("options", [dict(k0_waves=1), dict(k0_waves=2), dict(k0_waves=1, k0_admit=2), dict(k0_shared=1, k0_waves=2)])
+def test_pool_options_do_not_change_a_result(options):
+    """What engine.StreamPool sets on its contexts while it runs (round 5: K0 persistent at n waves per SIMD, at most M K0s of
+    the device in flight; the shared front stream, which nothing sets by default): same boundaries as the oracle, fp32 and
+    int16, one long event and many short ones at odd offsets, from four threads with a context each."""
+    import torch
+    from pypore_amd import _lib, engine
+    params = _lib.split_params(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    k_long = synth.random_dwell_counts(1_500_000, 91)
+    shorts = [synth.random_dwell_counts(30_000 + 137 * e, 200 + e, 300, 4000) for e in range(12)]
+    buf, starts, lens, pos = [], [], [], 0
+    for e, k in enumerate(shorts):
+        pad = np.zeros(e % 7 + 1, dtype=np.int64)
+        buf += [pad, k]; pos += pad.size; starts.append(pos); lens.append(k.size); pos += k.size
+    cat = np.concatenate(buf + [np.zeros(16, dtype=np.int64)])
+    ref_long = oracle.parse(synth.counts_to_pa(k_long, np.float64), prior_segments_per_second=10.)
+    ref_short = [oracle.parse(synth.counts_to_pa(k, np.float64), prior_segments_per_second=10.) for k in shorts]
+    errors = []
+
+    def work(t):
+        try:
+            cx = engine.Context(0)
+            for name, value in options.items():
+                cx.set_option(name, value)
+            for dtype in (torch.float32, torch.int16):
+                as_dev = (lambda k: torch.from_numpy(synth.counts_to_pa(k, np.float32)).cuda()) if dtype == torch.float32 else \
+                    (lambda k: torch.from_numpy(k.astype(np.int16)).cuda())
+                d_long, d_cat = as_dev(k_long), as_dev(cat)
+                for rep in range(3):
+                    b, _, _ = cx.segment_batch(d_long, np.array([0, d_long.numel()], dtype=np.int64), params, synth.QUANTUM, want_stats=False)
+                    if not np.array_equal(b.cpu().numpy(), ref_long):
+                        errors.append((t, str(dtype), "long"))
+                    b, off, _ = cx.segment_events(d_cat, np.array(starts, dtype=np.int64), np.array(lens, dtype=np.int64), params,
+                                                  synth.QUANTUM, want_stats=False)
+                    b = b.cpu().numpy()
+                    for e in range(len(shorts)):
+                        if not np.array_equal(b[off[e]:off[e + 1]], ref_short[e]):
+                            errors.append((t, str(dtype), "short", e))
+            cx.close()
+        except Exception as ex:                                       # noqa: BLE001 -- reported on the main thread
+            errors.append((t, repr(ex)))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert not errors, errors[:4]
