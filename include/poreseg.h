@@ -224,6 +224,15 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
  * and d_in no longer read when the call returns). */
 int ps_requantise(ps_ctx *ctx, const double *d_in, int64_t n, float *d_out, double *centre_out, double *step_out);
 
+/* Event.filter + the representation step for MANY events of one trace in one call (the inner loop of Experiment.parse,
+ * DataTypes.py:975-984; File.parse_events here): event e is samples[ev_start[e] .. + ev_len[e]) of d_samples; its filtered
+ * current (ps_filter_bessel) goes to d_filtered + sum of the lengths before it, its re-quantised copy (ps_requantise) to the
+ * same position of d_rounded, its centre and grid step to h_centre[e] / h_step[e].  Same results as the two entries called
+ * per event; one status check and two host synchronisations for the whole batch instead of three per event. */
+int ps_filter_requantise_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, const int64_t *ev_start,
+                               const int64_t *ev_len, int32_t n_ev, int32_t order, double cutoff, double sampling_freq,
+                               double *d_filtered, float *d_rounded, double *h_centre, double *h_step);
+
 /* Replaces cSegmentAligner(model_means, model_stds, model_durs, skip_penalty, backslip_penalty).align(seq_means,
  * seq_stds, seq_durs) (calignment.pyx:20-100; called from SegmentAligner.align, alignment.py:33-46) for a BATCH of
  * sequences against one model: sequence q is entries [h_seq_off[q], h_seq_off[q+1]) of the three device arrays

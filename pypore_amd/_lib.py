@@ -18,7 +18,7 @@ PS_ALIGN_OK, PS_ALIGN_VALUE_ERROR, PS_ALIGN_INDEX_ERROR, PS_ALIGN_ZERO_DIVISION,
 EXPORTS = ["ps_version", "ps_device_count", "ps_create", "ps_destroy", "ps_last_error", "ps_set_tiling", "ps_set_option",
            "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_segment_batch_ex", "ps_segment_events", "ps_detect_events", "ps_bounds_capacity",
            "ps_best_single_split", "ps_score_window", "ps_get_timings", "ps_synth_trace", "ps_filter_bessel",
-           "ps_requantise", "ps_align_batch", "ps_audit_bounds", "ps_counters"]
+           "ps_requantise", "ps_filter_requantise_batch", "ps_align_batch", "ps_audit_bounds", "ps_counters"]
 
 
 class SplitParams(ctypes.Structure):
@@ -73,6 +73,8 @@ def lib():
     L.ps_synth_trace.argtypes = [vp, vp, i32, i64, ctypes.c_uint64, P(i64), P(i32), i64]
     L.ps_filter_bessel.argtypes = [vp, vp, P(SampleFormat), i64, i32, dbl, dbl, vp]
     L.ps_requantise.argtypes = [vp, vp, i64, vp, P(dbl), P(dbl)]
+    L.ps_filter_requantise_batch.argtypes = [vp, vp, P(SampleFormat), P(i64), P(i64), ctypes.c_int32, ctypes.c_int32, dbl, dbl,
+                                             vp, vp, P(dbl), P(dbl)]
     L.ps_align_batch.argtypes = [vp, P(dbl), P(dbl), P(dbl), i32, dbl, dbl, vp, vp, vp, P(i64), i32, vp, vp, vp]
     L.ps_counters.argtypes = [vp]
     L.ps_counters.restype = P(i64)

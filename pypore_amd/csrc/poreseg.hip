@@ -104,6 +104,7 @@ struct ps_ctx {
     float noise_k = 0.1f;     // near-tie accounting of the wide route (DevCfg::noise_k; PORESEG_NOISE_K)
     int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
     bool gate_held = false;
+    bool defer_sync = false;  // (internal) ps_filter_requantise_batch: the filter entry only queues its kernels -- no status clear, copy, sync
     int scan_lds_pad = 0;     // diagnostics (PORESEG_SCAN_LDS_PAD): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
     int dbg_phase = 0;        // diagnostics (PORESEG_DBG_PHASE; WRONG or stale results, never set by the product): 1 a call that repeats the previous
                               // one's layout skips K0 (the digest is still there: what the scan kernels cost on their own), 2 K0 only
@@ -1693,13 +1694,14 @@ int filter_order_n(ps_ctx *ctx, const DevCfg &cfg, int64_t n, int order, double 
     const int64_t m = n + 2LL * f.pad, nseg = (m + S - 1) / S;
     HIP_TRY(ctx, ctx->filt_fwd.reserve(static_cast<size_t>(nseg) * static_cast<size_t>(S + H) * sizeof(double)));
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    if (!ctx->defer_sync) HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
     unsigned *st = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->status);
     const dim3 grid(static_cast<unsigned>((nseg + 63) / 64));
     if (cfg.dtype == PS_DTYPE_F32)      hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_F32>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
     else if (cfg.dtype == PS_DTYPE_F64) hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_F64>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
     else                                hipLaunchKernelGGL((filt_halo_kernel<PS_DTYPE_I16>), grid, dim3(64), 0, ctx->stream, cfg, f, n, S, H, ctx->filt_fwd.as<double>(), d_out, st);
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->defer_sync) return PS_OK;                   // (a batch: one status check for all of its events)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
@@ -1749,12 +1751,13 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
             const int T = FILT_CHUNK - 2 * H;
             const dim3 fgrid(static_cast<unsigned>((g.total + T - 1) / T));
             HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+            if (!ctx->defer_sync) HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
             unsigned *fst = reinterpret_cast<unsigned *>(&ctx->small.as<SmallLayout>()->status);
             if (cfg.dtype == PS_DTYPE_F32)      hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_F32>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
             else if (cfg.dtype == PS_DTYPE_F64) hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_F64>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
             else                                hipLaunchKernelGGL((filt_fused_kernel<PS_DTYPE_I16>), fgrid, dim3(FILT_NT), 0, ctx->stream, cfg, f, g, H, d_out, fst);
             HIP_TRY(ctx, hipGetLastError());
+            if (ctx->defer_sync) return PS_OK;
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
@@ -1767,7 +1770,7 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     HIP_TRY(ctx, ctx->filt_agg.reserve(static_cast<size_t>(n_chunks) * 2 * sizeof(double2)));
     HIP_TRY(ctx, ctx->filt_zin.reserve(static_cast<size_t>(n_chunks) * sizeof(double)));
     HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    if (!ctx->defer_sync) HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     unsigned *st = reinterpret_cast<unsigned *>(&sm->status);
     double *fwd = ctx->filt_fwd.as<double>();
@@ -1783,6 +1786,7 @@ int ps_filter_bessel(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     if (cfg.dtype == PS_DTYPE_F32) { PS_FILT(PS_DTYPE_F32) } else if (cfg.dtype == PS_DTYPE_F64) { PS_FILT(PS_DTYPE_F64) } else { PS_FILT(PS_DTYPE_I16) }
 #undef PS_FILT
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->defer_sync) return PS_OK;                   // (a batch: one status check for all of its events)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
@@ -1814,6 +1818,76 @@ int ps_requantise(ps_ctx *ctx, const double *d_in, int64_t n, float *d_out, doub
     // (the context's stream does not block on torch's: the caller may read d_out, or free d_in, as soon as this returns)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *centre_out = centre; *step_out = step;
+    return PS_OK;
+}
+
+int ps_filter_requantise_batch(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, const int64_t *ev_start,
+                               const int64_t *ev_len, int32_t n_ev, int32_t order, double cutoff, double sampling_freq,
+                               double *d_filtered, float *d_rounded, double *h_centre, double *h_step)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (n_ev < 0 || (n_ev > 0 && (!d_samples || !fmt || !ev_start || !ev_len || !d_filtered || !d_rounded || !h_centre || !h_step)))
+        return fail(ctx, PS_ERR_ARG, "null pointer or negative count");
+    if (n_ev == 0) return PS_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t es = fmt->dtype == PS_DTYPE_I16 ? 2 : fmt->dtype == PS_DTYPE_F64 ? 8 : 4;
+    std::vector<int64_t> off(static_cast<size_t>(n_ev) + 1, 0);
+    std::vector<int> by_len(static_cast<size_t>(n_ev));
+    for (int e = 0; e < n_ev; ++e) {
+        if (ev_len[e] < 1 || ev_start[e] < 0) return fail(ctx, PS_ERR_ARG, "event %d: empty or negative range", e);
+        off[e + 1] = off[e] + ev_len[e];
+        by_len[e] = e;
+    }
+    // (longest first: the scratch of the filter paths grows at most once, before anything that uses it is in flight)
+    std::sort(by_len.begin(), by_len.end(), [&](int a, int b) { return ev_len[a] > ev_len[b]; });
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+    // 1. every event's filter, queued back to back (one status word for all of them)
+    ctx->defer_sync = true;
+    int rc = PS_OK;
+    for (int k = 0; k < n_ev && rc == PS_OK; ++k) {
+        const int e = by_len[k];
+        rc = ps_filter_bessel(ctx, static_cast<const char *>(d_samples) + static_cast<size_t>(ev_start[e]) * es, fmt, ev_len[e], order, cutoff,
+                              sampling_freq, d_filtered + off[e]);
+    }
+    ctx->defer_sync = false;
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    // 2. sum / min / max of every filtered current, all events' partial results in one copy
+    std::vector<unsigned> grid(static_cast<size_t>(n_ev));
+    std::vector<size_t> poff(static_cast<size_t>(n_ev) + 1, 0);
+    for (int e = 0; e < n_ev; ++e) {
+        grid[e] = static_cast<unsigned>(std::min<int64_t>(1024, (ev_len[e] + 8 * RQ_NT - 1) / (8 * RQ_NT)));
+        poff[e + 1] = poff[e] + grid[e];
+    }
+    const size_t pbytes = poff[n_ev] * 3 * sizeof(double);
+    HIP_TRY(ctx, ctx->filt_agg.reserve(pbytes));         // (the filters above are done with it only in stream order: reserve() may
+    HIP_TRY(ctx, ctx->h_meta.reserve(pbytes));           //  free and allocate, which waits for the device -- correct, and rare)
+    for (int e = 0; e < n_ev; ++e)
+        hipLaunchKernelGGL(requant_stats_kernel, dim3(grid[e]), dim3(RQ_NT), 0, ctx->stream, d_filtered + off[e], static_cast<long long>(ev_len[e]),
+                           ctx->filt_agg.as<double>() + 3 * poff[e]);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->filt_agg.p, pbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = check_status(ctx, static_cast<unsigned>(ctx->h_small.as<SmallLayout>()->status));
+    if (rc) return rc;
+    // 3. centre and grid step per event (ps_requantise's rule), then the rounding passes
+    const double *part = ctx->h_meta.as<double>();
+    for (int e = 0; e < n_ev; ++e) {
+        double sum = 0.0, mn = INFINITY, mx = -INFINITY;
+        for (size_t g = poff[e]; g < poff[e + 1]; ++g) { sum += part[3 * g]; mn = std::min(mn, part[3 * g + 1]); mx = std::max(mx, part[3 * g + 2]); }
+        if (!std::isfinite(sum) || !std::isfinite(mn) || !std::isfinite(mx)) return fail(ctx, PS_ERR_ARG, "the current of event %d holds NaN or infinity", e);
+        double centre = sum / static_cast<double>(ev_len[e]);
+        const double span = std::max(mx - centre, centre - mn);
+        const double step = span > 0.0 ? std::ldexp(1.0, static_cast<int>(std::ceil(std::log2(span * 1.01))) - 22) : 1.0;
+        centre = std::nearbyint(centre / step) * step;
+        h_centre[e] = centre; h_step[e] = step;
+        const unsigned rg = static_cast<unsigned>(std::min<int64_t>(65535, (ev_len[e] + 4 * RQ_NT - 1) / (4 * RQ_NT)));
+        hipLaunchKernelGGL(requant_round_kernel, dim3(rg), dim3(RQ_NT), 0, ctx->stream, d_filtered + off[e], static_cast<long long>(ev_len[e]), centre,
+                           1.0 / step, step, d_rounded + off[e]);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PS_OK;
 }
 

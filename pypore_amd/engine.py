@@ -245,6 +245,31 @@ class Context(object):
         return out[:samples.numel()]
 
     @_serialised
+    def filter_requantise_batch(self, samples, ev_start, ev_len, quantum, cutoff=2000., sampling_freq=1.e5, order=1, offset_counts=0):
+        """ps_filter_requantise_batch: Event.filter + the re-quantisation for many events of ONE device-resident trace in one
+        call (two host synchronisations for the batch instead of three per event).  Returns (filtered float64 CUDA tensor,
+        rounded float32 CUDA tensor -- both the events back to back --, offsets int64 numpy [n_ev + 1], centres, steps)."""
+        assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
+        fmt = _lib.SampleFormat(_lib.PS_DTYPE_F64, 0, 1.0) if samples.dtype == torch.float64 else self._fmt(samples, quantum, offset_counts)
+        ev_start = np.ascontiguousarray(ev_start, dtype=np.int64)
+        ev_len = np.ascontiguousarray(ev_len, dtype=np.int64)
+        n_ev = ev_start.size
+        off = np.concatenate(([0], np.cumsum(ev_len))).astype(np.int64)
+        total = int(off[-1])
+        filtered = torch.empty(max(1, total), dtype=torch.float64, device=samples.device)
+        rounded = torch.empty(max(1, total), dtype=torch.float32, device=samples.device)
+        centre = np.zeros(max(1, n_ev), dtype=np.float64)
+        step = np.zeros(max(1, n_ev), dtype=np.float64)
+        P64, PD = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
+        torch.cuda.current_stream(samples.device).synchronize()
+        _lib.check(self.L.ps_filter_requantise_batch(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt),
+                                                     ev_start.ctypes.data_as(P64), ev_len.ctypes.data_as(P64), n_ev, int(order),
+                                                     float(cutoff), float(sampling_freq), ctypes.c_void_p(filtered.data_ptr()),
+                                                     ctypes.c_void_p(rounded.data_ptr()), centre.ctypes.data_as(PD), step.ctypes.data_as(PD)),
+                   self.handle)
+        return filtered[:total], rounded[:total], off, centre[:n_ev], step[:n_ev]
+
+    @_serialised
     def requantise(self, current):
         """ps_requantise: a filtered current (float64 CUDA tensor, pA) centred and rounded to the finest power-of-two
         grid that keeps its counts below 2**22.  Returns (float32 CUDA tensor on that grid, centre, step): segment it

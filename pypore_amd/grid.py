@@ -217,6 +217,19 @@ class Deferred(object):
         #  an allocation boundary is copied -- device to device, microseconds)
         return part.clone() if part.data_ptr() % 256 else part
 
+    def device_stretch(self, dev, upload):
+        """(int16 CUDA tensor of the whole family's counts, first sample, length) of this stretch -- no copy, whatever its
+        alignment -- or None when the family's counts are not parked on `dev` (callers that hand the library a base pointer
+        and ranges: FastStatSplit.parse_filtered_batch)."""
+        root = self._parent if self._parent is not None else self
+        if root.counts is None or self.counts is None:
+            return None
+        self.device_counts(dev, upload)                  # (uploads and parks the family's counts if nobody has yet)
+        cached = root.__dict__.get('_dev_counts')
+        if cached is None or cached.device != dev:
+            return None
+        return (cached, 0, self._n) if self is root else (cached, self._start, self._n)
+
     def _release_counts(self):
         if getattr(self, "_parked_counts", 0):
             Deferred._unpark(getattr(self, "_counts_key", None), self._parked_counts)
