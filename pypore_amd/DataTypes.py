@@ -379,7 +379,7 @@ class Experiment(object):
         are detected (and filtered) only; filter_params=None: no filter; meta=True: the currents are dropped afterwards.
 
         The reference takes one file after the other (:968-984).  Files are independent, so here up to `workers` of them
-        are in flight (default: 4 when detector and segmenter are this package's own device classes, else 1): while file
+        are in flight (default: 2 when detector and segmenter are this package's own device classes, else 1): while file
         k is segmented, file k+1 is read, uploaded and searched for events on another host thread -- every thread has
         its own device context (engine.context), its kernels overlap with the others' like the contexts of a StreamPool.
         `files`, and the lines printed with verbose=True, keep the order of `filenames` whatever finishes first."""
@@ -391,7 +391,7 @@ class Experiment(object):
         if workers is None:
             ours = isinstance(event_detector, lambda_event_parser) and getattr(event_detector, "_builtin", False) and \
                 (segmenter is None or isinstance(segmenter, SpeedyStatSplit))
-            workers = 4 if ours else 1
+            workers = 2 if ours else 1
         workers = max(1, min(int(workers), len(entries)))
 
         def one(entry, say=None):

@@ -212,10 +212,9 @@ class Deferred(object):
                 root._dev_counts, root._parked_counts, root._counts_key = cached, nbytes, Deferred._dev_key(cached)
         if self is root:
             return cached
-        part = cached[self._start:self._start + self._n]
-        # (the kernels load 16 bytes at a time relative to the pointer they are given: a stretch that does not start on
-        #  an allocation boundary is copied -- device to device, microseconds)
-        return part.clone() if part.data_ptr() % 256 else part
+        # (a view wherever it starts: 16-byte loads from 2-byte-aligned addresses are correct on this part -- round 5,
+        #  tools/probes/unaligned_probe.hip; until then a stretch off an allocation boundary was cloned)
+        return cached[self._start:self._start + self._n]
 
     def device_stretch(self, dev, upload):
         """(int16 CUDA tensor of the whole family's counts, first sample, length) of this stretch -- no copy, whatever its
