@@ -127,8 +127,10 @@ class Context(object):
             nt = self.near_ties()
             if nt:
                 import warnings
-                warnings.warn("%d window(s) were decided by a margin below 1e-9 relative (near tie): the reference's libm could "
-                              "round such a decision the other way" % nt, NearTieWarning, stacklevel=2)
+                warnings.warn("%d window(s) were decided by a margin inside the reference's own rounding noise (near tie: below 1e-9 "
+                              "relative on grid data -- the logarithm's last bit; on re-quantised float64 data, e.g. a filtered event, "
+                              "within the noise of the reference's cumsums): the reference could place such a boundary elsewhere, "
+                              "typically one sample beside it" % nt, NearTieWarning, stacklevel=2)
         total = int(boff[-1])
         if want_spine:
             return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None), spine[:total]
@@ -335,7 +337,8 @@ class Context(object):
 
 
 class NearTieWarning(UserWarning):
-    """A segment call decided at least one window by a margin inside the logarithm's rounding noise (Context.near_ties)."""
+    """A segment call decided at least one window by a margin inside the reference's own rounding noise: the logarithm's last
+    bit on grid data, the noise of its uncentred cumsums on re-quantised float64 data (Context.near_ties)."""
 
 
 NEAR_TIE_WARNING = True      # set False to skip the counter read after every call (one ps_get_timings, ~1 us)
