@@ -138,3 +138,30 @@ def test_segments_from_edges_equals_the_constructor():
     d.value()
     assert all(isinstance(raw_current(s), np.ndarray) for s in segments_from_edges(d, edges))
     assert segments_from_edges(d, [0, 3000])[0].std == pytest.approx(np.std(k * 0.5 + 2.0))
+
+
+def test_stretches_reach_the_device_as_views_of_the_familys_counts():
+    """Round 5: the counts of a file go up once, its events are stretches of that tensor wherever they start (no alignment
+    clone), and device_stretch names the family's tensor and the range -- what ps_filter_requantise_batch is handed."""
+    class FakeTensor(object):
+        def __init__(self, a, device="dev0"): self.a, self.device = a, device
+        def numel(self): return self.a.size
+        def element_size(self): return 2
+        def __getitem__(self, sl): return FakeTensor(self.a[sl], self.device)
+    uploads = []
+
+    def upload(counts, dev):
+        uploads.append(len(counts))
+        return FakeTensor(np.asarray(counts, dtype=np.int16), dev)
+    k = _counts(5000)
+    root = Deferred.from_counts(k, 0.25, 1.5)
+    a, b = root[1001:2501], root[3003:3503]                             # (odd starts: off every 16-byte boundary)
+    ta = a.device_counts("dev0", upload)
+    assert uploads == [5000] and np.array_equal(ta.a, k[1001:2501])
+    wa, wb = a.device_stretch("dev0", upload), b.device_stretch("dev0", upload)
+    assert uploads == [5000]                                            # one upload for the family
+    assert wa[0] is wb[0] and wa[1:] == (1001, 1500) and wb[1:] == (3003, 500)
+    assert root.device_stretch("dev0", upload)[1:] == (0, 5000)
+    # a current without counts (a float64 device tensor, a plain array) has no stretch
+    assert Deferred(10, lambda: np.zeros(10)).device_stretch("dev0", upload) is None
+    root._release()
