@@ -245,6 +245,9 @@ constexpr int K0_WB = 64 * K0_BPT;                     // blocks per wave
 #ifndef PS_K0_WAVES
 #define PS_K0_WAVES 4
 #endif
+#ifndef PS_K0_PKF32
+#define PS_K0_PKF32 1                                  // fp32 samples on the narrow digest: packed conversion + the packed int16 block sums (k0_block_sums_pkf32); 0: round 4's form
+#endif
 #ifndef PS_K0_PK16
 #define PS_K0_PK16 1                                   // int16 samples on the narrow digest: block sums on packed int16 arithmetic (k0_block_sums_pk16); 0: unpacked, as in round 4
 #endif
@@ -328,6 +331,14 @@ __device__ __forceinline__ void k0_offsets(const DevCfg &c, const int4 *raw, int
 // on the wide digest like any other such call --; S1 and S2 by v_dot2_i32_i16 (two samples per instruction, against (1, 1)
 // and against itself: 8 x 16383^2 < 2^31), the extremes by v_pk_min / v_pk_max_i16.  13 instructions less per sample pair.
 typedef short k0_v2s __attribute__((ext_vector_type(2)));
+// a.b without an accumulator (the three-operand form with a literal zero: the builtin took a v_mov_b32 for the zero first)
+__device__ __forceinline__ int k0_dot2_first(k0_v2s a, k0_v2s b)
+{
+    int out;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(out) : "v"(a), "v"(b));
+    return out;
+}
+
 template <int DT>
 __device__ __forceinline__ void k0_block_sums_pk16(const int4 raw, int k0pk, K0Rec<DT> &r)
 {
@@ -339,8 +350,41 @@ __device__ __forceinline__ void k0_block_sums_pk16(const int4 raw, int k0pk, K0R
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         y[q] = __builtin_elementwise_sub_sat(__builtin_bit_cast(k0_v2s, w[q]), k0v);
-        s1 = __builtin_amdgcn_sdot2(y[q], ones, s1, false);
-        s2 = __builtin_amdgcn_sdot2(y[q], y[q], s2, false);
+        s1 = q == 0 ? k0_dot2_first(y[q], ones) : __builtin_amdgcn_sdot2(y[q], ones, s1, false);
+        s2 = q == 0 ? k0_dot2_first(y[q], y[q]) : __builtin_amdgcn_sdot2(y[q], y[q], s2, false);
+    }
+    const k0_v2s mn = __builtin_elementwise_min(__builtin_elementwise_min(y[0], y[1]), __builtin_elementwise_min(y[2], y[3]));
+    const k0_v2s mx = __builtin_elementwise_max(__builtin_elementwise_max(y[0], y[1]), __builtin_elementwise_max(y[2], y[3]));
+    r.s1 = s1; r.s2 = static_cast<unsigned>(s2); r.s2w = 0;
+    r.ymin = min(static_cast<int>(mn.x), static_cast<int>(mn.y));
+    r.ymax = max(static_cast<int>(mx.x), static_cast<int>(mx.y));
+}
+
+// fp32 samples, narrow digest (round 5): the same packed int16 pipeline behind a packed conversion.  t = x / q is the count as a
+// float (v_pk_mul_f32; integral iff v_fract_f32(t) == 0 -- NaN for NaN, and an infinity saturates below), t - m is exact
+// (integers below 2^24), and v_cvt_pknorm_i16_f32((t - m) / 32767) gives round(clamp((t - m) / 32767, -1, 1) * 32767): the
+// product carries 2^-24 relative, 0.002 of a count at 32767, so every |y| <= 32767 comes out exactly and everything beyond
+// saturates to +-32767, which fails |y| < BS_WIDE like any wide count (tools/probes/pknorm_probe.hip checks all of
+// -70 000 .. 70 000 on the device).  5.5 instructions per sample where the unpacked form took ~10.
+template <int DT>
+__device__ __forceinline__ void k0_block_sums_pkf32(const int4 (&raw)[2], float inv_q, float mf, unsigned &nz, K0Rec<DT> &r)
+{
+    const f2 iq = {inv_q, inv_q}, m2 = {mf, mf};
+    const f2 cn = {1.0f / 32767.0f, 1.0f / 32767.0f};
+    const k0_v2s ones = {1, 1};
+    const int w[8] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w};
+    k0_v2s y[4];
+    int s1 = 0, s2 = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma clang fp contract(off)
+        const f2 x = {__int_as_float(w[2 * h]), __int_as_float(w[2 * h + 1])};
+        const f2 t = x * iq;
+        nz |= __float_as_uint(__builtin_amdgcn_fractf(t.x)) | __float_as_uint(__builtin_amdgcn_fractf(t.y));
+        const f2 a = (t - m2) * cn;
+        y[h] = __builtin_amdgcn_cvt_pknorm_i16(a.x, a.y);
+        s1 = h == 0 ? k0_dot2_first(y[h], ones) : __builtin_amdgcn_sdot2(y[h], ones, s1, false);
+        s2 = h == 0 ? k0_dot2_first(y[h], y[h]) : __builtin_amdgcn_sdot2(y[h], y[h], s2, false);
     }
     const k0_v2s mn = __builtin_elementwise_min(__builtin_elementwise_min(y[0], y[1]), __builtin_elementwise_min(y[2], y[3]));
     const k0_v2s mx = __builtin_elementwise_max(__builtin_elementwise_max(y[0], y[1]), __builtin_elementwise_max(y[2], y[3]));
@@ -507,6 +551,9 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
             K0Rec<DT> r;
             if constexpr (PK16) {
                 k0_block_sums_pk16<DT>(raw[k][0], k0pk, r);
+            } else if constexpr (sdt(DT) == PS_DTYPE_F32 && !WIDE && PS_K0_PKF32) {
+                k0_block_sums_pkf32<DT>(raw[k], c.inv_q, mf, nz, r);
+                asm volatile("" : "+v"(nz));
             } else {
             k0_offsets<DT>(c, raw[k], m, mf, nz, y);
             asm volatile("" : "+v"(nz));               // (the integrality word is complete here: left alone, the compiler keeps x/q and its rounding of all 32 samples for one OR tree at the end)

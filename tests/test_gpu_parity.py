@@ -707,3 +707,51 @@ def test_round4_options_change_no_result(ctx, option, value, default):
     finally:
         ctx.set_option(option, default)
         ctx.set_option("mode", int(os.environ.get("PORESEG_MODE", "0")))
+
+
+@pytest.mark.parametrize("k0_waves", [0, 1])
+def test_fp32_block_sums_at_the_edges_of_the_packed_conversion(ctx, k0_waves):
+    """K0's fp32 fast route turns (x/q - m) into packed int16 by v_cvt_pknorm_i16_f32 (seg_bs.hpp, k0_block_sums_pkf32):
+    offsets up to +-16383 stay on the 32-bit digest, anything wider must saturate, fail the range check and send the call
+    to the 64-bit digest -- +-16384, +-32767, +-32768, beyond +-65536 (where a wrap-around would look narrow again) and
+    counts next to 2^23; a sample half a count, or 2^-10 of a count, off the grid, a NaN and an infinity must be refused.
+    Reference: cparsers.pyx:110-111 takes the samples as they are; the device's exact sums need them on the grid."""
+    import torch
+    from pypore_amd import _lib
+    n = 600_000
+    kw = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    base = synth.random_dwell_counts(n, 5, 1000, 20000).astype(np.int64)
+    ev = np.array([0, n], dtype=np.int64)
+    first = int(base[0])
+
+    def run(counts):
+        x = torch.from_numpy(counts.astype(np.float32) * np.float32(synth.QUANTUM)).cuda()
+        b, _, _ = ctx.segment_batch(x, ev, _lib.split_params(**kw), synth.QUANTUM, want_stats=False)
+        return b.cpu().numpy()
+
+    ctx.set_option("k0_waves", k0_waves)
+    try:
+        for amp in (16383, -16383, 16384, -16384, 32767, -32767, 32768, -32768, 65536 + 5, -65536 - 5, 131072, 3_000_000):
+            k = base.copy()
+            k[300_000:300_400] = first + amp               # a 400-sample excursion in the middle of whole blocks
+            k[450_003] = first + amp                       # and a lone sample
+            assert abs(k).max() < 2 ** 23
+            ref = oracle.parse(k.astype(np.float64) * synth.QUANTUM, **kw)
+            np.testing.assert_array_equal(run(k), ref, err_msg="amplitude %d" % amp)
+        # counts next to 2^23 (offsets narrow): a short event, so that the reference's own fp64 sums of squares stay exact
+        # (2.6e5 pA squared times 24 000 samples < 2^53; beyond that its cumsum rounding decides, tools/fuzz_gpu.py)
+        n2 = 24_000
+        k = synth.random_dwell_counts(n2, 6, 300, 2000).astype(np.int64)
+        k += 8_380_000 - int(k.max())
+        ref = oracle.parse(k.astype(np.float64) * synth.QUANTUM, **kw)
+        x = torch.from_numpy(k.astype(np.float32) * np.float32(synth.QUANTUM)).cuda()
+        b, _, _ = ctx.segment_batch(x, np.array([0, n2], dtype=np.int64), _lib.split_params(**kw), synth.QUANTUM, want_stats=False)
+        np.testing.assert_array_equal(b.cpu().numpy(), ref)
+        assert len(ref) > 5
+        for bad in (0.5, 2.0 ** -10, float("nan"), float("inf"), -float("inf")):
+            x = base.astype(np.float32) * np.float32(synth.QUANTUM)
+            x[333_333] = (base[333_333] + bad) * synth.QUANTUM if np.isfinite(bad) else bad
+            with pytest.raises(ValueError):
+                ctx.segment_batch(torch.from_numpy(x).cuda(), ev, _lib.split_params(**kw), synth.QUANTUM, want_stats=False)
+    finally:
+        ctx.set_option("k0_waves", 0)
