@@ -114,7 +114,14 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * "k0_shared" 1: this context queues its upload + K0 launches on the device's shared front stream, where the K0
  * kernels of all such contexts run back to back (they are bound by HBM: side by side they only share it) and the
  * context's own stream takes over behind an event; 0 (default) everything on the context's stream -- a host that keeps
- * several contexts busy (engine.StreamPool) sets it for the duration of its runs.  Unknown names return PS_ERR_ARG. */
+ * several contexts busy (engine.StreamPool) sets it for the duration of its runs (measured slower: nothing sets it);
+ * "k0_admit" M > 0: at most M calls of this device have their K0 in flight at a time (a call waits for a permit before
+ * it queues K0; the permit comes back when K0's event has completed), 0 (default) no limit -- engine.StreamPool sets 3;
+ * "bridge_ext" 1 (default): seams whose bridge ran out of anchors (256 without meeting a downstream tile's chain:
+ * densely stepped data) and open tiles entered exactly at their start are continued on the device -- up to four rounds,
+ * 16 384 more anchors per seam -- before the call falls back to the host stitch, 0 straight to the host stitch;
+ * "bridge_budget" 1..256 (default 256): anchors a bridge may add before it gives up (tests lower it to reach the second
+ * chance on small inputs).  Unknown names return PS_ERR_ARG. */
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);
 /* Blocks until all work submitted on the context's stream has finished. */
 int ps_synchronize(ps_ctx *ctx);

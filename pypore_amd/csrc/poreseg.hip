@@ -143,6 +143,9 @@ struct ps_ctx {
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
+    DevBuf bridge_ext, ext_slot, ext_list;          // second chance for seams that gave up (seg_device.hpp: EXT_MAX)
+    int bridge_budget = BR_MAX;                     // option bridge_budget (1 .. BR_MAX): anchors before a seam gives up -- tests lower it to reach the second chance on small inputs
+    int bridge_ext_on = 1;                          // option bridge_ext / PORESEG_BRIDGE_EXT: 0 = straight to the host stitch, as before round 5
     HostBuf h_hdr;
     DevBuf spine_jobs, spine_scratch, spine_dense, spine_meta, tree_jobs, tree_scratch, tree_spill,
         tree_counts, items, item_pos, first_item, ev_off, bounds_off, small;
@@ -574,7 +577,34 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (d_hdr) {
         const AsmHeader hd = hs.hdr;
         if (hdr_out) *hdr_out = hd;
-        if (hd.fail) return RC_FALLBACK;
+        if (hd.fail) {
+            if (std::getenv("PORESEG_DEBUG")) {        // which seams gave up (diagnostics)
+                const size_t nt = static_cast<size_t>(ctx->counters[2]);
+                std::vector<int4> bm(nt), mt(nt);
+                std::vector<SpineJob> jb(nt);
+                if (nt && hipMemcpy(bm.data(), ctx->bmeta.p, nt * sizeof(int4), hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(mt.data(), ctx->spine_meta.p, nt * sizeof(int4), hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(jb.data(), ctx->spine_jobs.p, nt * sizeof(SpineJob), hipMemcpyDeviceToHost) == hipSuccess) {
+                    int shown = 0;
+                    size_t n_open = 0, n_gave_up = 0, n_defer = 0;
+                    for (size_t g = 0; g < nt; ++g) {
+                        if (bm[g].w == 4) ++n_defer;
+                        else if (bm[g].w == 3 && mt[g].x == 0 && bm[g].x == 0) ++n_open;
+                        else if (bm[g].w == 3) ++n_gave_up;
+                    }
+                    fprintf(stderr, "[poreseg] stitch failed: %zu tiles; bridges that gave up after anchors of their own %zu, open tiles not bridged %zu, deferred and not finished %zu\n",
+                            nt, n_gave_up, n_open, n_defer);
+                    for (size_t g = 0; g < nt && shown < 6; ++g)
+                        if ((bm[g].w == 3 && !(mt[g].x == 0 && bm[g].x == 0)) || bm[g].w == 4) {
+                            fprintf(stderr, "[poreseg] stitch failed: tile %zu (event %d, tile %zu of %d, [%d, %d) of %d) bridge status %d after %d anchors (next window %d); its own list: %d anchors, ended %d, open at %d\n",
+                                    g, jb[g].ev, g - static_cast<size_t>(jb[g].first_tile), jb[g].ntiles, jb[g].start, jb[g].stop, jb[g].end,
+                                    bm[g].w, bm[g].x, bm[g].y, mt[g].x, mt[g].y, mt[g].z);
+                            ++shown;
+                        }
+                }
+            }
+            return RC_FALLBACK;
+        }
     }
     ctx->counters[0] = static_cast<int64_t>(hs.work0);
     ctx->counters[1] = static_cast<int64_t>(hs.work1);
@@ -637,7 +667,7 @@ template <int DT> int launch_bridge_la(ps_ctx *ctx, const DevCfg &cfg, unsigned 
     hipLaunchKernelGGL((bridge_la_kernel<DT>), dim3(grid), dim3(64 * BR_LA), 0, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
                        ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
-                       &sm->work0, static_cast<int>(nj));
+                       &sm->work0, static_cast<int>(nj), nullptr, nullptr, nullptr, 0, ctx->bridge_budget);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -650,7 +680,7 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
     hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
                        ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
-                       &sm->work0, static_cast<int>(nj), ctx->bridge_single);
+                       &sm->work0, static_cast<int>(nj), ctx->bridge_single, ctx->bridge_budget);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -905,28 +935,94 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
     const int use_lds = tile_lds <= 150 * 1024;
     if (use_lds)
         HIP_TRY(ctx, set_dyn_lds(ctx, reinterpret_cast<const void *>(assemble_tiles_kernel), static_cast<int>(tile_lds)));
-    hipLaunchKernelGGL(assemble_tiles_kernel, dim3(1), dim3(1024), use_lds ? tile_lds : 0, ctx->stream,
-                       static_cast<int>(nj), ctx->spine_meta.as<int4>(), ctx->bmeta.as<int4>(),
-                       ctx->ev_first_tile.as<int64_t>(), n_ev, ti, ti + njp, ti + 2 * njp, ti + 3 * njp,
-                       ctx->sp_off.as<long long>(), ctx->first_item.as<int64_t>(), ctx->asm_hdr.as<AsmHeader>(),
-                       static_cast<long long>(max_items), use_lds, reinterpret_cast<const unsigned *>(&sm->status));
-    HIP_TRY(ctx, hipGetLastError());
-    // no host round trip here: the downstream kernels read the item count from the header on the device
-    // (launches sized by the host-side upper bound), header and status are checked after the final sync
-    const AsmHeader *d_hdr = ctx->asm_hdr.as<AsmHeader>();
-    if (max_items > 0) {
-        const unsigned ag = static_cast<unsigned>(std::min<int64_t>((max_items + 255) / 256, 2048));
-        hipLaunchKernelGGL(assemble_items_kernel, dim3(ag), dim3(256), 0,
-                           ctx->stream, ctx->spine_jobs.as<SpineJob>(), static_cast<int>(nj), ctx->spine_meta.as<int4>(),
-                           ctx->spine_scratch.as<int2>(), ctx->bridges.as<int2>(), ti + 3 * njp,
-                           ctx->sp_off.as<long long>(), 0LL, mw, W, ctx->tree_jobs.as<TreeJob>(),
-                           ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr, cfg.bsum != nullptr ? cfg.ev_info : nullptr);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     AsmHeader hd = {};
-    int rc = finish_batch(ctx, cfg, static_cast<size_t>(max_items), max_items, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin,
+    int rc = PS_OK;
+    int64_t items_cap = max_items;                      // (grows with the seams a second-chance round extends)
+    int slots_used = 0, ext_stride = EXT_MAX;
+    for (int round = 0;; ++round) {
+        hipLaunchKernelGGL(assemble_tiles_kernel, dim3(1), dim3(1024), use_lds ? tile_lds : 0, ctx->stream,
+                           static_cast<int>(nj), ctx->spine_meta.as<int4>(), ctx->bmeta.as<int4>(),
+                           ctx->ev_first_tile.as<int64_t>(), n_ev, ti, ti + njp, ti + 2 * njp, ti + 3 * njp,
+                           ctx->sp_off.as<long long>(), ctx->first_item.as<int64_t>(), ctx->asm_hdr.as<AsmHeader>(),
+                           static_cast<long long>(items_cap), use_lds, reinterpret_cast<const unsigned *>(&sm->status));
+        HIP_TRY(ctx, hipGetLastError());
+        // no host round trip here: the downstream kernels read the item count from the header on the device
+        // (launches sized by the host-side upper bound), header and status are checked after the final sync
+        const AsmHeader *d_hdr = ctx->asm_hdr.as<AsmHeader>();
+        if (items_cap > 0) {
+            const unsigned ag = static_cast<unsigned>(std::min<int64_t>((items_cap + 255) / 256, 2048));
+            hipLaunchKernelGGL(assemble_items_kernel, dim3(ag), dim3(256), 0,
+                               ctx->stream, ctx->spine_jobs.as<SpineJob>(), static_cast<int>(nj), ctx->spine_meta.as<int4>(),
+                               ctx->spine_scratch.as<int2>(), ctx->bridges.as<int2>(), ti + 3 * njp,
+                               ctx->sp_off.as<long long>(), 0LL, mw, W, ctx->tree_jobs.as<TreeJob>(),
+                               ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr, cfg.bsum != nullptr ? cfg.ev_info : nullptr,
+                               ctx->bridge_ext.as<int2>(), ctx->ext_slot.as<int>(), ext_stride);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        if (ctx->timing >= 2 && round == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+        rc = finish_batch(ctx, cfg, static_cast<size_t>(items_cap), items_cap, n_ev, d_bounds, cap, h_bounds_off, d_stats, t_begin,
                           d_hdr, &hd, use_bs);
+        // ---- second chance for seams that gave up (the block-sum pipeline only: it has the look-ahead kernel) -------------
+        if (rc != RC_FALLBACK || !use_bs || !nj || round == EXT_ROUNDS || !ctx->bridge_ext_on) break;
+        HIP_TRY(ctx, ctx->h_meta.reserve(2 * nj * sizeof(int4)));
+        int4 *h_bm = ctx->h_meta.as<int4>(), *h_mt = h_bm + nj;
+        HIP_TRY(ctx, hipMemcpyAsync(h_bm, ctx->bmeta.p, nj * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_mt, ctx->spine_meta.p, nj * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // on the true path: whatever failed there (a seam out of anchors, an open tile entered at its start); elsewhere: the
+        // seams that ran out of anchors (few; they may lie on the path once the first ones are mended)
+        std::vector<int> list;
+        bool hopeless = false;
+        if (round == 0) {                              // few seams: long extensions; many (a batch of events): shorter ones
+            size_t n_fail = 0;
+            for (size_t g = 0; g < nj; ++g) n_fail += h_bm[g].w == BR_FAIL_REACHED || (h_bm[g].w == BR_FAIL && h_bm[g].x == ctx->bridge_budget);
+            ext_stride = n_fail <= static_cast<size_t>(EXT_SLOTS) / 2 ? EXT_MAX : EXT_MAX_MANY;
+        }
+        const int slot_cap = EXT_SLOTS * (EXT_MAX / ext_stride);
+        for (size_t g = 0; g < nj; ++g) {
+            const bool reached = h_bm[g].w == BR_FAIL_REACHED;
+            const bool gave_up = h_bm[g].x == ctx->bridge_budget;                 // (out of anchors in the first pass)
+            if (!reached && !(h_bm[g].w == BR_FAIL && gave_up)) continue;
+            const bool open_tile = h_mt[g].x == 0 && h_bm[g].x == 0;
+            if (!gave_up && !open_tile) { if (reached) hopeless = true; continue; }   // (extended before and still not joined)
+            if (slots_used + static_cast<int>(list.size()) < slot_cap) list.push_back(static_cast<int>(g));
+            else if (reached) hopeless = true;
+        }
+        if (list.empty() || hopeless) break;
+        if (std::getenv("PORESEG_DEBUG")) fprintf(stderr, "[poreseg] second chance, round %d: %zu seams continued on the device\n", round + 1, list.size());
+        const size_t n_ext = list.size();
+        HIP_TRY(ctx, ctx->bridge_ext.reserve(static_cast<size_t>(EXT_SLOTS) * EXT_MAX * sizeof(int2)));
+        HIP_TRY(ctx, ctx->ext_slot.reserve(nj * sizeof(int)));
+        HIP_TRY(ctx, ctx->ext_list.reserve(static_cast<size_t>(EXT_SLOTS) * (EXT_MAX / EXT_MAX_MANY) * sizeof(int)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ext_list.p, list.data(), n_ext * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                       // (list is a local)
+        HIP_TRY(ctx, hipMemsetAsync(&sm->hdr, 0, sizeof(AsmHeader), ctx->stream));
+        {
+            const bool f32 = cfg.dtype == PS_DTYPE_F32;
+            const unsigned g = static_cast<unsigned>(n_ext);
+#define PS_EXT(DTV) hipLaunchKernelGGL((bridge_la_kernel<DTV, true>), dim3(g), dim3(64 * BR_LA), 0, ctx->stream, cfg,                      \
+                                       ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),          \
+                                       ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),           \
+                                       &sm->work0, static_cast<int>(n_ext), ctx->ext_list.as<int>(), ctx->bridge_ext.as<int2>(),           \
+                                       ctx->ext_slot.as<int>(), slots_used, BR_MAX, ext_stride)
+            if (wide) { if (f32) PS_EXT(PS_DTYPE_F32 | DT_WIDE); else PS_EXT(PS_DTYPE_I16 | DT_WIDE); }
+            else      { if (f32) PS_EXT(PS_DTYPE_F32); else PS_EXT(PS_DTYPE_I16); }
+#undef PS_EXT
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        ctx->counters[4] += static_cast<int64_t>(n_ext);
+        slots_used += static_cast<int>(n_ext);
+        // room for the anchors the continued seams may add
+        items_cap += static_cast<int64_t>(n_ext) * ext_stride;
+        const int64_t ts2 = total_len / mw + items_cap + 1;
+        HIP_TRY(ctx, ctx->spine_items.reserve(static_cast<size_t>(items_cap) * sizeof(int4)));
+        HIP_TRY(ctx, ctx->tree_jobs.reserve(static_cast<size_t>(items_cap) * sizeof(TreeJob)));
+        HIP_TRY(ctx, ctx->tree_counts.reserve(static_cast<size_t>(items_cap) * sizeof(int32_t)));
+        HIP_TRY(ctx, ctx->items.reserve(static_cast<size_t>(items_cap) * sizeof(Item)));
+        HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(items_cap) + 1) * sizeof(int64_t)));
+        HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(ts2) * sizeof(int32_t)));
+        HIP_TRY(ctx, ctx->tree_spill.reserve(static_cast<size_t>(ts2) * sizeof(int2)));
+    }
     ctx->counters[3] = hd.n_items;
     float ms = 0;
     if (ctx->timing >= 2 && nj && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[0]) == hipSuccess) ctx->ms[6] = ms;       // blocksum_kernel (K0)
@@ -1005,6 +1101,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_SLOTS_PCT")) ctx->slots_pct = std::max(1, std::min(100, std::atoi(e)));
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
+    if (const char *e = std::getenv("PORESEG_BRIDGE_EXT")) ctx->bridge_ext_on = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
     *out = ctx;
     return PS_OK;
@@ -1021,7 +1118,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
                       &ctx->ev_boff, &ctx->blk_mm, &ctx->grp, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
-                      &ctx->align_in, &ctx->align_scratch};
+                      &ctx->align_in, &ctx->align_scratch, &ctx->bridge_ext, &ctx->ext_slot, &ctx->ext_list};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1053,6 +1150,8 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "k0_waves" && value >= 0 && value <= 16) ctx->k0_waves = static_cast<int>(value);
     else if (n == "k0_shared") ctx->k0_shared = value != 0;
     else if (n == "k0_admit" && value >= 0) ctx->k0_admit = static_cast<int>(value);
+    else if (n == "bridge_ext" && (value == 0 || value == 1)) ctx->bridge_ext_on = static_cast<int>(value);
+    else if (n == "bridge_budget" && value >= 1 && value <= BR_MAX) ctx->bridge_budget = static_cast<int>(value);
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
     else if (n == "tree_tail_pct" && value >= 0 && value <= 100) ctx->tree_tail_pct = static_cast<int>(value);

@@ -35,6 +35,14 @@ constexpr int BR_MAX = 256;       // bridge chain: anchors a seam may add before
                                   // data: two chains pick the best of ~10 steps per window and can take dozens of
                                   // anchors to meet; a seam that gives up sends the whole call to the host stitch)
 constexpr int LST_MAX = 256;
+// Round 5: seams that the bridges gave up on (BR_MAX anchors without meeting a downstream list: densely stepped data, where two
+// chains can stay out of step for a long stretch) and open tiles that the true chain enters exactly at their start get a second
+// chance on the device before the call falls back to the host stitch: the look-ahead kernel continues them with room for
+// EXT_MAX more anchors each, in a side buffer (anchor i >= BR_MAX of seam g lives at ext[ext_slot[g] * EXT_MAX + i - BR_MAX]).
+constexpr int EXT_MAX = 16384;     // further anchors of an extended seam when few seams need them (<= EXT_SLOTS) ...
+constexpr int EXT_SLOTS = 64;
+constexpr int EXT_MAX_MANY = 2048; // ... and when many do (a batch of events with a failed seam each): the side buffer holds
+constexpr int EXT_ROUNDS = 4;      // EXT_SLOTS * EXT_MAX anchors either way; the stride is fixed by the first round of a call
 constexpr int QMAX = 256;          // blocks of candidates queued for full evaluation per window
 constexpr int PBLK = 8;            // candidates per pruning block      // anchors of the downstream tile cached in LDS for membership tests        // buffered outputs per job (int2 anchors / 2x int boundaries)
 
@@ -1254,14 +1262,21 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
 // start): from there on the two chains are identical.  bmeta[g] = (count, join_tile, join_idx,
 // status); status 0 nothing to do, 1 joined (continue with list[join_tile][join_idx+1..]),
 // 2 the chain reached the end of the event, 3 gave up (host fallback).
-enum : int { BR_NONE = 0, BR_JOINED = 1, BR_ENDED = 2, BR_FAIL = 3, BR_DEFER = 4 };
+enum : int { BR_NONE = 0, BR_JOINED = 1, BR_ENDED = 2, BR_FAIL = 3, BR_DEFER = 4,
+              BR_FAIL_REACHED = 5 };                     // (set by the stitch: a failed seam that lies on the true path)
+__device__ __forceinline__ int2 bridge_at(const int2 *bridges, const int2 *ext, const int *ext_slot, int ext_stride, int g, int i)
+{
+    return i < BR_MAX ? bridges[static_cast<long long>(g) * BR_MAX + i]
+                      : ext[static_cast<long long>(ext_slot[g]) * ext_stride + (i - BR_MAX)];
+}
 constexpr int BR_PATIENCE = 3;     // windows without a hit a single-wave bridge scans in one find_split before it defers
                                    // the seam to the look-ahead kernel (bmeta = (count, next window, -, BR_DEFER))
 
 template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BRIDGE_MINW : 4)) PS_BRIDGE_REGS void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                        const int4 *meta, int2 *bridges, int4 *bmeta,
-                                                       unsigned *status, unsigned long long *work, int n_jobs, int max_single)
+                                                       unsigned *status, unsigned long long *work, int n_jobs, int max_single,
+                                                       int budget = BR_MAX)       // anchors before the seam gives up (option bridge_budget: tests)
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
@@ -1287,7 +1302,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BRIDGE_MINW : 4)) PS_BRIDGE_REGS
         int a = m.x > 0 ? lists[job.out_off + m.x - 1].x : job.start;
         int cnt = 0, st = BR_FAIL, jt = -1, ji = 0, cached = -1, ccnt = 0;
         const EvRef er = ev_ref_of(c, job.ev);
-        for (int step = 0; step <= BR_MAX; ++step) {
+        for (int step = 0; step <= budget; ++step) {
             int u = a / job.tile_len;
             if (u > job.ntiles - 1) u = job.ntiles - 1;
             u += job.first_tile;
@@ -1311,7 +1326,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BRIDGE_MINW : 4)) PS_BRIDGE_REGS
                 }
             }
             if (found != -2 && u != g) { st = BR_JOINED; jt = u; ji = found; break; }
-            if (step == BR_MAX) break;
+            if (step == budget) break;
             // option bridge_single (default: off): hand the seam to the look-ahead kernel after max_single anchors
             // (measured slower: 0.064 -> 0.076 / 0.083 ms with 2 / 1 anchors -- most seams need no second anchor)
             if (NT == 64 && c.bsum != nullptr && cnt >= max_single) { st = BR_DEFER; jt = 0; break; }
@@ -1341,10 +1356,15 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BRIDGE_MINW : 4)) PS_BRIDGE_REGS
 // bridge kernel is the place for it: few seams need more than a window or two, so the machine is nearly idle while
 // the longest seam sets the kernel's duration.  Semantics: find_split (cparsers.pyx:186-201) window by window.
 constexpr int BR_LA = 4;
-template <int DT>
+// EXT (second chance, see EXT_MAX): the seams listed in ext_list (slot = position in the list) instead of the deferred ones;
+// a seam that gave up resumes behind its last anchor, an open tile at its start (behind the windows its own chain scanned);
+// anchors beyond BR_MAX go to the side buffer.
+template <int DT, bool EXT = false>
 __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bridge_la_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                                   const int4 *meta, int2 *bridges, int4 *bmeta,
-                                                                  unsigned *status, unsigned long long *work, int n_jobs)
+                                                                  unsigned *status, unsigned long long *work, int n_jobs,
+                                                                  const int *ext_list = nullptr, int2 *ext = nullptr, int *ext_slot = nullptr,
+                                                                  int slot_base = 0, int budget = BR_MAX, int ext_stride = EXT_MAX)
 {
     __shared__ SharedT<64> shw[BR_LA];                 // one scratch per wave
     __shared__ int lst[LST_MAX];                       // downstream anchor positions (shared by the waves)
@@ -1356,19 +1376,23 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
     unsigned bad = 0;
     Work wk = PS_WORK_INIT;
     enum : int { O_CONT = 0, O_HIT = 1, O_EARLY = 2, O_LATE = 3, O_NONE = 4 };
-    for (int g = blockIdx.x; g < n_jobs; g += gridDim.x) {
+    const int LIMIT = EXT ? BR_MAX + ext_stride : budget;
+    for (int gi = blockIdx.x; gi < n_jobs; gi += gridDim.x) {
+        const int g = EXT ? ext_list[gi] : gi;
         const int4 bm = bmeta[g];
-        if (bm.w != BR_DEFER) continue;                // only the seams the single-wave bridge kernel deferred
+        if (!EXT && bm.w != BR_DEFER) continue;        // only the seams the single-wave bridge kernel deferred
         const SpineJob job = jobs[g];
         const int4 m = meta[g];
         int cnt = bm.x;                                // anchors the seam already has; the chain resumes behind the last one
-        for (int i = threadIdx.x; i < cnt; i += 64 * BR_LA) obuf[i] = bridges[static_cast<int64_t>(g) * BR_MAX + i];
+        for (int i = threadIdx.x; i < cnt && i < BR_MAX; i += 64 * BR_LA) obuf[i] = bridges[static_cast<int64_t>(g) * BR_MAX + i];
         __syncthreads();
-        int a = cnt > 0 ? obuf[cnt - 1].x : (m.x > 0 ? lists[job.out_off + m.x - 1].x : job.start);
+        const long long slot = slot_base + gi;         // (EXT) this seam's part of the side buffer
+        int a = cnt > 0 ? obuf[cnt - 1].x : (m.x > 0 ? lists[job.out_off + m.x - 1].x : job.start);   // (EXT: cnt <= BR_MAX, the host sees to it)
         int st = BR_FAIL, jt = -1, ji = 0, cached = -1, ccnt = 0;
         const EvRef er = ev_ref_of(c, job.ev);
-        long long jres = bm.y;                         // window of the current find_split to resume at
-        for (int step = cnt; step <= BR_MAX; ++step) {
+        // window of the current find_split to resume at (EXT: an open tile resumes behind the windows of its own chain)
+        long long jres = EXT ? (cnt == 0 && m.x == 0 ? m.z : 0) : bm.y;
+        for (int step = cnt; step <= LIMIT; ++step) {
             int u = a / job.tile_len;
             if (u > job.ntiles - 1) u = job.ntiles - 1;
             u += job.first_tile;
@@ -1392,7 +1416,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                 }
             }
             if (found != -2 && u != g) { st = BR_JOINED; jt = u; ji = found; break; }
-            if (step == BR_MAX) break;
+            if (step == LIMIT) break;
             // find_split(a, job.end) with look-ahead
             const long long start = a, end = job.end;
             const long long lim = end - 2LL * c.mw;
@@ -1431,13 +1455,19 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                 }
             }
             if (kind == KIND_NONE) { st = BR_ENDED; break; }
-            if (threadIdx.x == 0) obuf[cnt] = make_int2(s, kind);
+            if (threadIdx.x == 0) {
+                if (!EXT || cnt < BR_MAX) obuf[cnt] = make_int2(s, kind);
+                else ext[slot * ext_stride + (cnt - BR_MAX)] = make_int2(s, kind);
+            }
             ++cnt;
             a = s;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += 64 * BR_LA) bridges[static_cast<int64_t>(g) * BR_MAX + i] = obuf[i];
-        if (threadIdx.x == 0) bmeta[g] = make_int4(cnt, jt, ji, st);
+        for (int i = threadIdx.x; i < cnt && i < BR_MAX; i += 64 * BR_LA) bridges[static_cast<int64_t>(g) * BR_MAX + i] = obuf[i];
+        if (threadIdx.x == 0) {
+            bmeta[g] = make_int4(cnt, jt, ji, st);
+            if (EXT) ext_slot[g] = static_cast<int>(slot);
+        }
         __syncthreads();                               // obuf / lst are reused by the next tile
     }
     flush_wave(bad, wk, status, work, 1);              // counters: every wave counted its own scans
@@ -1878,7 +1908,7 @@ __device__ __forceinline__ void chunk_exscan2(long long v1, long long v2, long l
 // them, how many anchors each contributes.  The per-tile arrays live in LDS when they fit
 // (use_lds), otherwise in HBM scratch.
 __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
-    int n_tiles, const int4 *meta, const int4 *bmeta, const int64_t *ev_first_tile, int n_ev,
+    int n_tiles, const int4 *meta, int4 *bmeta, const int64_t *ev_first_tile, int n_ev,
     int *g_reach, int *g_jump_a, int *g_jump_b, int *entry_out, long long *sp_off_out,
     int64_t *first_item, AsmHeader *hdr, long long max_items, int use_lds, const unsigned *status)
 {
@@ -1929,7 +1959,10 @@ __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
         if (!reach[g]) continue;
         const int4 b = bmeta[g];
         if (b.w == BR_JOINED) entry[b.y] = b.z + 1;
-        if (b.w == BR_FAIL || b.w == BR_DEFER) fail_s = 1;
+        if (b.w == BR_FAIL || b.w == BR_DEFER || b.w == BR_FAIL_REACHED) {
+            fail_s = 1;
+            if (b.w == BR_FAIL) bmeta[g].w = BR_FAIL_REACHED;      // (for the host: this one lies on the true path)
+        }
     }
     __syncthreads();
     // D. contribution of every tile and its offset in the true spine
@@ -1969,7 +2002,8 @@ __global__ __launch_bounds__(1024) void assemble_tiles_kernel(
 __global__ __launch_bounds__(256) void assemble_items_kernel(
     const SpineJob *jobs, int n_tiles, const int4 *meta, const int2 *lists, const int2 *bridges,
     const int *entry, const long long *sp_off, long long n_items_host, int mw, int W,
-    TreeJob *tjobs, Item *items, int32_t *counts, const AsmHeader *hdr, const int4 *ev_info)
+    TreeJob *tjobs, Item *items, int32_t *counts, const AsmHeader *hdr, const int4 *ev_info,
+    const int2 *ext = nullptr, const int *ext_slot = nullptr, int ext_stride = EXT_MAX)
 {
     const long long n_items = dev_count(hdr, n_items_host);
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n_items; i += gridDim.x * 256LL) {
@@ -1989,9 +2023,9 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
         pred = (en + k) > 0 ? lists[jb2.out_off + en + k - 1].x : jb2.start;
     } else {
         const int kb = k - (cnt - en);
-        el = bridges[static_cast<long long>(g) * BR_MAX + kb];
+        el = bridge_at(bridges, ext, ext_slot, ext_stride, g, kb);
         // (a tile that gave up before its first anchor is entered at its start: that is the predecessor then)
-        pred = kb > 0 ? bridges[static_cast<long long>(g) * BR_MAX + kb - 1].x : (cnt > 0 ? lists[jb2.out_off + cnt - 1].x : jb2.start);
+        pred = kb > 0 ? bridge_at(bridges, ext, ext_slot, ext_stride, g, kb - 1).x : (cnt > 0 ? lists[jb2.out_off + cnt - 1].x : jb2.start);
     }
     const bool has = el.y == KIND_HIT || el.y == KIND_LATE;
     Item it;

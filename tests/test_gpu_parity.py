@@ -755,3 +755,37 @@ def test_fp32_block_sums_at_the_edges_of_the_packed_conversion(ctx, k0_waves):
                 ctx.segment_batch(torch.from_numpy(x).cuda(), ev, _lib.split_params(**kw), synth.QUANTUM, want_stats=False)
     finally:
         ctx.set_option("k0_waves", 0)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "int16"])
+def test_seams_out_of_anchors_get_a_second_chance_on_the_device(ctx, dtype):
+    """A seam's bridge gives up after BR_MAX anchors without meeting a downstream list (densely stepped data: 4 of the 1 536
+    seams of a 1e8-sample trace with dwells of 100-400 samples); the look-ahead kernel then continues those seams with room
+    for more anchors before the call falls back to the host stitch (seg_device.hpp: EXT_MAX; 236 -> 7 ms on that trace).
+    Here on a small dense trace with the budget lowered (option bridge_budget) so that most seams need it, against the oracle;
+    with the second chance switched off the same calls take the host stitch and give the same boundaries.
+    Reference: _recursive_split, cparsers.pyx:180-203 -- whatever way the chain is cut into pieces, it is one chain."""
+    import torch
+    from pypore_amd import _lib
+    n = 3_000_000
+    kw = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    d = synth.dwell_table(77, n, 100, 400)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    t = ctx.synth_trace(n, 77, np.cumsum(d), lv, dtype=getattr(torch, dtype))
+    x = t.cpu().numpy().astype(np.float64) * (synth.QUANTUM if dtype == "int16" else 1.0)
+    ref = oracle.parse(x, **kw)
+    ev = np.array([0, n], dtype=np.int64)
+    try:
+        seen = {}
+        for budget, ext in ((256, 1), (8, 1), (1, 1), (1, 0)):
+            ctx.set_option("bridge_budget", budget)
+            ctx.set_option("bridge_ext", ext)
+            b, _, _ = ctx.segment_batch(t, ev, _lib.split_params(**kw), synth.QUANTUM, want_stats=False)
+            np.testing.assert_array_equal(b.cpu().numpy(), ref, err_msg="budget %d, second chance %d" % (budget, ext))
+            seen[(budget, ext)] = int(ctx.timings()["repairs"])
+        assert seen[(256, 1)] == 0                                 # nothing to mend with the full budget on this trace
+        assert 0 < seen[(8, 1)] < 1_000_000 and 0 < seen[(1, 1)] < 1_000_000     # mended on the device
+        assert seen[(1, 0)] >= 1_000_000                           # (the host stitch marks its count that way)
+    finally:
+        ctx.set_option("bridge_budget", 256)
+        ctx.set_option("bridge_ext", 1)

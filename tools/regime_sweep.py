@@ -11,6 +11,11 @@ cases = [
     ("dwell 100-400", (100, 400), {}),
     ("dwell 500-5000", (500, 5000), {}),
     ("dwell 1e5-1e6", (100000, 1000000), {}),
+    ("dwell 1e6-1e7", (1000000, 10000000), {}),
+    ("dwell 1e7-5e7", (10000000, 50000000), {}),
+    ("no step at all", (n + 1, n + 2), {}),
+    ("no step at all, max_width 1e9", (n + 1, n + 2), dict(max_width=1000000000)),
+    ("dwell 1e5-1e6 max_width 1e9", (100000, 1000000), dict(max_width=1000000000)),
     ("dwell 1000-20000 W=1000", (1000, 20000), dict(window_width=1000)),
     ("dwell 1000-20000 W=50000", (1000, 20000), dict(window_width=50000)),
     ("dwell 1000-20000 mw=8 W=2000", (1000, 20000), dict(min_width=8, window_width=2000)),
