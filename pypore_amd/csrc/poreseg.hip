@@ -1102,6 +1102,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_BRIDGE_EXT")) ctx->bridge_ext_on = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_BRIDGE_BUDGET")) ctx->bridge_budget = std::min(std::max(std::atoi(e), 1), static_cast<int>(BR_MAX));
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
     *out = ctx;
     return PS_OK;
