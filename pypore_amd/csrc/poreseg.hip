@@ -976,7 +976,7 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
         if (round == 0) {                              // few seams: long extensions; many (a batch of events): shorter ones
             size_t n_fail = 0;
             for (size_t g = 0; g < nj; ++g) n_fail += h_bm[g].w == BR_FAIL_REACHED || (h_bm[g].w == BR_FAIL && h_bm[g].x == ctx->bridge_budget);
-            ext_stride = n_fail <= static_cast<size_t>(EXT_SLOTS) / 2 ? EXT_MAX : EXT_MAX_MANY;
+            ext_stride = n_fail <= static_cast<size_t>(EXT_SLOTS) ? EXT_MAX : EXT_MAX_MANY;
         }
         const int slot_cap = EXT_SLOTS * (EXT_MAX / ext_stride);
         for (size_t g = 0; g < nj; ++g) {
