@@ -208,3 +208,31 @@ def test_config3_full_size_abf_file_end_to_end(ctx, tmp_path):
     for e in range(len(st)):
         np.testing.assert_array_equal(bl[e], refs[e], err_msg="event %d" % e)
     assert sum(len(b) for b in bl) > 5000
+
+
+def test_dense_steps_full_size_are_mended_on_the_device(ctx):
+    """The 1e8-sample trace with dwells of 100-400 samples (400 000 segments): four of its 1 536 seams run out of anchors, the
+    look-ahead kernel continues them (seg_device.hpp: EXT_MAX) -- the call must not fall back to the host stitch (236 ms
+    before round 5, 6.5 with the second chance) and must give what the host stitch gives (option bridge_ext = 0: tiles with
+    halos, the LDS-window kernels, the chain followed on the host; the small edition of this test in test_gpu_parity.py
+    compares both with the oracle, which would take half a minute of one core here).
+    Reference: _recursive_split, cparsers.pyx:180-203."""
+    import torch
+    from pypore_amd import _lib
+    if os.environ.get("PORESEG_SCAN_BS") == "0" or os.environ.get("PORESEG_STITCH"):
+        pytest.skip("the second chance belongs to the block-sum device-stitch pipeline")
+    n = 100_000_000
+    d = synth.dwell_table(77, n, 100, 400)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    t = ctx.synth_trace(n, 77, np.cumsum(d), lv, dtype=torch.float32)
+    ctx.set_option("wide_bs", 1)                             # (forget a wide route an earlier test may have left this quantum on)
+    b, _, _ = ctx.segment_batch(t, np.array([0, n], dtype=np.int64), _lib.split_params(**DEF), synth.QUANTUM, want_stats=False)
+    repairs = int(ctx.timings()["repairs"])
+    assert 0 < repairs < 1_000_000, "the call fell back to the host stitch, or had nothing to mend"
+    try:
+        ctx.set_option("bridge_ext", 0)
+        ref, _, _ = ctx.segment_batch(t, np.array([0, n], dtype=np.int64), _lib.split_params(**DEF), synth.QUANTUM, want_stats=False)
+        assert int(ctx.timings()["repairs"]) >= 1_000_000      # (the host stitch marks its count that way)
+    finally:
+        ctx.set_option("bridge_ext", 1)
+    assert torch.equal(b, ref) and b.numel() > 300_000
