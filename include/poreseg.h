@@ -120,6 +120,9 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * "bridge_ext" 1 (default): seams whose bridge ran out of anchors (256 without meeting a downstream tile's chain:
  * densely stepped data) and open tiles entered exactly at their start are continued on the device -- up to four rounds,
  * 16 384 more anchors per seam -- before the call falls back to the host stitch, 0 straight to the host stitch;
+ * "lat_help" 1 (default): in the look-ahead kernel, workgroups that are through with their own seams scan chunks of 16
+ * windows ahead of the seams that walk long stretches without splits and publish what they find; the seam's owner takes a
+ * published chunk instead of scanning it (2 x on traces with stretches of 1e6 samples and more), 0 every seam walks alone;
  * "bridge_budget" 1..256 (default 256): anchors a bridge may add before it gives up (tests lower it to reach the second
  * chance on small inputs).  Unknown names return PS_ERR_ARG. */
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);

@@ -144,6 +144,10 @@ struct ps_ctx {
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
     DevBuf bridge_ext, ext_slot, ext_list;          // second chance for seams that gave up (seg_device.hpp: EXT_MAX)
+    DevBuf lat_state, lat_seam, lat_res;            // helpers of the look-ahead kernel (seg_device.hpp: LAT_D)
+    unsigned lat_tag_next = 1;                      // tags handed to calls so far (24 bits; the results are cleared before they run out)
+    unsigned lat_tag_base = 0;                      // this call's
+    int lat_help = 1;                               // option lat_help / PORESEG_LAT_HELP: 0 = every seam walks alone, as before round 5
     int bridge_budget = BR_MAX;                     // option bridge_budget (1 .. BR_MAX): anchors before a seam gives up -- tests lower it to reach the second chance on small inputs
     int bridge_ext_on = 1;                          // option bridge_ext / PORESEG_BRIDGE_EXT: 0 = straight to the host stitch, as before round 5
     HostBuf h_hdr;
@@ -252,7 +256,8 @@ void gate_leave(const ps_ctx *ctx, int device)       // the call has ended (or f
 // (hdr: the stitch header lives behind the counters so that one copy brings both back)
 // (SMALL_TAIL bytes behind it hold the per-event offsets of small batches, so that one copy brings everything back)
 constexpr size_t SMALL_TAIL = 64 * 1024;
-struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9], qctl, qhead, tree_tail; AsmHeader hdr; };
+struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9], qctl, qhead, tree_tail; AsmHeader hdr;
+                     unsigned long long lat_ctl[4]; int lat_prog[LAT_D]; };     // (helpers of the look-ahead kernel, seg_device.hpp: LAT_D)
 
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
              double min_gain, DevCfg *c)
@@ -661,13 +666,28 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
 
 
 
+// The helpers' shared state for this call (none when switched off, or not the block-sum pipeline)
+LatHelp lat_help_of(ps_ctx *ctx, const DevCfg &cfg, SmallLayout *sm)
+{
+    if (!ctx->lat_help || cfg.bsum == nullptr || !ctx->lat_res.p) return LAT_NONE;
+    LatHelp h;
+    h.ctl = sm->lat_ctl;
+    h.state = ctx->lat_state.as<unsigned long long>();
+    h.seam = ctx->lat_seam.as<int>();
+    h.prog = sm->lat_prog;
+    h.res = ctx->lat_res.as<unsigned long long>();
+    h.tag_base = ctx->lat_tag_base;
+    return h;
+}
+
 template <int DT> int launch_bridge_la(ps_ctx *ctx, const DevCfg &cfg, unsigned nj, SmallLayout *sm)
 {
     const unsigned grid = std::min(nj, resident_slots(ctx, bridge_la_kernel<DT>, 64 * BR_LA, 0));
     hipLaunchKernelGGL((bridge_la_kernel<DT>), dim3(grid), dim3(64 * BR_LA), 0, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
                        ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
-                       &sm->work0, static_cast<int>(nj), nullptr, nullptr, nullptr, 0, ctx->bridge_budget);
+                       &sm->work0, static_cast<int>(nj), nullptr, nullptr, nullptr, 0, ctx->bridge_budget, static_cast<int>(EXT_MAX),
+                       lat_help_of(ctx, cfg, sm));
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -680,7 +700,8 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
     hipLaunchKernelGGL((bridge_kernel<NT, DT>), dim3(grid), dim3(NT), lds, ctx->stream, cfg,
                        ctx->spine_jobs.as<SpineJob>(), ctx->spine_scratch.as<int2>(), ctx->spine_meta.as<int4>(),
                        ctx->bridges.as<int2>(), ctx->bmeta.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),
-                       &sm->work0, static_cast<int>(nj), ctx->bridge_single, ctx->bridge_budget);
+                       &sm->work0, static_cast<int>(nj), ctx->bridge_single, ctx->bridge_budget,
+                       NT == 64 ? lat_help_of(ctx, cfg, sm) : LAT_NONE);
     HIP_TRY(ctx, hipGetLastError());
     return PS_OK;
 }
@@ -778,6 +799,21 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
     HIP_TRY(ctx, ctx->spine_scratch.reserve(std::max<int64_t>(1, list_entries) * sizeof(int2)));
     HIP_TRY(ctx, ctx->spine_meta.reserve(std::max<size_t>(4, nj) * sizeof(int4)));
     HIP_TRY(ctx, ctx->bridges.reserve(std::max<size_t>(1, nj) * BR_MAX * sizeof(int2)));
+    if (use_bs && ctx->lat_help) {
+        // (published chunk results carry the tag of their listing; a fresh buffer is zero, tags start at 1, and before the 24
+        //  bits run out the buffer is cleared)
+        const size_t res_bytes = static_cast<size_t>(LAT_D) * LAT_C * sizeof(unsigned long long);
+        HIP_TRY(ctx, ctx->lat_state.reserve(LAT_D * sizeof(unsigned long long)));
+        HIP_TRY(ctx, ctx->lat_seam.reserve(LAT_D * sizeof(int)));
+        HIP_TRY(ctx, ctx->lat_res.reserve_zeroed(res_bytes, ctx->stream));
+        if (ctx->lat_tag_next + 2u * LAT_TAGS >= (1u << 24)) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->lat_res.p, 0, res_bytes, ctx->stream));
+            ctx->stream_idle = false;
+            ctx->lat_tag_next = 1;
+        }
+        ctx->lat_tag_base = ctx->lat_tag_next;
+        ctx->lat_tag_next += LAT_TAGS;
+    }
     HIP_TRY(ctx, ctx->bmeta.reserve(std::max<size_t>(1, nj) * sizeof(int4)));
     HIP_TRY(ctx, ctx->tile_i32.reserve(std::max<size_t>(1, nj) * 4 * sizeof(int)));
     HIP_TRY(ctx, ctx->sp_off.reserve((nj + 1) * sizeof(long long)));
@@ -1102,6 +1138,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
     if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
     if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
     if (const char *e = std::getenv("PORESEG_BRIDGE_EXT")) ctx->bridge_ext_on = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_LAT_HELP")) ctx->lat_help = std::atoi(e) != 0;
     if (const char *e = std::getenv("PORESEG_BRIDGE_BUDGET")) ctx->bridge_budget = std::min(std::max(std::atoi(e), 1), static_cast<int>(BR_MAX));
     if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
     *out = ctx;
@@ -1119,7 +1156,8 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->tile_i32, &ctx->sp_off, &ctx->spine_items, &ctx->asm_hdr, &ctx->ev_first_tile, &ctx->ev_len,
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
                       &ctx->ev_boff, &ctx->blk_mm, &ctx->grp, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
-                      &ctx->align_in, &ctx->align_scratch, &ctx->bridge_ext, &ctx->ext_slot, &ctx->ext_list};
+                      &ctx->align_in, &ctx->align_scratch, &ctx->bridge_ext, &ctx->ext_slot, &ctx->ext_list,
+                      &ctx->lat_state, &ctx->lat_seam, &ctx->lat_res};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1152,6 +1190,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "k0_shared") ctx->k0_shared = value != 0;
     else if (n == "k0_admit" && value >= 0) ctx->k0_admit = static_cast<int>(value);
     else if (n == "bridge_ext" && (value == 0 || value == 1)) ctx->bridge_ext_on = static_cast<int>(value);
+    else if (n == "lat_help" && (value == 0 || value == 1)) ctx->lat_help = static_cast<int>(value);
     else if (n == "bridge_budget" && value >= 1 && value <= BR_MAX) ctx->bridge_budget = static_cast<int>(value);
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);

@@ -39,6 +39,32 @@ constexpr int LST_MAX = 256;
 // chains can stay out of step for a long stretch) and open tiles that the true chain enters exactly at their start get a second
 // chance on the device before the call falls back to the host stitch: the look-ahead kernel continues them with room for
 // EXT_MAX more anchors each, in a side buffer (anchor i >= BR_MAX of seam g lives at ext[ext_slot[g] * EXT_MAX + i - BR_MAX]).
+// Round 5, long stretches without splits.  The windows of a chain between two anchors lie on a lattice a + J * W/2, and whether
+// window J holds a split does not depend on who asks.  In the look-ahead kernel an OWNER (the workgroup that walks a seam) that
+// has scanned LAT_W windows of one find_split without a hit LISTS the stretch: lattice origin, a fresh tag, the chunk (LAT_W
+// windows) it is in.  Workgroups that are through with their own seams HELP: they scan chunks ahead of the listed owners -- a
+// few at first, more as the owner gets further -- and publish each chunk's first hit as one 64-bit word under the stretch's
+// tag.  An owner at a chunk boundary takes a published result instead of scanning the chunk, and scans it itself when there is
+// none: nobody waits for anybody's result.  Forced splits (start + max_width) keep the lattice when max_width is a multiple of
+// W/2; a real split starts a new one (listed again once it has gone LAT_W windows).  Helpers stay while the single-wave bridge
+// kernel has seen a deferred seam with an open tile ahead (ctl[0]) and until every workgroup is through with its own seams.
+constexpr int LAT_D = 256;         // listed stretches' slots (one per seam that ever lists)
+constexpr int LAT_W = 16;          // windows per chunk
+constexpr int LAT_C = 2048;        // chunks per lattice (32 768 windows: 1.6e8 samples at W = 10 000)
+constexpr int LAT_TAGS = 4096;     // listings per call (tags are unique per context until the host clears the results: 24 bits)
+struct LatHelp {
+    unsigned long long *ctl;       // [0] hint (bridge_kernel) [1] slots taken [2] tags taken [3] workgroups through with their own seams
+    unsigned long long *state;     // [LAT_D] lattice origin | tag << 32 | first helped chunk << 56 (one word: read and written whole)
+    int *seam;                     // [LAT_D] the seam (tile) of the slot
+    int *prog;                     // [LAT_D] 0: nothing to help with; else 1 + the chunk the owner is in (zeroed with the call's status block)
+    unsigned long long *res;       // [LAT_D * LAT_C] tag << 40 | offset of the chunk's first hit << 32 | its split (0xffffffff: none)
+    unsigned tag_base;             // first tag of this call
+};
+constexpr LatHelp LAT_NONE = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+__device__ __forceinline__ unsigned long long lat_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int lat_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lat_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lat_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr int EXT_MAX = 16384;     // further anchors of an extended seam when few seams need them (<= EXT_SLOTS) ...
 constexpr int EXT_SLOTS = 64;
 constexpr int EXT_MAX_MANY = 2048; // ... and when many do (a batch of events with a failed seam each): the side buffer holds
@@ -1276,7 +1302,8 @@ template <int NT, int DT>
 __global__ __launch_bounds__(NT, (NT == 64 ? PS_BRIDGE_MINW : 4)) PS_BRIDGE_REGS void bridge_kernel(DevCfg c, const SpineJob *jobs, const int2 *lists,
                                                        const int4 *meta, int2 *bridges, int4 *bmeta,
                                                        unsigned *status, unsigned long long *work, int n_jobs, int max_single,
-                                                       int budget = BR_MAX)       // anchors before the seam gives up (option bridge_budget: tests)
+                                                       int budget = BR_MAX,       // anchors before the seam gives up (option bridge_budget: tests)
+                                                       LatHelp lat = LAT_NONE)
 {
     extern __shared__ int ys[];
     __shared__ SharedT<NT> sh;
@@ -1343,7 +1370,19 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BRIDGE_MINW : 4)) PS_BRIDGE_REGS
         }
         __syncthreads();
         for (int i = threadIdx.x; i < cnt; i += NT) bridges[static_cast<int64_t>(g) * BR_MAX + i] = sh.obuf[i];
-        if (threadIdx.x == 0) bmeta[g] = make_int4(cnt, jt, ji, st);
+        if (threadIdx.x == 0) {
+            bmeta[g] = make_int4(cnt, jt, ji, st);
+            // a deferred seam with an open tile a chunk ahead: the stretch goes on -- the look-ahead kernel's idle workgroups stay to help
+            if (st == BR_DEFER && lat.ctl != nullptr && c.half > 0) {
+                const long long ps0 = static_cast<long long>(a) + static_cast<long long>(jt + LAT_W) * c.half;
+                if (ps0 < static_cast<long long>(job.end) - 2LL * c.mw) {
+                    int u = static_cast<int>(ps0 / job.tile_len);
+                    if (u > job.ntiles - 1) u = job.ntiles - 1;
+                    const int4 mu = meta[job.first_tile + u];
+                    if (mu.x == 0 && mu.y == 0) atomicAdd(&lat.ctl[0], 1ull);
+                }
+            }
+        }
         __syncthreads();                               // obuf / lst are reused by the next tile
     }
     flush(bad, wk, status, work, 1);
@@ -1364,13 +1403,19 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                                                                   const int4 *meta, int2 *bridges, int4 *bmeta,
                                                                   unsigned *status, unsigned long long *work, int n_jobs,
                                                                   const int *ext_list = nullptr, int2 *ext = nullptr, int *ext_slot = nullptr,
-                                                                  int slot_base = 0, int budget = BR_MAX, int ext_stride = EXT_MAX)
+                                                                  int slot_base = 0, int budget = BR_MAX, int ext_stride = EXT_MAX,
+                                                                  LatHelp lat = LAT_NONE)
 {
+    __shared__ unsigned long long lat_e;               // a published chunk result / a decision of thread 0 (broadcast)
+    __shared__ unsigned long long lat_state[EXT ? 1 : LAT_D];
+    __shared__ int lat_prog[EXT ? 1 : LAT_D];
     __shared__ SharedT<64> shw[BR_LA];                 // one scratch per wave
     __shared__ int lst[LST_MAX];                       // downstream anchor positions (shared by the waves)
     __shared__ int2 obuf[BR_MAX];
     __shared__ int2 res[BR_LA];                        // per wave: (outcome, value)
     if ((*status & ST_WIDE_RANGE) != 0u) return;       // K0 refused the data: the host redoes the call
+    // (the single-wave bridge kernel's hint, requested here so that nobody waits for it at the end: do idle workgroups stay to help?)
+    const bool lat_stay = !EXT && lat.res != nullptr && c.half > 0 && lat.ctl[0] != 0ull;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     SharedT<64> &sh = shw[wave];
     unsigned bad = 0;
@@ -1392,6 +1437,12 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
         const EvRef er = ev_ref_of(c, job.ev);
         // window of the current find_split to resume at (EXT: an open tile resumes behind the windows of its own chain)
         long long jres = EXT ? (cnt == 0 && m.x == 0 ? m.z : 0) : bm.y;
+        // the seam's listed stretch, if any (see LAT_D): slot, lattice origin, tag
+        const bool lat_use = lat_stay;                 // (no helpers, no listing)
+        int lslot = -1;
+        long long la0 = 0;
+        unsigned ltag = 0;
+        bool lat_valid = false;
         for (int step = cnt; step <= LIMIT; ++step) {
             int u = a / job.tile_len;
             if (u > job.ntiles - 1) u = job.ntiles - 1;
@@ -1423,10 +1474,73 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
             int kind = KIND_NONE, s = -1;
             const long long jfirst = jres;
             jres = 0;
-            for (long long j = jfirst;; j += BR_LA) {
+            // Window j of this find_split is lattice window Jbase + j: of the listed lattice while the phase holds (the find_split
+            // that listed it, and those behind forced splits), else of the find_split's own (Jbase 0), not listed yet.  Steps are
+            // aligned to multiples of four lattice windows so that chunk boundaries are step boundaries.
+            bool on_lat = lat_valid && start >= la0 && (start - la0) % c.half == 0;
+            if (!on_lat && lat_valid) {                                        // a real split broke the phase: the listed stretch is over
+                lat_valid = false;
+                if (threadIdx.x == 0) lat_st(&lat.prog[lslot], 0);
+            }
+            long long Jbase = on_lat ? (start - la0) / c.half : 0;
+            int nw = BR_LA;
+            for (long long j = jfirst;; j += nw) {
+                nw = (lat_use && Jbase + j >= LAT_W / 2) ? BR_LA - static_cast<int>((Jbase + j) & (BR_LA - 1)) : BR_LA;   // (aligned from the eighth window on)
+                if (lat_use && lslot != -2 && ((Jbase + j) & (LAT_W - 1)) == 0 && Jbase + j >= LAT_W) {
+                    // ---- a chunk boundary, LAT_W or more windows into a stretch ----
+                    const long long ci = (Jbase + j) / LAT_W;
+                    if (!on_lat) {                                             // a stretch on a lattice of its own: list it
+                        if (threadIdx.x == 0) {
+                            int sl = lslot;
+                            if (sl < 0) {
+                                const unsigned long long t = atomicAdd(&lat.ctl[1], 1ull);
+                                sl = t < static_cast<unsigned long long>(LAT_D) ? static_cast<int>(t) : -2;
+                                if (sl >= 0) lat_st(&lat.seam[sl], g);
+                            }
+                            unsigned long long tg = 0;
+                            if (sl >= 0) {
+                                tg = atomicAdd(&lat.ctl[2], 1ull);
+                                if (tg >= static_cast<unsigned long long>(LAT_TAGS)) sl = -2;
+                            }
+                            lat_e = (static_cast<unsigned long long>(static_cast<unsigned>(sl)) << 32) | (lat.tag_base + static_cast<unsigned>(tg));
+                        }
+                        __syncthreads();
+                        lslot = static_cast<int>(static_cast<unsigned>(lat_e >> 32));
+                        ltag = static_cast<unsigned>(lat_e);
+                        __syncthreads();
+                        if (lslot >= 0 && ci < 256) {
+                            la0 = start; Jbase = 0; lat_valid = true; on_lat = true;
+                            if (threadIdx.x == 0)
+                                lat_st(&lat.state[lslot], static_cast<unsigned long long>(static_cast<unsigned>(start)) |
+                                                          (static_cast<unsigned long long>(ltag) << 32) | (static_cast<unsigned long long>(ci) << 56));
+                        }
+                    }
+                    if (on_lat && ci < LAT_C) {
+                        if (threadIdx.x == 0) {
+                            // where the owner is (release: the slot's seam and state are out before a helper sees the slot active)
+                            __hip_atomic_store(&lat.prog[lslot], static_cast<int>(ci) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            lat_e = lat_ld(&lat.res[static_cast<long long>(lslot) * LAT_C + ci]);
+                        }
+                        __syncthreads();
+                        const unsigned long long e = lat_e;
+                        __syncthreads();
+                        if (static_cast<unsigned>(e >> 40) == ltag) {                          // a helper has been here
+                            const int pos = static_cast<int>(static_cast<unsigned>(e));
+                            const int off = static_cast<int>((e >> 32) & 15u);
+                            const long long last = pos >= 0 ? j + off : j + LAT_W - 1;          // the last window the result stands for
+                            const long long ps_last = start + last * c.half;
+                            if (ps_last < lim && ps_last <= start + c.maxw) {                   // (none of them ends the loop or forces a split)
+                                if (pos >= 0) { kind = KIND_HIT; s = pos; break; }
+                                nw = LAT_W;
+                                continue;
+                            }
+                        }
+                    }
+                }
                 const long long ps = start + (j + wave) * c.half;
                 int oc = O_CONT, val = -1;
-                if (ps >= lim) {                                               // the loop is over: :199-201
+                if (wave >= nw) {                                              // (alignment step: this wave sits it out)
+                } else if (ps >= lim) {                                        // the loop is over: :199-201
                     if (end - start <= c.maxw) oc = O_NONE;
                     else { oc = O_LATE; const long long x = start + c.maxw, y = end - c.mw; val = static_cast<int>(x < y ? x : y); }
                 } else if (ps > start + c.maxw) {                              // :189-191
@@ -1467,8 +1581,87 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
         if (threadIdx.x == 0) {
             bmeta[g] = make_int4(cnt, jt, ji, st);
             if (EXT) ext_slot[g] = static_cast<int>(slot);
+            if (lslot >= 0) lat_st(&lat.prog[lslot], 0);                       // nothing left to help with
         }
         __syncthreads();                               // obuf / lst are reused by the next tile
+    }
+    // ---- helper: chunks of the listed stretches, ahead of their owners (see LAT_D) -----------------------------------------
+    if constexpr (!EXT) {
+        if (lat_stay) {
+            if (threadIdx.x == 0) atomicAdd(&lat.ctl[3], 1ull);                // through with my own seams
+            const bool stay = true;
+            const long long t_start = wall_clock64();
+            const int H = static_cast<int>(gridDim.x);
+            while (stay) {
+                if (threadIdx.x == 0) lat_e = (min(lat_ld(&lat.ctl[1]), static_cast<unsigned long long>(LAT_D)) << 32) | lat_ld(&lat.ctl[3]);
+                __syncthreads();
+                const int D = static_cast<int>(lat_e >> 32);
+                const bool all_through = static_cast<unsigned>(lat_e) >= gridDim.x;
+                __syncthreads();
+                for (int t = threadIdx.x; t < D; t += 64 * BR_LA) {
+                    lat_prog[t] = __hip_atomic_load(&lat.prog[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - 1;   // (-1: not active)
+                    lat_state[t] = lat_ld(&lat.state[t]);
+                }
+                int act = 0;
+                __syncthreads();
+                for (int t = threadIdx.x; t < D; t += 64 * BR_LA) act |= lat_prog[t] >= 0;
+                const bool any_active = __syncthreads_or(act) != 0;
+                if (!any_active && all_through) break;
+                if (wall_clock64() - t_start > 5000000LL) break;              // (50 ms at 100 MHz: a guard, never the way out)
+                bool worked = false;
+                for (int sI = 0; sI < D; ++sI) {
+                    const int pr = lat_prog[sI];
+                    if (pr < 0) continue;
+                    const unsigned long long stw = lat_state[sI];
+                    const int cfirst = static_cast<int>(stw >> 56);
+                    const unsigned tag = static_cast<unsigned>(stw >> 32) & 0xffffffu;
+                    const long long a0 = static_cast<long long>(static_cast<unsigned>(stw));
+                    const int look = max(4, min(H, 2 * (pr - cfirst) + 4));   // how far ahead of the owner: grows with its progress
+                    const int r = (static_cast<int>(blockIdx.x) + H - (sI * 7) % H) % H;
+                    const int ci = pr + 1 + ((r - (pr + 1) % H + H) % H);     // my chunk among the next H
+                    if (ci > pr + look || ci >= LAT_C) continue;
+                    unsigned long long *slot_p = &lat.res[static_cast<long long>(sI) * LAT_C + ci];
+                    if (threadIdx.x == 0) lat_e = (static_cast<unsigned>(lat_ld(slot_p) >> 40) == tag) ? 1ull : 0ull;
+                    __syncthreads();
+                    const bool published = lat_e != 0ull;
+                    __syncthreads();
+                    if (published) continue;
+                    const int hg = lat_ld(&lat.seam[sI]);
+                    if (hg < 0 || hg >= n_jobs) continue;                      // (cannot be: the slot's seam is out before the slot is active)
+                    const SpineJob job = jobs[hg];
+                    const long long end = job.end, lim = end - 2LL * c.mw;
+                    const long long ps0 = a0 + static_cast<long long>(ci) * LAT_W * c.half;
+                    const EvRef er = ev_ref_of(c, job.ev);
+                    int hit_off = 0, hit_pos = -1;
+                    for (int rr = 0; rr < LAT_W / BR_LA; ++rr) {
+                        const long long ps = ps0 + static_cast<long long>(rr * BR_LA + wave) * c.half;
+                        int val = -1;
+                        if (ps < lim) {
+                            long long pe = ps + c.W;
+                            if (pe > end) pe = end;
+                            if (pe - ps > 2LL * c.mw) {
+                                wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1;
+                                val = scan_window_bs<DT>(c, er, job.base, static_cast<int>(ps), static_cast<int>(pe),
+                                                         static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
+                            }
+                        }
+                        if ((threadIdx.x & 63) == 0) res[wave] = make_int2(val >= 0 ? O_HIT : O_CONT, val);
+                        __syncthreads();
+                        int first = -1;
+#pragma unroll
+                        for (int w = BR_LA - 1; w >= 0; --w) if (res[w].x != O_CONT) first = w;
+                        const int2 rv = res[first < 0 ? 0 : first];
+                        __syncthreads();
+                        if (first >= 0) { hit_off = rr * BR_LA + first; hit_pos = rv.y; break; }
+                    }
+                    if (threadIdx.x == 0)
+                        lat_st(slot_p, (static_cast<unsigned long long>(tag) << 40) | (static_cast<unsigned long long>(hit_off & 15) << 32) | static_cast<unsigned>(hit_pos));
+                    worked = true;
+                }
+                if (!worked) __builtin_amdgcn_s_sleep(32);
+                __syncthreads();                                               // lat_prog / lat_state are rewritten by the next round
+            }
+        }
     }
     flush_wave(bad, wk, status, work, 1);              // counters: every wave counted its own scans
 }

@@ -792,3 +792,44 @@ def test_seams_out_of_anchors_get_a_second_chance_on_the_device(ctx, dtype):
     finally:
         ctx.set_option("bridge_budget", 256)
         ctx.set_option("bridge_ext", 1)
+
+
+SPARSE = [
+    ("no step", None, {}),
+    ("no step, max_width not a multiple of W/2", None, dict(max_width=123456)),
+    ("no step, W 4000, max_width 50000", None, dict(window_width=4000, max_width=50000)),
+    ("dwell 1e5-1e6", (100000, 1000000), {}),
+    ("dwell 3e5-3e6, max_width 250000", (300000, 3000000), dict(max_width=250000)),
+]
+
+
+@pytest.mark.parametrize("case", SPARSE, ids=[c[0] for c in SPARSE])
+def test_long_stretches_without_splits_with_and_without_helpers(case, ctx):
+    """The chain through a stretch without splits is sequential by the reference's definition (find_split, cparsers.pyx:186-201:
+    the next window starts where the last anchor is); the look-ahead kernel's idle workgroups scan chunks of the stretch's
+    window lattice ahead of the seam's owner, who takes their results instead of scanning (seg_device.hpp: LAT_D).  Whatever
+    they publish, the boundaries are the oracle's -- across forced splits that keep the lattice (max_width a multiple of
+    W/2) and ones that do not, and the same with the helpers switched off (option lat_help)."""
+    import torch
+    from pypore_amd import _lib
+    name, dwell, extra = case
+    n = 4_000_000
+    kw = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
+    kw.update(extra)
+    lo, hi = dwell if dwell else (n + 1, n + 2)
+    d = synth.dwell_table(77, n, lo, hi)
+    lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    t = ctx.synth_trace(n, 77, np.cumsum(d), lv, dtype=torch.float32)
+    ref = oracle.parse(t.cpu().numpy().astype(np.float64), **kw)
+    ctx.set_option("wide_bs", 1)                             # (forget a wide route an earlier test may have left this quantum on)
+    windows = {}
+    try:
+        for on in (1, 0):
+            ctx.set_option("lat_help", on)
+            b, _, _ = ctx.segment_batch(t, np.array([0, n], dtype=np.int64), _lib.split_params(**kw), synth.QUANTUM, want_stats=False)
+            np.testing.assert_array_equal(b.cpu().numpy(), ref, err_msg="helpers %d" % on)
+            windows[on] = int(ctx.timings()["windows"])
+    finally:
+        ctx.set_option("lat_help", 1)
+    if not (os.environ.get("PORESEG_SCAN_BS") == "0" or os.environ.get("PORESEG_STITCH")):
+        assert windows[1] > windows[0]                       # the helpers did scan (speculation costs windows, saves time)
