@@ -46,8 +46,9 @@ constexpr int LST_MAX = 256;
 // few at first, more as the owner gets further -- and publish each chunk's first hit as one 64-bit word under the stretch's
 // tag.  An owner at a chunk boundary takes a published result instead of scanning the chunk, and scans it itself when there is
 // none: nobody waits for anybody's result.  Forced splits (start + max_width) keep the lattice when max_width is a multiple of
-// W/2; a real split starts a new one (listed again once it has gone LAT_W windows).  Helpers stay while the single-wave bridge
-// kernel has seen a deferred seam with an open tile ahead (ctl[0]) and until every workgroup is through with its own seams.
+// W/2; a real split starts a new one (listed again once it has gone LAT_W windows).  Helpers stay only if the single-wave bridge
+// kernel has seen a deferred seam with an open tile ahead (ctl[0]: never on densely stepped data), and leave when nothing is
+// listed and every workgroup is through with its own seams -- or nothing has been listed for ~0.1 ms.
 constexpr int LAT_D = 256;         // listed stretches' slots (one per seam that ever lists)
 constexpr int LAT_W = 16;          // windows per chunk
 constexpr int LAT_C = 2048;        // chunks per lattice (32 768 windows: 1.6e8 samples at W = 10 000)
@@ -1590,6 +1591,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
         if (lat_stay) {
             if (threadIdx.x == 0) atomicAdd(&lat.ctl[3], 1ull);                // through with my own seams
             const bool stay = true;
+            int idle_polls = 0;
             const long long t_start = wall_clock64();
             const int H = static_cast<int>(gridDim.x);
             while (stay) {
@@ -1606,7 +1608,11 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                 __syncthreads();
                 for (int t = threadIdx.x; t < D; t += 64 * BR_LA) act |= lat_prog[t] >= 0;
                 const bool any_active = __syncthreads_or(act) != 0;
-                if (!any_active && all_through) break;
+                // Out when nothing is listed and either every workgroup of the launch is through with its own seams, or nothing
+                // has been listed for a while (~0.1 ms): workgroups of this launch that have not started yet may be waiting for
+                // the very slots the helpers sit on -- a helper must never wait for them.
+                idle_polls = any_active ? 0 : idle_polls + 1;
+                if (!any_active && (all_through || idle_polls > 32)) break;
                 if (wall_clock64() - t_start > 5000000LL) break;              // (50 ms at 100 MHz: a guard, never the way out)
                 bool worked = false;
                 for (int sI = 0; sI < D; ++sI) {

@@ -447,6 +447,15 @@ class StreamPool(object):
             self._k0w = k0w
         elif k0w and hasattr(self.contexts[0], "set_option"):
             self.contexts[0].set_option("k0_waves", k0w)
+        # The look-ahead kernel's helpers ("lat_help": idle workgroups scan ahead of a seam that walks a long stretch without
+        # splits) are for a call that has the chip to itself -- 2 x on sparse traces; with sixteen calls in flight the other
+        # calls are the better use of an idle workgroup (measured: a trace without steps 1.2 -> 8.6 ms per step with them on).
+        lh = 0 if T > 1 and n_jobs > 1 else 1
+        if "PORESEG_LAT_HELP" not in os.environ and lh != getattr(self, "_lat_help", 1):
+            for cx in self.contexts:
+                if hasattr(cx, "set_option"):
+                    cx.set_option("lat_help", lh)
+            self._lat_help = lh
         admit = int(os.environ.get("PORESEG_POOL_K0_MAX", "3")) if T > 3 else 0
         if admit != getattr(self, "_admit", 0):
             for cx in self.contexts:
@@ -464,6 +473,9 @@ class StreamPool(object):
             self._front_stream(self.contexts[0], 0)
         if getattr(self, "_k0w", 0) and hasattr(self.contexts[0], "set_option"):
             self.contexts[0].set_option("k0_waves", 0)   # (set again for contexts[0] at the next run)
+        if not getattr(self, "_lat_help", 1) and hasattr(self.contexts[0], "set_option"):
+            self.contexts[0].set_option("lat_help", 1)   # (the caller's own context is a lone one again)
+            self._lat_help = 1                           # (... so the next run sets all of them again)
         if errors:
             raise errors[0]
         return results
@@ -501,6 +513,8 @@ def context(device=None):
         mine = _thread_contexts.by_device = {}
     if device not in mine:
         mine[device] = Context(device)
+        if "PORESEG_LAT_HELP" not in os.environ and hasattr(mine[device], "set_option"):
+            mine[device].set_option("lat_help", 0)       # (a worker thread's context shares the chip with the others': no helpers)
     return mine[device]
 
 

@@ -16,7 +16,7 @@ ctx0 = pool.contexts[0]
 traces = []
 for t in range(T):
     sd = 2024 + 1000 * t
-    d = synth.dwell_table(sd, n); ends = np.cumsum(d); lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
+    d = synth.dwell_table(sd, n, int(float(os.environ.get("DWELL_LO", 1000))), int(float(os.environ.get("DWELL_HI", 20000)))); ends = np.cumsum(d); lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
     traces.append(ctx0.synth_trace(n, sd, ends, lv, dtype=torch.float32))
 ev_off = np.array([0, n], dtype=np.int64)
 outs = [torch.empty(n // 100 + 1, dtype=torch.int32, device="cuda") for _ in range(T)]
