@@ -118,3 +118,38 @@ def test_pool_options_do_not_change_a_result(options):
     for x in th: x.start()
     for x in th: x.join()
     assert not errors, errors[:4]
+
+
+def test_pool_sets_the_options_of_shared_contexts_and_gives_the_callers_context_back(monkeypatch):
+    """engine.StreamPool.run: while several contexts are in flight they run K0 persistent, with a limit on the K0s in flight
+    and WITHOUT the look-ahead kernel's helpers (idle workgroups belong to the other calls then); afterwards the caller's own
+    context -- contexts[0], the one SpeedyStatSplit.parse uses -- is a lone context again.  (No GPU: recording contexts.)"""
+    from pypore_amd import engine
+
+    class Rec(object):
+        def __init__(self, device):
+            self.device = device
+            self.opts = {}
+            self.log = []
+
+        def set_option(self, name, value):
+            self.opts[name] = value
+            self.log.append((name, value))
+    monkeypatch.setattr(engine, "Context", Rec)
+    monkeypatch.setattr(engine, "_contexts", {})
+    for k in ("PORESEG_LAT_HELP", "PORESEG_K0_WAVES", "PORESEG_POOL_K0_WAVES", "PORESEG_POOL_K0_MAX", "PORESEG_POOL_SHARED"):
+        monkeypatch.delenv(k, raising=False)
+    pool = engine.StreamPool(0, 4)
+    during = []
+    out = pool.run(8, lambda cx, k, t: during.append((t, dict(cx.opts))) or k)
+    assert out == list(range(8))
+    for t, o in during:
+        assert o.get("lat_help") == 0 and o.get("k0_waves") == 1 and o.get("k0_admit") == 3, (t, o)
+    assert pool.contexts[0].opts["lat_help"] == 1 and pool.contexts[0].opts["k0_waves"] == 0      # the caller's context: lone again
+    assert all(c.opts["lat_help"] == 0 for c in pool.contexts[1:])
+    during.clear()
+    pool.run(8, lambda cx, k, t: during.append((t, dict(cx.opts))) or k)                          # a second run sets context 0 again
+    assert all(o.get("lat_help") == 0 and o.get("k0_waves") == 1 for _, o in during)
+    pool.run(1, lambda cx, k, t: during.append((t, dict(cx.opts))) or k)                          # one job: nothing shared
+    assert during[-1][1]["lat_help"] == 1 and during[-1][1]["k0_waves"] == 0
+    pool.close()
