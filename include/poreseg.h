@@ -273,7 +273,8 @@ int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_mod
  * kernels, or the host stitch), ms[5] bridge kernels, ms[6] block-prefix kernel (K0; 0 for the LDS-window scan)
  * -- every such event keeps the next kernel from starting back to back (about 6 us of idle GPU each), so the
  * breakdown is a diagnostic and off by default.  counters[0] window scans, [1] candidate
- * positions covered, [2] tiles, [3] tree jobs, [4] seam repairs, [5] windows decided in fp64 (among
+ * positions covered, [2] tiles, [3] tree jobs, [4] seams mended: 1 .. 999 999 seams continued on the device (option
+ * "bridge_ext"), 1 000 000 + n the call was redone by the host stitch, with n repairs, [5] windows decided in fp64 (among
  * contenders or by a whole-window scan), [6] of which whole-window scans, [7] 1 = the call was redone on the 64-bit
  * digest, 2 = on the LDS-window kernels (counts too wide for the block sums), [8] [9] [10] window scans of the spine /
  * bridge / subtree kernels, [11] near ties: windows decided among fp64 contenders whose margin -- winner against the best
