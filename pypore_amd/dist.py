@@ -41,6 +41,17 @@ def gather_varlen(local, group=None):
     return [o[:c] for o, c in zip(out, counts)]
 
 
+class _StreamDone(object):
+    """wait() of a gather queued on a stream by the library (BoundaryGather backend "library"): an event on that stream."""
+
+    def __init__(self, stream):
+        self.ev = torch.cuda.Event()
+        self.ev.record(stream)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class BoundaryGather:
     """The boundary gather as ONE fixed-shape collective per batch and no host synchronisation on the
     submitting side: every rank contributes a slot of `capacity` elements, element 0 = its count,
@@ -54,10 +65,23 @@ class BoundaryGather:
     buffer's head is sent as it is (whatever lies behind the count's worth of payload is ignored by the receiver)."""
     HEADER = 4          # elements before the payload (16 bytes: the payload keeps its alignment)
 
-    def __init__(self, capacity, device, dtype=torch.int32, group=None, depth=2):
+    def __init__(self, capacity, device, dtype=torch.int32, group=None, depth=2, backend="torch"):
+        """backend "torch" (default): torch.distributed's all_gather on the group (RCCL on GPUs, gloo in the CPU tests);
+        "library": the C ABI's own entry point, ps_gather_bounds of libporeseg_comm.so (include/poreseg_comm.h) -- the
+        same ncclAllGather underneath, on a communicator the library sets up (its id travels over the torch group once)."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.cap = int(capacity)
+        self.comm = None
+        if backend == "library":
+            from . import _comm
+            assert dtype == torch.int32, "ps_gather_bounds gathers int32 boundaries"
+            ids = [_comm.unique_id() if dist.get_rank(group) == 0 else None]
+            dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            dev = torch.device(device)
+            self.comm = _comm.Comm.for_rank(self.world, dist.get_rank(group), ids[0], dev.index if dev.index is not None else torch.cuda.current_device())
+        else:
+            assert backend == "torch", backend
         self.slots = [dict(send=torch.zeros(self.cap, dtype=dtype, device=device),
                            recv=torch.zeros(self.world * self.cap, dtype=dtype, device=device),
                            work=None, local=None) for _ in range(depth)]
@@ -79,7 +103,11 @@ class BoundaryGather:
             if n <= self.cap - self.HEADER:
                 send[self.HEADER:self.HEADER + n].copy_(local)
         s["local"] = local
-        s["work"] = dist.all_gather_into_tensor(s["recv"], send, group=self.group, async_op=True)
+        if self.comm is not None:
+            self.comm.gather_bounds(send, s["recv"])         # on the current stream: ordered behind the kernels that wrote `send`
+            s["work"] = _StreamDone(torch.cuda.current_stream(send.device))
+        else:
+            s["work"] = dist.all_gather_into_tensor(s["recv"], send, group=self.group, async_op=True)
         self.k += 1
         return self.k - 1
 

@@ -24,6 +24,24 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in L.ps_version()
 
 
+def test_comm_library_loads_and_exports_every_declared_symbol():
+    """libporeseg_comm.so (include/poreseg_comm.h: SURVEY 8(b)'s ps_comm_init_all / ps_gather_bounds); no call that needs a GPU."""
+    from pypore_amd import _comm
+    L = _comm.lib()
+    hdr = open(os.path.join(ROOT, "include", "poreseg_comm.h")).read()
+    declared = set(re.findall(r"\b(ps_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_comm.EXPORTS)
+    for name in sorted(declared):
+        assert hasattr(L, name), "libporeseg_comm.so does not export %s" % name
+    assert int(re.search(r"#define PS_COMM_ID_BYTES (\d+)", hdr).group(1)) == _comm.ID_BYTES
+    assert int(re.search(r"#define PS_GATHER_HEADER (\d+)", hdr).group(1)) == _comm.HEADER
+    from pypore_amd import dist as pdist
+    assert pdist.BoundaryGather.HEADER == _comm.HEADER
+    assert L.ps_comm_world(None) == 0 and L.ps_comm_rank(None) == -1          # (NULL handles are answered, not dereferenced)
+    h = ctypes.c_void_p()
+    assert L.ps_comm_init_rank(2, 5, b"x" * 128, 0, ctypes.byref(h)) == -1 and b"rank 5" in L.ps_comm_last_error()
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.SplitParams) == 56
     assert ctypes.sizeof(_lib.SampleFormat) == 16
