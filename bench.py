@@ -281,6 +281,9 @@ def main():
                     help="contexts (HIP streams) the K steps of the trace / file workloads are spread over: independent "
                          "batches overlap on the GPU (engine.StreamPool); 1 = one batch at a time")
     ap.add_argument("--workload", choices=["trace", "file", "sharded-trace", "files"], default="trace")
+    ap.add_argument("--diag-env", action="store_true",
+                    help="experiments only: apply the PORESEG_* variables of the environment as context options "
+                         "(engine.apply_env_defaults); without it they are recorded in host.poreseg_env_seen and ignored")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="run only the N > 1 plumbing of this file on CPU tensors over gloo (no GPU needed) and print one JSON line")
     args = ap.parse_args()
@@ -304,6 +307,11 @@ def main():
     from pypore_amd import dist as pdist
 
     rank = int(os.environ.get("RANK", "0"))
+
+    def stage(msg):
+        """progress of an N > 1 job on stderr (stdout carries rank 0's one JSON line)"""
+        sys.stderr.write("[bench] %s\n" % msg)
+        sys.stderr.flush()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = args.gpus > 1 or world > 1 or os.environ.get("PORESEG_BENCH_DIST") == "1"   # env: exercise the
@@ -311,11 +319,23 @@ def main():
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
+        stage("rank %d/%d: init_process_group(nccl) on cuda:%d of %d visible" % (rank, world, local_rank, torch.cuda.device_count()))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # a first run on N GPUs that dies should say where: every rank reports on stderr before the clock
+        try:
+            rccl = ".".join(str(v_) for v_ in torch.cuda.nccl.version())
+        except Exception as e_:                          # noqa: BLE001
+            rccl = "unknown (%s)" % e_
+        probe = torch.tensor([rank], dtype=torch.int64, device=torch.device("cuda", local_rank))
+        seen = torch.zeros(world, dtype=torch.int64, device=probe.device)
+        dist.all_gather_into_tensor(seen, probe)
+        stage("rank %d: RCCL %s, ranks_seen=%d, first all_gather %s" % (rank, rccl, dist.get_world_size(), seen.cpu().tolist()))
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
     device = torch.device("cuda", dev)
+    if args.diag_env:
+        engine.apply_env_defaults()
     ctx = engine.context(dev)
     params = _lib.split_params(**PARAMS)
     W, mw = PARAMS["window_width"], PARAMS["min_width"]
@@ -383,6 +403,8 @@ def main():
             jg = JobGather(steps, JobGather.slot_for(most), world, device)
             acc, acc_counts = jg.acc, jg.counts
             final_gather = jg.run
+            stage("rank %d: first batch %d boundaries; per_rank_boundaries before the clock %s; gather slot %d"
+                  % (rank, int(b0.numel()), [int(t.numel()) for t in pdist.gather_varlen(b0)], jg.slot))
 
     elif wl == "sharded-trace":
         halo = 8 * W
@@ -637,12 +659,20 @@ def main():
         achieved = per_gpu_bytes / (seq * 1e-3) / 1e9 if seq > 0 else 0.0
         names = ("blocksum_ms", "spine_ms", "bridge_ms", "tree_ms")
         dom = max(names, key=lambda k: kern[k])
-        k0_bytes = (bytes_per_sample + 2) * (trace.numel() if trace is not None else n)
         traffic = None
         if wl == "trace" and os.path.exists(PMC_FILE) and not args.dwell and not args.stats and n == 100_000_000 \
-                and not os.environ.get("PORESEG_LIB"):
+                and not os.environ.get("PORESEG_LIB") and not args.diag_env:
             with open(PMC_FILE) as f:
                 traffic = json.load(f)                   # {"source": ..., "total": bytes, "per_kernel": {...}}
+        # what K0 moves per launch: the samples once + 8 B of digest per 8 samples + 16 B of group record per 256 + 16 B of
+        # chunk totals per 1 024 = bytes_per_sample + 1.078 B per sample -- or, where this run is the profiled
+        # command, the bytes the PMC passes counted for the kernel (round 5's line priced it at +2 B: round 2's 16-byte digest)
+        n_k0 = trace.numel() if trace is not None else n
+        k0_bytes = int(round((bytes_per_sample + 1.0 + 16.0 / 256.0 + 16.0 / 1024.0) * n_k0))
+        k0_bytes_src = "model: %d B read + 1.078 B written per sample (digest 8 B / 8 samples, group record 16 B / 256, chunk totals 16 B / 1 024)" % bytes_per_sample
+        if traffic and traffic.get("per_kernel", {}).get("blocksum_kernel"):
+            k0_bytes = int(traffic["per_kernel"]["blocksum_kernel"])
+            k0_bytes_src = "PMC: FETCH x 2 + WRITE of the kernel, " + os.path.basename(PMC_FILE)
         workload_text = {
             "trace": "one %.0e-sample fp32 trace per GPU (5-level step signal, dwell U[1000,20000), sigma 1 pA, 2^-5 pA grid), "
                      "single SpeedyStatSplit.parse over the whole trace; every stream segments its own trace (seeds 2024 + 1000 t)" % n,
@@ -686,7 +716,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes),
                          "longest_kernel": dom.replace("_ms", "_kernel"),
                          "streaming_kernel": {"name": "blocksum_kernel", "ms": round(kern["blocksum_ms"], 4),
-                                              "algorithmic_bytes": k0_bytes,
+                                              "bytes_per_launch": k0_bytes, "bytes_source": k0_bytes_src,
                                               "achieved": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / 1e9, 1) if kern["blocksum_ms"] > 0 else None,
                                               "frac": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / HBM_PEAK, 4) if kern["blocksum_ms"] > 0 else None},
                          "traffic_per_kernel": traffic["per_kernel"] if traffic else None,
@@ -720,7 +750,12 @@ def main():
             # LDS-window path (counts too wide for the block sums), full fp64 window scans
             "host": {"omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "torch_threads": torch.get_num_threads(),
                      "affinity_cpus": len(os.sched_getaffinity(0)), "under_torchrun": "TORCHELASTIC_RUN_ID" in os.environ,
-                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                     # libporeseg.so and pypore_amd read no PORESEG_* variable (round 6): listed so that a line measured with
+                     # --diag-env or a diagnostic library says so itself
+                     "poreseg_env_seen": {k_: v_ for k_, v_ in sorted(os.environ.items()) if k_.startswith("PORESEG_")},
+                     "poreseg_env_applied": bool(args.diag_env), "library": os.path.basename(_lib.LIB_PATH),
+                     "library_version": _lib.lib().ps_version().decode()},
             "fallbacks": {"host_stitch": int(tm["repairs"] >= 1000000), "seam_repairs": int(tm["repairs"] % 1000000),
                           "wide_range_redo": int(tm.get("wide_redo", 0)), "full_exact_scans": int(tm["full_exact_scans"]),
                           "near_ties": int(tm.get("near_ties", 0))},

@@ -122,9 +122,23 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * 16 384 more anchors per seam -- before the call falls back to the host stitch, 0 straight to the host stitch;
  * "lat_help" 1 (default): in the look-ahead kernel, workgroups that are through with their own seams scan chunks of 16
  * windows ahead of the seams that walk long stretches without splits and publish what they find; the seam's owner takes a
- * published chunk instead of scanning it (2 x on traces with stretches of 1e6 samples and more), 0 every seam walks alone;
+ * published chunk instead of scanning it (2 x on traces with stretches of 1e6 samples and more), 0 every seam walks alone,
+ * 2 as 1 but the helpers stay until every workgroup of the launch is through with its own seams (never leave on idle polls:
+ * for tests that must see them work -- counters[12], [13] of ps_get_timings; only for a call that has the chip to itself);
  * "bridge_budget" 1..256 (default 256): anchors a bridge may add before it gives up (tests lower it to reach the second
- * chance on small inputs).  Unknown names return PS_ERR_ARG. */
+ * chance on small inputs);
+ * "shared_device" n: ONE call for a host that keeps n contexts busy on one device (a pool of host threads, one context
+ * each): n > 1 sets k0_waves 1, lat_help 0 and, for n > 3, k0_admit 3 -- the measured settings of a shared chip
+ * (INTEGRATION.md has the table) --, n <= 1 restores the defaults of a lone context (k0_waves 0, lat_help 1, k0_admit 0);
+ * "debug" 1: the library reports on stderr which occupancy it found and which seams gave up (prints only);
+ * "slots_pct" 1..100 (default 100) share of the resident wave slots the single-wave scan kernels are launched on;
+ * "tree_jobs_per_wave" (default 4) subtree kernel: jobs / this many of its slots work, between half and all of them;
+ * "noise_k_ppm" (default 100 000 = 0.1): near-tie accounting of the 64-bit digest, margin factor in millionths.
+ * Unknown names return PS_ERR_ARG.
+ * THE LIBRARY READS NO ENVIRONMENT VARIABLE (round 6): what a call returns depends on its arguments and on these two
+ * setters only.  The experiments' switches that return stale or partial results ("dbg_phase", "dbg_k0_nogrp",
+ * "scan_lds_pad", "rep_*") and the PORESEG_* variables exist in libporeseg_diag.so only (make -C pypore_amd/csrc diag;
+ * ps_version() of that build says DIAGNOSTIC BUILD). */
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value);
 /* Blocks until all work submitted on the context's stream has finished. */
 int ps_synchronize(ps_ctx *ctx);
@@ -280,9 +294,11 @@ int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_mod
  * bridge / subtree kernels, [11] near ties: windows decided among fp64 contenders whose margin -- winner against the best
  * other candidate, or against min_gain -- is below 1e-9 * max(1, |gain|).  The device logarithm is not glibc's bit for bit
  * (gains differ by ~1e-11), so the reference could have decided such a window the other way; exact ties are decided like
- * the reference (first maximum wins, cparsers.pyx:175-177) and counted too. */
+ * the reference (first maximum wins, cparsers.pyx:175-177) and counted too; [12] chunk results (16 windows each) that the
+ * look-ahead kernel's helpers published (option "lat_help"), [13] published chunks that a seam's owner took instead of
+ * scanning them. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);
-/* The twelve work counters of ps_get_timings in place (valid for the life of the context; host memory, updated by every
+/* The fourteen work counters of ps_get_timings in place (valid for the life of the context; host memory, updated by every
  * call before it returns): a caller that checks one of them after each call -- counters[11], the near ties -- reads it
  * there instead of making a second call. */
 const int64_t *ps_counters(const ps_ctx *ctx);

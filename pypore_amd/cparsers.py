@@ -9,6 +9,8 @@ import numpy as np
 from . import _lib, engine
 from .core import Segment, segments_from_edges
 
+FILTER_BATCH = True          # False: a file's events are filtered and re-quantised one library call each (A/B: tools/profile_filtered_file.py)
+
 
 def _dc_counts(level, step):
     """A level in pA as whole counts of `step`, clipped to int32 (ps_sample_format.offset_counts of fp32 samples)."""
@@ -175,9 +177,8 @@ class FastStatSplit(object):
                 continue
             base, a0, n0 = where
             groups.setdefault((base.data_ptr(), float(g[1])), []).append((i, base, a0, n0, float(g[2])))
-        import os
         for key, members in groups.items():
-            if len(members) < 2 or os.environ.get("PORESEG_FILTER_BATCH", "1") == "0":
+            if len(members) < 2 or not FILTER_BATCH:
                 continue
             base = members[0][1]
             starts = [a0 for _, _, a0, _, _ in members]

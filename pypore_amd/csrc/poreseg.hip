@@ -105,9 +105,16 @@ struct ps_ctx {
     int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
     bool gate_held = false;
     bool defer_sync = false;  // (internal) ps_filter_requantise_batch: the filter entry only queues its kernels -- no status clear, copy, sync
-    int scan_lds_pad = 0;     // diagnostics (PORESEG_SCAN_LDS_PAD): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
-    int dbg_phase = 0;        // diagnostics (PORESEG_DBG_PHASE; WRONG or stale results, never set by the product): 1 a call that repeats the previous
-                              // one's layout skips K0 (the digest is still there: what the scan kernels cost on their own), 2 K0 only
+    int scan_lds_pad = 0;     // diagnostics (libporeseg_diag.so only: option scan_lds_pad): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
+    int debug = 0;            // option debug: the library says on stderr which seams gave up, which occupancy it found (prints only; results unchanged)
+#ifdef PS_DIAG
+    // Diagnostics that return WRONG or stale results exist in libporeseg_diag.so only (make -C pypore_amd/csrc diag): the product
+    // library neither holds this code nor reads the environment (round 6).
+    int dbg_phase = 0;        // 1 a call that repeats the previous one's layout skips K0 (the digest is still there: what the scan kernels cost
+                              // on their own), 2 K0 only
+    int dbg_k0_nogrp = 0;     // 1 a call that repeats the previous one's layout runs K0 WITHOUT its group-record part (the records of the previous
+                              // call are still there and the scans read those: what K0's ~37 instructions per block cost the step)
+#endif
     int k0_shared = 0;        // 1: upload + K0 of this context run on the device's shared FRONT stream (round 5): the K0 launches of all contexts that
                               // ask for it are serialised there, back to back, and the context's own stream takes over behind an event.  K0 is the
                               // one kernel of a call that is bound by HBM; several of them at once only share the same bytes per second while the
@@ -158,7 +165,7 @@ struct ps_ctx {
     int timing = 1;           // 0: no events, 1: start/end of the sequence, 2: an event between the phases as well (each costs
                               // ~6 us of idle GPU: the next kernel does not start back to back)
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t counters[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t counters[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [12] chunk results the look-ahead helpers published, [13] of which an owner took
 };
 
 namespace {
@@ -193,11 +200,13 @@ FrontStream *front_for(ps_ctx *ctx)
     FrontStream *f = &g_front[ctx->device];
     std::lock_guard<std::mutex> lk(f->mu);
     if (!f->s) {
+#ifdef PS_DIAG
         int lo = 0, hi = 0;
         const char *pr = std::getenv("PORESEG_FRONT_PRIORITY");         // 1: highest priority the device offers (experiments)
         if (pr && std::atoi(pr) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
             if (hipStreamCreateWithPriority(&f->s, hipStreamNonBlocking, hi) != hipSuccess) { f->s = nullptr; (void)hipGetLastError(); }
         }
+#endif
         if (!f->s && hipStreamCreateWithFlags(&f->s, hipStreamNonBlocking) != hipSuccess) { f->s = nullptr; (void)hipGetLastError(); return nullptr; }
     }
     return f;
@@ -220,20 +229,32 @@ void gate_drop(K0Gate &g, const ps_ctx *owner)
     for (size_t i = 0; i < g.slots.size();)
         if (g.slots[i].owner == owner) g.slots.erase(g.slots.begin() + static_cast<long>(i)); else ++i;
 }
-void gate_enter(ps_ctx *ctx, int device, int max_in_flight, hipEvent_t ev)
+// Returns PS_OK with a permit held, or PS_ERR_HIP when the device reports an error for a K0 event (a fault or a hang: the slot
+// is given back, the error goes to the caller -- nobody spins on a dead device).  The wait is bounded: a caller that has not
+// been admitted after GATE_WAIT_MS goes ahead WITHOUT a permit (admission is a throughput measure, never a correctness one).
+constexpr int GATE_WAIT_MS = 250;
+int gate_enter(ps_ctx *ctx, int device, int max_in_flight, hipEvent_t ev, bool *held)
 {
     K0Gate &g = g_gate[device & 15];
+    *held = false;
+    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; ++spin) {
+        hipError_t bad = hipSuccess;
         {
             std::lock_guard<std::mutex> lk(g.mu);
             if (spin == 0) gate_drop(g, ctx);          // (a slot of this context's previous call: that call has ended)
             for (size_t i = 0; i < g.slots.size();) {
-                if (g.slots[i].recorded && hipEventQuery(g.slots[i].ev) == hipSuccess) g.slots.erase(g.slots.begin() + static_cast<long>(i));
+                hipError_t q = g.slots[i].recorded ? hipEventQuery(g.slots[i].ev) : hipErrorNotReady;
+                if (q == hipSuccess) g.slots.erase(g.slots.begin() + static_cast<long>(i));
+                else if (q != hipErrorNotReady) { bad = q; g.slots.erase(g.slots.begin() + static_cast<long>(i)); }   // (device error: the slot goes back)
                 else ++i;
             }
             (void)hipGetLastError();                   // (hipErrorNotReady of the queries)
-            if (static_cast<int>(g.slots.size()) < max_in_flight) { g.slots.push_back({ctx, ev, false}); return; }
+            if (bad == hipSuccess && static_cast<int>(g.slots.size()) < max_in_flight) { g.slots.push_back({ctx, ev, false}); *held = true; return PS_OK; }
         }
+        if (bad != hipSuccess)
+            return fail(ctx, PS_ERR_HIP, "K0 admission: hipEventQuery failed: %s (%s:%d)", hipGetErrorString(bad), __FILE__, __LINE__);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(GATE_WAIT_MS)) return PS_OK;   // (no permit: go ahead)
         // (a K0 takes 100-300 us: a look every few tens of microseconds is plenty, and thirteen waiting threads that hammer
         //  the runtime with queries get in the way of the three that are launching)
         std::this_thread::sleep_for(std::chrono::microseconds(25));
@@ -257,7 +278,7 @@ void gate_leave(const ps_ctx *ctx, int device)       // the call has ended (or f
 // (SMALL_TAIL bytes behind it hold the per-event offsets of small batches, so that one copy brings everything back)
 constexpr size_t SMALL_TAIL = 64 * 1024;
 struct SmallLayout { unsigned long long status, work0, work1, work2, dense, stamp[12], life[9], qctl, qhead, tree_tail; AsmHeader hdr;
-                     unsigned long long lat_ctl[4]; int lat_prog[LAT_D]; };     // (helpers of the look-ahead kernel, seg_device.hpp: LAT_D)
+                     unsigned long long lat_ctl[6]; int lat_prog[LAT_D]; };     // (helpers of the look-ahead kernel, seg_device.hpp: LAT_D)
 
 int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int mw, int maxw, int W,
              double min_gain, DevCfg *c)
@@ -314,7 +335,7 @@ template <typename K> unsigned resident_slots(ps_ctx *ctx, K kernel, int nt, siz
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, lds) != hipSuccess || per_cu <= 0)
         per_cu = 1;
     unsigned slots = static_cast<unsigned>(per_cu) * static_cast<unsigned>(ctx->n_cu);
-    if (std::getenv("PORESEG_DEBUG")) fprintf(stderr, "[poreseg] occupancy: %d workgroups of %d threads per CU (dynamic LDS %zu), %d CUs\n", per_cu, nt, lds, ctx->n_cu);
+    if (ctx->debug) fprintf(stderr, "[poreseg] occupancy: %d workgroups of %d threads per CU (dynamic LDS %zu), %d CUs\n", per_cu, nt, lds, ctx->n_cu);
     if (nt <= 256) slots = std::max(1u, static_cast<unsigned>(static_cast<unsigned long long>(slots) * static_cast<unsigned>(ctx->slots_pct) / 100u));
     ctx->occ_cache.push_back({fn, nt, lds, slots});
     return slots;
@@ -583,7 +604,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         const AsmHeader hd = hs.hdr;
         if (hdr_out) *hdr_out = hd;
         if (hd.fail) {
-            if (std::getenv("PORESEG_DEBUG")) {        // which seams gave up (diagnostics)
+            if (ctx->debug) {                          // which seams gave up (option debug)
                 const size_t nt = static_cast<size_t>(ctx->counters[2]);
                 std::vector<int4> bm(nt), mt(nt);
                 std::vector<SpineJob> jb(nt);
@@ -619,6 +640,8 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     for (int k = 0; k < 3; ++k) ctx->counters[8 + k] = static_cast<int64_t>(hs.life[3 * k + 1]);              // window scans of the spine / bridge / subtree kernels
     ctx->counters[11] = static_cast<int64_t>(hs.stamp[0]);                                                     // near-tie decisions (seg_bs.hpp: bs_decide)
 #endif
+    ctx->counters[12] = static_cast<int64_t>(hs.lat_ctl[4]);                                                   // look-ahead helpers: chunk results published
+    ctx->counters[13] = static_cast<int64_t>(hs.lat_ctl[5]);                                                   // ... and taken by an owner instead of scanning
 #ifdef PS_STAMP
     {
         static const char *nm[12] = {"level", "sweep", "drain", "decide", "contend", "setup", "exact", "outside", "-", "-", "-", "-"};
@@ -677,6 +700,7 @@ LatHelp lat_help_of(ps_ctx *ctx, const DevCfg &cfg, SmallLayout *sm)
     h.prog = sm->lat_prog;
     h.res = ctx->lat_res.as<unsigned long long>();
     h.tag_base = ctx->lat_tag_base;
+    h.stay = ctx->lat_help == 2 ? 1 : 0;
     return h;
 }
 
@@ -902,9 +926,16 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
 #define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), k0_lds, fs, cfg,       \
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
-                                    reinterpret_cast<unsigned *>(&sm->status), const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp)))
-        if (ctx->k0_admit > 0 && !front) { gate_enter(ctx, ctx->device, ctx->k0_admit, ctx->ev_front[1]); ctx->gate_held = true; }
-        if (ctx->dbg_phase == 1 && reuse) { /* diagnostics: the previous call's digest */ }
+                                    reinterpret_cast<unsigned *>(&sm->status), k0_grp)
+        if (ctx->k0_admit > 0 && !front) { const int grc = gate_enter(ctx, ctx->device, ctx->k0_admit, ctx->ev_front[1], &ctx->gate_held); if (grc) return grc; }
+#ifdef PS_DIAG
+        const bool skip_k0 = ctx->dbg_phase == 1 && reuse;     // diagnostics: the previous call's digest
+        uint4 *const k0_grp = (ctx->dbg_k0_nogrp && reuse) ? nullptr : const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp));
+#else
+        const bool skip_k0 = false;
+        uint4 *const k0_grp = const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp));
+#endif
+        if (skip_k0) { }
         else if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
         else           { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
 #undef PS_K0
@@ -918,12 +949,14 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
         HIP_TRY(ctx, hipEventRecord(ctx->ev_front[1], fs));
         gate_publish(ctx, ctx->device);
     }
+#ifdef PS_DIAG
     if (ctx->dbg_phase == 2) {                           // diagnostics: K0 only
         if (front) front_lock.unlock();
         HIP_TRY(ctx, hipStreamSynchronize(fs));
         for (int e = 0; e <= n_ev; ++e) h_bounds_off[e] = 0;
         return PS_OK;
     }
+#endif
     if (front) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_front[1], fs));
         front_lock.unlock();
@@ -1025,7 +1058,7 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
             else if (reached) hopeless = true;
         }
         if (list.empty() || hopeless) break;
-        if (std::getenv("PORESEG_DEBUG")) fprintf(stderr, "[poreseg] second chance, round %d: %zu seams continued on the device\n", round + 1, list.size());
+        if (ctx->debug) fprintf(stderr, "[poreseg] second chance, round %d: %zu seams continued on the device\n", round + 1, list.size());
         const size_t n_ext = list.size();
         HIP_TRY(ctx, ctx->bridge_ext.reserve(static_cast<size_t>(EXT_SLOTS) * EXT_MAX * sizeof(int2)));
         HIP_TRY(ctx, ctx->ext_slot.reserve(nj * sizeof(int)));
@@ -1078,9 +1111,60 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
 }
 }  // namespace
 
+#ifdef PS_DIAG
+// libporeseg_diag.so only (make -C pypore_amd/csrc diag): a new context takes its settings from PORESEG_* variables, as every
+// build did until round 5.  The product library has no getenv: what a call returns depends on its arguments and on
+// ps_set_option / ps_set_tiling, never on the caller's environment.
+namespace {
+void diag_env(ps_ctx *ctx)
+{
+    if (const char *e = std::getenv("PORESEG_MODE")) ctx->mode = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_SPINE_NT")) ctx->spine_nt = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_TREE_NT")) ctx->tree_nt = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_REP_EVAL")) ctx->rep_eval = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_REP_STAGE")) ctx->rep_stage = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_GROUPS")) ctx->groups = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_TREE_PAR")) ctx->tree_par = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_K0_WAVES")) ctx->k0_waves = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_K0_SHARED")) ctx->k0_shared = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_DBG_PHASE")) ctx->dbg_phase = std::atoi(e);
+    if (const char *e = std::getenv("PORESEG_SCAN_LDS_PAD")) ctx->scan_lds_pad = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_K0_MAX")) ctx->k0_admit = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_NOISE_K")) ctx->noise_k = static_cast<float>(std::atof(e));
+    if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
+    if (const char *e = std::getenv("PORESEG_FILTER_FUSED")) ctx->filter_fused = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
+    if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_TREE_JPW")) ctx->tree_jobs_per_wave = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PORESEG_SLOTS_PCT")) ctx->slots_pct = std::max(1, std::min(100, std::atoi(e)));
+    if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
+    if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
+    if (const char *e = std::getenv("PORESEG_BRIDGE_EXT")) ctx->bridge_ext_on = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PORESEG_LAT_HELP")) ctx->lat_help = std::max(0, std::min(2, std::atoi(e)));
+    if (const char *e = std::getenv("PORESEG_BRIDGE_BUDGET")) ctx->bridge_budget = std::min(std::max(std::atoi(e), 1), static_cast<int>(BR_MAX));
+    if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
+    if (const char *e = std::getenv("PORESEG_DEBUG")) ctx->debug = std::atoi(e) != 0 || e[0] == 0;
+    if (const char *e = std::getenv("PORESEG_DBG_K0_NOGRP")) ctx->dbg_k0_nogrp = std::atoi(e) != 0;
+}
+}  // namespace
+#endif
+
 extern "C" {
 
-const char *ps_version(void) { return "poreseg 0.1 (gfx950)"; }
+const char *ps_version(void)
+{
+#ifdef PS_DIAG
+    return "poreseg 0.2 (gfx950) DIAGNOSTIC BUILD";
+#else
+    return "poreseg 0.2 (gfx950)";
+#endif
+}
 
 int ps_device_count(void)
 {
@@ -1110,37 +1194,9 @@ int ps_create(int device, void *stream, ps_ctx **out)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     if (ctx->small.reserve(sizeof(SmallLayout) + SMALL_TAIL) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     ctx->lds_max_samples = (LDS_BYTES_MAX - 1024 * 8 - 256) / (static_cast<int>(sizeof(lds_t)) + 1);   // samples + block sums
-    if (const char *e = std::getenv("PORESEG_MODE")) ctx->mode = std::atoi(e);
-    if (const char *e = std::getenv("PORESEG_SPINE_NT")) ctx->spine_nt = std::atoi(e);
-    if (const char *e = std::getenv("PORESEG_TREE_NT")) ctx->tree_nt = std::atoi(e);
-    if (const char *e = std::getenv("PORESEG_REP_EVAL")) ctx->rep_eval = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_REP_STAGE")) ctx->rep_stage = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_REP_SUM")) ctx->rep_sum = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_PRUNE")) ctx->prune = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_SCAN_BS")) ctx->scan_bs = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_GROUPS")) ctx->groups = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_TREE_PAR")) ctx->tree_par = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_K0_WAVES")) ctx->k0_waves = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_K0_SHARED")) ctx->k0_shared = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_DBG_PHASE")) ctx->dbg_phase = std::atoi(e);
-    if (const char *e = std::getenv("PORESEG_SCAN_LDS_PAD")) ctx->scan_lds_pad = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_K0_MAX")) ctx->k0_admit = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_NOISE_K")) ctx->noise_k = static_cast<float>(std::atof(e));
-    if (const char *e = std::getenv("PORESEG_WIDE_BS")) ctx->wide_bs = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_BRIDGE_SINGLE")) ctx->bridge_single = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_TREE_TAIL")) ctx->tree_tail_pct = std::max(0, std::min(100, std::atoi(e)));
-    if (const char *e = std::getenv("PORESEG_FILTER_FUSED")) ctx->filter_fused = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_UPLOAD")) ctx->upload_by_kernel = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_TIMING")) ctx->timing = std::max(0, std::min(2, std::atoi(e)));
-    if (const char *e = std::getenv("PORESEG_TREE_MW")) ctx->tree_mw = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_TREE_JPW")) ctx->tree_jobs_per_wave = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("PORESEG_SLOTS_PCT")) ctx->slots_pct = std::max(1, std::min(100, std::atoi(e)));
-    if (const char *e = std::getenv("PORESEG_STITCH")) ctx->stitch_host = std::string(e) == "host";
-    if (const char *e = std::getenv("PORESEG_TILE")) ctx->tile_len = std::atoll(e);
-    if (const char *e = std::getenv("PORESEG_BRIDGE_EXT")) ctx->bridge_ext_on = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_LAT_HELP")) ctx->lat_help = std::atoi(e) != 0;
-    if (const char *e = std::getenv("PORESEG_BRIDGE_BUDGET")) ctx->bridge_budget = std::min(std::max(std::atoi(e), 1), static_cast<int>(BR_MAX));
-    if (const char *e = std::getenv("PORESEG_HALO")) ctx->halo = std::atoll(e);
+#ifdef PS_DIAG
+    diag_env(ctx);                                      // libporeseg_diag.so: the PORESEG_* variables of the experiments (tools/)
+#endif
     *out = ctx;
     return PS_OK;
 }
@@ -1190,7 +1246,31 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
     else if (n == "k0_shared") ctx->k0_shared = value != 0;
     else if (n == "k0_admit" && value >= 0) ctx->k0_admit = static_cast<int>(value);
     else if (n == "bridge_ext" && (value == 0 || value == 1)) ctx->bridge_ext_on = static_cast<int>(value);
-    else if (n == "lat_help" && (value == 0 || value == 1)) ctx->lat_help = static_cast<int>(value);
+    // lat_help: 0 every seam walks alone, 1 idle workgroups of the look-ahead kernel help (they leave when nothing has been listed
+    // for ~0.1 ms), 2 as 1 but the helpers stay until every workgroup of the launch is through with its own seams -- for a test
+    // that must SEE the helpers work; only for a call that has the chip to itself (a helper then waits for nobody)
+    else if (n == "lat_help" && value >= 0 && value <= 2) ctx->lat_help = static_cast<int>(value);
+    // shared_device: the number of contexts that share this device (a pool of host threads, include/poreseg.h) -- one call that sets
+    // what engine.StreamPool set by hand until round 5: n <= 1 a lone context (one-shot K0, helpers on, no admission), n > 1
+    // persistent K0 at one wave per SIMD, no helpers, and for n > 3 at most three K0s in flight on the device
+    else if (n == "shared_device" && value >= 0 && value <= 4096) {
+        const bool sh = value > 1;
+        ctx->k0_waves = sh ? 1 : 0;
+        ctx->lat_help = sh ? 0 : 1;
+        ctx->k0_admit = value > 3 ? 3 : 0;
+    }
+    else if (n == "debug") ctx->debug = value != 0;
+    else if (n == "slots_pct" && value >= 1 && value <= 100) ctx->slots_pct = static_cast<int>(value);
+    else if (n == "tree_jobs_per_wave" && value >= 0 && value <= 1024) ctx->tree_jobs_per_wave = static_cast<int>(value);
+    else if (n == "noise_k_ppm" && value >= 0) ctx->noise_k = static_cast<float>(static_cast<double>(value) * 1.0e-6);
+#ifdef PS_DIAG
+    else if (n == "dbg_phase" && value >= 0 && value <= 2) ctx->dbg_phase = static_cast<int>(value);
+    else if (n == "dbg_k0_nogrp") ctx->dbg_k0_nogrp = value != 0;
+    else if (n == "scan_lds_pad" && value >= 0 && value <= 65536) ctx->scan_lds_pad = static_cast<int>(value);
+    else if (n == "rep_eval" && value >= 1) ctx->rep_eval = static_cast<int>(value);
+    else if (n == "rep_stage" && value >= 1) ctx->rep_stage = static_cast<int>(value);
+    else if (n == "rep_sum" && value >= 1) ctx->rep_sum = static_cast<int>(value);
+#endif
     else if (n == "bridge_budget" && value >= 1 && value <= BR_MAX) ctx->bridge_budget = static_cast<int>(value);
     else if (n == "wide_bs") { ctx->wide_bs = value != 0; ctx->wide_skip = 0; }
     else if (n == "bridge_single" && value >= 1) ctx->bridge_single = static_cast<int>(value);
@@ -1720,11 +1800,11 @@ int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counter
 {
     if (!ctx) return PS_ERR_ARG;
     for (int i = 0; i < n_ms && ms; ++i) ms[i] = i < 8 ? ctx->ms[i] : 0.0;
-    for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 12 ? ctx->counters[i] : 0;
+    for (int i = 0; i < n_counters && counters; ++i) counters[i] = i < 14 ? ctx->counters[i] : 0;
     return PS_OK;
 }
 
-// The context's twelve work counters where ps_get_timings copies them from: a host that looks at one of them after every
+// The context's fourteen work counters where ps_get_timings copies them from: a host that looks at one of them after every
 // call (the near-tie count, counters[11]) reads it in place instead of making a second call.
 const int64_t *ps_counters(const ps_ctx *ctx) { return ctx ? ctx->counters : nullptr; }
 

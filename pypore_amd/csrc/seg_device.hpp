@@ -55,13 +55,15 @@ constexpr int LAT_C = 2048;        // chunks per lattice (32 768 windows: 1.6e8 
 constexpr int LAT_TAGS = 4096;     // listings per call (tags are unique per context until the host clears the results: 24 bits)
 struct LatHelp {
     unsigned long long *ctl;       // [0] hint (bridge_kernel) [1] slots taken [2] tags taken [3] workgroups through with their own seams
+                                   // [4] chunk results published by helpers [5] published chunks an owner took instead of scanning (counters)
     unsigned long long *state;     // [LAT_D] lattice origin | tag << 32 | first helped chunk << 56 (one word: read and written whole)
     int *seam;                     // [LAT_D] the seam (tile) of the slot
     int *prog;                     // [LAT_D] 0: nothing to help with; else 1 + the chunk the owner is in (zeroed with the call's status block)
     unsigned long long *res;       // [LAT_D * LAT_C] tag << 40 | offset of the chunk's first hit << 32 | its split (0xffffffff: none)
     unsigned tag_base;             // first tag of this call
+    int stay;                      // 1 (option lat_help = 2): helpers do not leave on idle polls, only when every workgroup is through (tests)
 };
-constexpr LatHelp LAT_NONE = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+constexpr LatHelp LAT_NONE = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0};
 __device__ __forceinline__ unsigned long long lat_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int lat_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lat_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
     __shared__ int2 res[BR_LA];                        // per wave: (outcome, value)
     if ((*status & ST_WIDE_RANGE) != 0u) return;       // K0 refused the data: the host redoes the call
     // (the single-wave bridge kernel's hint, requested here so that nobody waits for it at the end: do idle workgroups stay to help?)
-    const bool lat_stay = !EXT && lat.res != nullptr && c.half > 0 && lat.ctl[0] != 0ull;
+    const bool lat_stay = !EXT && lat.res != nullptr && c.half > 0 && (lat.ctl[0] != 0ull || lat.stay != 0);
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     SharedT<64> &sh = shw[wave];
     unsigned bad = 0;
@@ -1531,6 +1533,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                             const long long last = pos >= 0 ? j + off : j + LAT_W - 1;          // the last window the result stands for
                             const long long ps_last = start + last * c.half;
                             if (ps_last < lim && ps_last <= start + c.maxw) {                   // (none of them ends the loop or forces a split)
+                                if (threadIdx.x == 0) atomicAdd(&lat.ctl[5], 1ull);               // (counter: a published chunk taken)
                                 if (pos >= 0) { kind = KIND_HIT; s = pos; break; }
                                 nw = LAT_W;
                                 continue;
@@ -1612,7 +1615,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                 // has been listed for a while (~0.1 ms): workgroups of this launch that have not started yet may be waiting for
                 // the very slots the helpers sit on -- a helper must never wait for them.
                 idle_polls = any_active ? 0 : idle_polls + 1;
-                if (!any_active && (all_through || idle_polls > 32)) break;
+                if (!any_active && (all_through || (idle_polls > 32 && !lat.stay))) break;
                 if (wall_clock64() - t_start > 5000000LL) break;              // (50 ms at 100 MHz: a guard, never the way out)
                 bool worked = false;
                 for (int sI = 0; sI < D; ++sI) {
@@ -1660,8 +1663,10 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                         __syncthreads();
                         if (first >= 0) { hit_off = rr * BR_LA + first; hit_pos = rv.y; break; }
                     }
-                    if (threadIdx.x == 0)
+                    if (threadIdx.x == 0) {
                         lat_st(slot_p, (static_cast<unsigned long long>(tag) << 40) | (static_cast<unsigned long long>(hit_off & 15) << 32) | static_cast<unsigned>(hit_pos));
+                        atomicAdd(&lat.ctl[4], 1ull);                                              // (counter: a chunk result published)
+                    }
                     worked = true;
                 }
                 if (!worked) __builtin_amdgcn_s_sleep(32);

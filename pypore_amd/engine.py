@@ -15,6 +15,60 @@ from . import _lib
 
 _contexts = {}
 
+# Options every new Context of this process gets (ps_set_option name -> value) and its tiling (ps_set_tiling).  EMPTY in
+# the product: neither this package nor libporeseg.so reads a PORESEG_* variable on its own (round 6; the one exception is
+# PORESEG_LIB / PORESEG_COMM_LIB, the path of the library to load).  tests/conftest.py and the scripts under tools/ fill
+# them from the environment through apply_env_defaults(), so that `PORESEG_MODE=2 pytest -m gpu` still runs the whole
+# suite in verify mode on the product library.
+DEFAULT_OPTIONS = {}
+DEFAULT_TILING = [0, 0]
+# options a StreamPool applies to its contexts on top of "shared_device" while it runs (experiments: tools/)
+POOL_OVERRIDES = {}
+
+_ENV_OPTIONS = {
+    "PORESEG_MODE": "mode", "PORESEG_SPINE_NT": "spine_nt", "PORESEG_TREE_NT": "tree_nt", "PORESEG_PRUNE": "prune",
+    "PORESEG_SCAN_BS": "scan_bs", "PORESEG_GROUPS": "groups", "PORESEG_TREE_PAR": "tree_par", "PORESEG_K0_WAVES": "k0_waves",
+    "PORESEG_K0_SHARED": "k0_shared", "PORESEG_K0_MAX": "k0_admit", "PORESEG_WIDE_BS": "wide_bs",
+    "PORESEG_BRIDGE_SINGLE": "bridge_single", "PORESEG_TREE_TAIL": "tree_tail_pct", "PORESEG_FILTER_FUSED": "filter_fused",
+    "PORESEG_UPLOAD": "upload_by_kernel", "PORESEG_TIMING": "timing", "PORESEG_TREE_MW": "tree_mw",
+    "PORESEG_TREE_JPW": "tree_jobs_per_wave", "PORESEG_SLOTS_PCT": "slots_pct", "PORESEG_BRIDGE_EXT": "bridge_ext",
+    "PORESEG_LAT_HELP": "lat_help", "PORESEG_BRIDGE_BUDGET": "bridge_budget", "PORESEG_DEBUG": "debug",
+    # libporeseg_diag.so only (PORESEG_LIB=.../libporeseg_diag.so): stale or partial results, never the product
+    "PORESEG_DBG_PHASE": "dbg_phase", "PORESEG_DBG_K0_NOGRP": "dbg_k0_nogrp", "PORESEG_SCAN_LDS_PAD": "scan_lds_pad",
+}
+
+
+def options_from_env(environ=None):
+    """(options, tiling, pool overrides) named by PORESEG_* variables -- for tests and tools, which call it explicitly."""
+    env = os.environ if environ is None else environ
+    opts = {}
+    for var, name in _ENV_OPTIONS.items():
+        if var in env and env[var] != "":
+            opts[name] = int(env[var])
+    if env.get("PORESEG_STITCH"):
+        opts["stitch_host"] = 1 if env["PORESEG_STITCH"] == "host" else 0
+    if "PORESEG_NOISE_K" in env:
+        opts["noise_k_ppm"] = int(round(float(env["PORESEG_NOISE_K"]) * 1e6))
+    tiling = [int(env.get("PORESEG_TILE", "0") or 0), int(env.get("PORESEG_HALO", "0") or 0)]
+    pool = {}
+    if "PORESEG_POOL_K0_WAVES" in env:
+        pool["k0_waves"] = int(env["PORESEG_POOL_K0_WAVES"])
+    if "PORESEG_POOL_K0_MAX" in env:
+        pool["k0_admit"] = int(env["PORESEG_POOL_K0_MAX"])
+    if env.get("PORESEG_POOL_SHARED", "0") == "1":
+        pool["k0_shared"] = 1
+    return opts, tiling, pool
+
+
+def apply_env_defaults(environ=None):
+    """Contexts created from now on start with the settings the PORESEG_* variables name (tests/conftest.py, tools/)."""
+    opts, tiling, pool = options_from_env(environ)
+    DEFAULT_OPTIONS.update(opts)
+    if tiling[0] or tiling[1]:
+        DEFAULT_TILING[:] = tiling
+    POOL_OVERRIDES.update(pool)
+    return opts, tiling, pool
+
 
 def _serialised(method):
     """The method runs under its Context's lock."""
@@ -40,6 +94,10 @@ class Context(object):
         self.handle = h
         self.L = L
         self.lock = threading.RLock()                   # one call at a time per ps_ctx (see engine.context)
+        if DEFAULT_TILING[0] or DEFAULT_TILING[1]:
+            self.set_tiling(*DEFAULT_TILING)
+        for name, value in DEFAULT_OPTIONS.items():
+            self.set_option(name, value)
 
     def close(self):
         if self.handle:
@@ -53,10 +111,13 @@ class Context(object):
             pass
 
     def set_tiling(self, tile_len=0, halo=0):
-        _lib.check(self.L.ps_set_tiling(self.handle, int(tile_len), int(halo)), self.handle)
+        with self.lock:
+            _lib.check(self.L.ps_set_tiling(self.handle, int(tile_len), int(halo)), self.handle)
 
     def set_option(self, name, value):
-        _lib.check(self.L.ps_set_option(self.handle, name.encode(), int(value)), self.handle)
+        """ps_set_option, under the context's lock: an option never changes in the middle of another thread's call."""
+        with self.lock:
+            _lib.check(self.L.ps_set_option(self.handle, name.encode(), int(value)), self.handle)
 
     def seq_ms(self):
         """Device time of the most recent segment call (HIP events, first upload .. last result copy), in ms: the
@@ -68,12 +129,13 @@ class Context(object):
 
     def timings(self):
         ms = (ctypes.c_double * 8)()
-        cnt = (ctypes.c_int64 * 12)()
-        _lib.check(self.L.ps_get_timings(self.handle, ms, 8, cnt, 12))
+        cnt = (ctypes.c_int64 * 14)()
+        _lib.check(self.L.ps_get_timings(self.handle, ms, 8, cnt, 14))
         return dict(spine_ms=ms[0], tree_ms=ms[1], gather_ms=ms[2], total_ms=ms[3], stitch_ms=ms[4], bridge_ms=ms[5], blocksum_ms=ms[6], seq_ms=ms[7],
                     windows=cnt[0], candidates=cnt[1], tiles=cnt[2], tree_jobs=cnt[3], repairs=cnt[4],
                     exact_rescans=cnt[5], full_exact_scans=cnt[6], wide_redo=cnt[7],
-                    windows_spine=cnt[8], windows_bridge=cnt[9], windows_tree=cnt[10], near_ties=cnt[11])
+                    windows_spine=cnt[8], windows_bridge=cnt[9], windows_tree=cnt[10], near_ties=cnt[11],
+                    helper_chunks_published=cnt[12], helper_chunks_taken=cnt[13])
 
     def near_ties(self):
         """Windows of the most recent segment call that were decided among fp64 contenders with a margin inside the
@@ -363,11 +425,15 @@ class StreamPool(object):
     contexts before the runtime starts (bench.py: 16).  Round 4, 1e8-sample trace: 4 / 8 / 16 contexts in flight deliver a
     batch every 0.216 / 0.202 / 0.189 ms."""
 
-    def __init__(self, device=None, streams=2):
+    def __init__(self, device=None, streams=2, overrides=None):
+        """overrides: ps_set_option name -> value applied to the pool's contexts while it runs, on top of "shared_device"
+        (default: engine.POOL_OVERRIDES, empty in the product)."""
         import queue
         import threading
         base = context(device)
         self.contexts = [base] + [Context(base.device) for _ in range(max(1, int(streams)) - 1)]
+        self.overrides = dict(POOL_OVERRIDES if overrides is None else overrides)
+        self._shared_now = {}                            # id(context) -> the "shared_device" value it was last given
         # persistent workers for contexts 1 .. T-1 (the caller's thread drives context 0): a run() costs a queue
         # hand-over per worker, not a thread start
         self._inbox = [queue.SimpleQueue() for _ in self.contexts]
@@ -408,74 +474,55 @@ class StreamPool(object):
             self._inbox[t].put(None)
         self._threads = []
 
-    @staticmethod
-    def _front_stream(cx, on):
-        if hasattr(cx, "set_option"):
-            cx.set_option("k0_shared", on)
+    # What a context that shares the chip wants (ps_set_option "shared_device" n, include/poreseg.h; measured in round 5):
+    #   * K0 as a persistent kernel at one wave per SIMD: beside the scan waves of other calls a K0 that takes every wave slot
+    #     it can get is in the way (sixteen in flight: 0.193 -> 0.170 ms per step); a lone call is faster with the one-shot K0;
+    #   * no look-ahead helpers: with sixteen calls in flight the other calls are the better use of an idle workgroup (a trace
+    #     without steps 1.2 -> 8.6 ms per step with them on); for a lone call they are worth 2 x on sparse traces;
+    #   * more than three contexts: at most three K0s in flight (K0 is bound by HBM; sixteen of them at once finish late together,
+    #     with every call's scan kernels behind them: 0.188 -> 0.175 ms per step).
+    # The front stream ("k0_shared") lost (0.26-0.30 ms per step) and is set by nothing; overrides can name it for the record.
+    def _configure(self, cx, n):
+        """context `cx` shares its device with n - 1 others (n <= 1: a lone context again)"""
+        if not hasattr(cx, "set_option") or self._shared_now.get(id(cx)) == n:
+            return
+        cx.set_option("shared_device", n)
+        if n > 1:
+            for name, value in self.overrides.items():
+                cx.set_option(name, value)
+        else:
+            if "k0_shared" in self.overrides:
+                cx.set_option("k0_shared", 0)
+            if _device_shared(getattr(cx, "device", None), cx):
+                cx.set_option("lat_help", 0)             # (other threads' contexts are alive on the device: see _note_live)
+        # (what the process was started with -- tests / tools through engine.DEFAULT_OPTIONS -- stays in force)
+        for name in ("k0_waves", "lat_help", "k0_admit"):
+            if name in DEFAULT_OPTIONS:
+                cx.set_option(name, DEFAULT_OPTIONS[name])
+        self._shared_now[id(cx)] = n
 
     def run(self, n_jobs, job, dynamic=False):
         """Runs job(ctx, k, t) for k = 0 .. n_jobs-1 and returns the results in job order.  Job k runs on context
-        t = k % T, or -- dynamic=True -- on whichever context is free next (jobs of unequal length)."""
+        t = k % T, or -- dynamic=True -- on whichever context is free next (jobs of unequal length).  While more than one
+        job is in flight the contexts are configured for a shared device; afterwards the caller's own context
+        (contexts[0], the one SpeedyStatSplit.parse uses on this thread) is a lone context again, whatever happened."""
         import itertools
         T = len(self.contexts)
         results = [None] * n_jobs
         errors = []
-        # Round 5: while the pool runs, the contexts queue their upload + K0 launches on the device's shared front stream
-        # (ps_set_option "k0_shared"): K0 is the one HBM-bound kernel of a call, and T of them at once only share the same
-        # bytes per second while every call's scan kernels wait -- in a row, call i's scans run under call i+1's K0.
-        # The caller's own context (contexts[0]) goes back to its private stream afterwards: a lone call saves the hand-over.
-        # (measured, round 5: the front stream LOSES -- 0.26-0.30 ms per step against 0.175 -- a lone K0 competes for wave slots with
-        #  the scan kernels of fifteen other calls and gets a sixteenth of what frees up; PORESEG_POOL_SHARED=1 keeps the experiment)
-        shared = T > 1 and n_jobs > 1 and os.environ.get("PORESEG_POOL_SHARED", "0") == "1"
-        if shared:
-            for cx in self.contexts:
-                self._front_stream(cx, 1)
-        # What does pay is a limit on the K0 kernels in flight: at most three calls of the pool stream their samples at a time
-        # ("k0_admit": a call waits for a permit before it queues K0 and returns it when K0's event has completed).  K0 is
-        # bound by HBM; sixteen of them at once finish late together, with every call's scan kernels behind them.
-        # 16 contexts, 100 steps: 0.188 -> 0.175 ms per step; the driver's 20 steps: 0.208 -> 0.197 (profiles/r05_experiments).
-        # ... and K0 as a persistent kernel at one wave per SIMD ("k0_waves"): beside the scan waves of other calls a K0 that takes
-        # every wave slot it can get is in the way (sixteen in flight: 0.193 -> 0.170 ms per step); a lone call is faster
-        # with the one-shot K0, so the caller's own context goes back to it afterwards
-        k0w = int(os.environ.get("PORESEG_POOL_K0_WAVES", "1")) if T > 1 and n_jobs > 1 else 0
-        if "PORESEG_K0_WAVES" in os.environ:
-            k0w = None                                   # (the environment decides: experiments)
-        if k0w is not None and k0w != getattr(self, "_k0w", 0):
-            for cx in self.contexts:
-                if hasattr(cx, "set_option"):
-                    cx.set_option("k0_waves", k0w)
-            self._k0w = k0w
-        elif k0w and hasattr(self.contexts[0], "set_option"):
-            self.contexts[0].set_option("k0_waves", k0w)
-        # The look-ahead kernel's helpers ("lat_help": idle workgroups scan ahead of a seam that walks a long stretch without
-        # splits) are for a call that has the chip to itself -- 2 x on sparse traces; with sixteen calls in flight the other
-        # calls are the better use of an idle workgroup (measured: a trace without steps 1.2 -> 8.6 ms per step with them on).
-        lh = 0 if T > 1 and n_jobs > 1 else 1
-        if "PORESEG_LAT_HELP" not in os.environ and lh != getattr(self, "_lat_help", 1):
-            for cx in self.contexts:
-                if hasattr(cx, "set_option"):
-                    cx.set_option("lat_help", lh)
-            self._lat_help = lh
-        admit = int(os.environ.get("PORESEG_POOL_K0_MAX", "3")) if T > 3 else 0
-        if admit != getattr(self, "_admit", 0):
-            for cx in self.contexts:
-                if hasattr(cx, "set_option"):
-                    cx.set_option("k0_admit", admit)
-            self._admit = admit
-        ticket = itertools.count() if dynamic else None
-        busy = [t for t in range(1, T) if t < n_jobs]
-        for t in busy:
-            self._inbox[t].put((n_jobs, job, results, errors, ticket))
-        self._share(0, n_jobs, job, results, errors, ticket)
-        for _ in busy:
-            self._done.get()
-        if shared:
-            self._front_stream(self.contexts[0], 0)
-        if getattr(self, "_k0w", 0) and hasattr(self.contexts[0], "set_option"):
-            self.contexts[0].set_option("k0_waves", 0)   # (set again for contexts[0] at the next run)
-        if not getattr(self, "_lat_help", 1) and hasattr(self.contexts[0], "set_option"):
-            self.contexts[0].set_option("lat_help", 1)   # (the caller's own context is a lone one again)
-            self._lat_help = 1                           # (... so the next run sets all of them again)
+        n_shared = T if (T > 1 and n_jobs > 1) else 1
+        try:
+            for cx in (self.contexts if n_shared > 1 else self.contexts[:1]):
+                self._configure(cx, n_shared)
+            ticket = itertools.count() if dynamic else None
+            busy = [t for t in range(1, T) if t < n_jobs]
+            for t in busy:
+                self._inbox[t].put((n_jobs, job, results, errors, ticket))
+            self._share(0, n_jobs, job, results, errors, ticket)
+            for _ in busy:
+                self._done.get()
+        finally:
+            self._configure(self.contexts[0], 1)         # (every option the run changed, k0_admit included)
         if errors:
             raise errors[0]
         return results
@@ -505,17 +552,44 @@ def context(device=None):
     device = int(device)
     if threading.current_thread() is threading.main_thread():
         with _contexts_lock:
-            if device not in _contexts:
+            fresh = device not in _contexts
+            if fresh:
                 _contexts[device] = Context(device)
-            return _contexts[device]
+            cx = _contexts[device]
+        if fresh:
+            _note_live(device, cx)
+        return cx
     mine = getattr(_thread_contexts, "by_device", None)
     if mine is None:
         mine = _thread_contexts.by_device = {}
     if device not in mine:
         mine[device] = Context(device)
-        if "PORESEG_LAT_HELP" not in os.environ and hasattr(mine[device], "set_option"):
-            mine[device].set_option("lat_help", 0)       # (a worker thread's context shares the chip with the others': no helpers)
+        _note_live(device, mine[device])
     return mine[device]
+
+
+_live = {}                                              # device -> weak set of the contexts engine.context() handed out
+
+
+def _device_shared(device, cx):
+    with _contexts_lock:
+        return any(c is not cx and getattr(c, "handle", None) for c in _live.get(device, ()))
+
+
+def _note_live(device, cx):
+    """The look-ahead kernel's helpers are for a call that has the chip to itself.  Whether a context is alone is a matter of
+    how many contexts are alive on its device -- not of which thread made it: a program that does all its work on ONE worker
+    thread (a notebook kernel, a server) keeps the helpers; once a second context appears on the device, all of them run
+    without (the sharing may end when a thread does; the helpers then stay off for the survivors, which is the safe side)."""
+    import weakref
+    with _contexts_lock:
+        live = _live.setdefault(device, weakref.WeakSet())
+        live.add(cx)
+        others = [c for c in live if c is not cx and getattr(c, "handle", None)]
+    if others and "lat_help" not in DEFAULT_OPTIONS:
+        for c in others + [cx]:
+            if hasattr(c, "set_option"):
+                c.set_option("lat_help", 0)
 
 
 # ---- host-side input normalisation -------------------------------------------------------------

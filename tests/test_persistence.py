@@ -1,5 +1,6 @@
 """JSON persistence of the results: Event / File to_dict, to_json, from_json, to_meta, from_segments
-(DataTypes.py:480-545, :683-796).  Host-side only; the segmentation results are put in by hand."""
+(DataTypes.py:480-545, :683-796).  The first tests are host-side only (the segmentation results are put in by hand); the
+last one (-m gpu) sends what the DEVICE produced through to_json -> from_json -> MemoryParse."""
 import json
 import os
 
@@ -51,7 +52,12 @@ def test_file_json_round_trip_with_the_abf_at_hand(tmp_path):
             assert (a.start, a.end, a.duration) == (b.start, b.end, b.duration)
             np.testing.assert_array_equal(a.current, b.current)
     # reading the file written to disk gives the same thing as the string
-    assert File.from_json(os.path.join(str(tmp_path), "run1.json")).filename == f.filename or True
+    on_disk = json.load(open(os.path.join(str(tmp_path), "run1.json")))
+    assert on_disk == json.loads(js)
+    on_disk["filename"] = path[:-4]
+    json.dump(on_disk, open(os.path.join(str(tmp_path), "run1b.json"), "w"))
+    h = File.from_json(os.path.join(str(tmp_path), "run1b.json"))           # a *.json path is read from disk (:745-747)
+    assert h.filename == f.filename and h.n == 2 and [ev.n for ev in h.events] == [3, 2]
 
 
 def test_file_json_round_trip_without_the_abf_gives_meta_objects(tmp_path):
@@ -125,3 +131,105 @@ def test_reference_readme_example_loads_and_round_trips():
         else:
             assert a == b, (path, a, b)
     contained(ref, out)
+
+
+@pytest.mark.gpu
+def test_device_results_round_trip_through_json_and_replay_with_memoryparse(tmp_path):
+    """SURVEY 8 f-4 on what the device produced (VERDICT r5 next #3a): File.parse + File.parse_events on a synthetic .abf --
+    detection and segmentation on the GPU, filtered currents still PARKED on the device (grid.Deferred) when to_json asks for
+    the statistics -- -> to_json -> File.from_json with the .abf at hand (views of the current again, filtered events filtered
+    again: DataTypes.py:753-790) and without it (Meta objects from the stored numbers) -> replay of the stored split points
+    with MemoryParse (parsers.py:110-122, as File.from_database does: DataTypes.py:839-846): identical events, boundaries and
+    means at every stage."""
+    from pypore_amd.core import raw_current
+    from pypore_amd.grid import Deferred
+    from pypore_amd.parsers import MemoryParse
+    counts, _ = synth.file_trace_counts(1_600_000, 40)
+    path = os.path.join(str(tmp_path), "run0.abf")
+    abf.write_abf(path, counts.astype(np.int16))
+    seg_kw = dict(prior_segments_per_second=10, cutoff_freq=2000.)
+
+    def analysed(filter_params):
+        f = File(filename=path)
+        f.parse(lambda_event_parser(threshold=90))
+        f.parse_events(SpeedyStatSplit(**seg_kw), filter_params=filter_params)
+        return f
+
+    for filter_params in ((1, 2000), None):
+        f = analysed(filter_params)
+        rate = f.second
+        assert f.n >= 2 and all(ev.n > 1 for ev in f.events)
+        if filter_params is not None:
+            # the case the review names: currents that have not left the device when the JSON is written
+            parked = [isinstance(raw_current(ev), Deferred) and raw_current(ev).tensor is not None and raw_current(ev).tensor.is_cuda
+                      for ev in f.events]
+            assert all(parked), parked
+        js = f.to_json(os.path.join(str(tmp_path), "run0.json"))
+        d = json.loads(js)
+        assert d["n"] == f.n and [len(e["segments"]) for e in d["events"]] == [ev.n for ev in f.events]
+        assert all(e["filtered"] is (filter_params is not None) for e in d["events"])
+        assert d["events"][0]["state_parser"]["name"] == "SpeedyStatSplit" and d["events"][0]["state_parser"]["cutoff_freq"] == 2000.0
+        # the stored statistics are those of the (filtered) float64 current the user sees
+        for ev, ej in zip(f.events, d["events"]):
+            cur = np.asarray(ev.current)
+            for sg, sj in zip(ev.segments, ej["segments"]):
+                i, j = int(round(sg.start * rate)), int(round(sg.end * rate))
+                assert sj["mean"] == pytest.approx(float(np.mean(cur[i:j])), rel=1e-9, abs=1e-9)
+                assert sj["std"] == pytest.approx(float(np.std(cur[i:j])), rel=1e-6, abs=1e-9)
+                assert (sj["start"], sj["end"], sj["duration"]) == (sg.start, sg.end, sg.duration)
+        # ---- with the .abf at hand: Event / Segment objects on views of the file's current
+        d_abf = dict(d, filename=path[:-4])
+        g = File.from_json(json.dumps(d_abf))
+        assert type(g) is File and g.n == f.n and g.event_parser.threshold == 90
+        for ev_f, ev_g in zip(f.events, g.events):
+            assert type(ev_g) is Event and bool(ev_g.filtered) is (filter_params is not None)
+            a, b = int(ev_f.start * rate), int(ev_f.end * rate)               # (the reference's own truncation, :765)
+            assert (ev_g.start, ev_g.end) == (a / rate, b / rate) and len(ev_g.current) == b - a
+            if filter_params is None:
+                np.testing.assert_array_equal(np.asarray(ev_g.current), np.asarray(f.current[a:b]))
+            else:
+                assert (ev_g.filter_order, ev_g.filter_cutoff) == (1, 2000)
+                if (a, b) == (int(round(ev_f.start * rate)), int(round(ev_f.end * rate))):
+                    np.testing.assert_allclose(np.asarray(ev_g.current), np.asarray(ev_f.current), rtol=0, atol=1e-9)   # filtered again: same filter, same samples
+            assert ev_g.n == ev_f.n and type(ev_g.state_parser) is SpeedyStatSplit and ev_g.state_parser.cutoff_freq == 2000.0
+            for sf, sg in zip(ev_f.segments, ev_g.segments):
+                assert type(sg) is Segment and sg.event is ev_g
+                assert (sg.start, sg.end, sg.duration) == (sf.start, sf.end, sf.duration)
+                i, j = int(sf.start * rate), int(sf.end * rate)
+                np.testing.assert_array_equal(np.asarray(sg.current), np.asarray(ev_g.current[i:j]))
+                if (i, j) == (int(round(sf.start * rate)), int(round(sf.end * rate))) and len(ev_g.current) == len(ev_f.current):
+                    assert sg.mean == pytest.approx(float(sf.mean), rel=1e-9, abs=1e-9)
+        # ---- without it: Meta objects carrying the stored numbers
+        h = File.from_json(json.dumps(dict(d, filename="/nonexistent/run0")))
+        assert all(isinstance(ev, MetaEvent) for ev in h.events) and h.n == f.n
+        for ev_f, ev_h in zip(f.events, h.events):
+            assert [s.mean for s in ev_h.segments] == pytest.approx([float(s.mean) for s in ev_f.segments], rel=1e-12)
+            assert [s.start for s in ev_h.segments] == [s.start for s in ev_f.segments]
+            assert ev_h.mean == pytest.approx(float(ev_f.mean), rel=1e-12) and ev_h.n == ev_f.n
+        # ---- MemoryParse: the stored split points replayed on a fresh File (File.from_database's route)
+        r = File(filename=path)
+        ev_starts = [int(round(e["start"] * rate)) for e in d["events"]]
+        ev_ends = [int(round(e["end"] * rate)) for e in d["events"]]
+        r.parse(MemoryParse(ev_starts, ev_ends))
+        assert [(int(round(ev.start * rate)), int(round((ev.start + ev.duration) * rate))) for ev in r.events] == list(zip(ev_starts, ev_ends))
+        for ev_r, ev_f, ej in zip(r.events, f.events, d["events"]):
+            np.testing.assert_array_equal(np.asarray(ev_r.current), np.asarray(f.current[int(round(ev_f.start * rate)):int(round(ev_f.end * rate))]))
+            if filter_params is not None:
+                ev_r.filter(*filter_params)
+                np.testing.assert_allclose(np.asarray(ev_r.current), np.asarray(ev_f.current), rtol=0, atol=1e-9)
+            ev_r.filtered = False                       # (the replay cuts the current it is given: no re-quantisation, no device)
+            ev_r.parse(MemoryParse([int(round(sj["start"] * rate)) for sj in ej["segments"]],
+                                   [int(round(sj["end"] * rate)) for sj in ej["segments"]]))
+            assert [s.start for s in ev_r.segments] == pytest.approx([s.start for s in ev_f.segments], abs=1e-12)
+            assert [s.duration for s in ev_r.segments] == pytest.approx([s.duration for s in ev_f.segments], abs=1e-12)
+            assert [s.n for s in ev_r.segments] == [s.n for s in ev_f.segments]
+            assert [float(s.mean) for s in ev_r.segments] == pytest.approx([float(s.mean) for s in ev_f.segments], rel=1e-9, abs=1e-9)
+            assert [float(s.std) for s in ev_r.segments] == pytest.approx([float(s.std) for s in ev_f.segments], rel=1e-6, abs=1e-9)
+        # the device run itself is the oracle's (unfiltered route: the counts are exact)
+        if filter_params is None:
+            import oracle
+            x = np.asarray(f.current, dtype=np.float64)
+            for ev in f.events:
+                a, b = int(round(ev.start * rate)), int(round(ev.end * rate))
+                ref = oracle.parse(x[a:b], **seg_kw)
+                np.testing.assert_array_equal([int(round(s.start * rate)) for s in ev.segments[1:]], ref)

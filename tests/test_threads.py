@@ -121,9 +121,11 @@ def test_pool_options_do_not_change_a_result(options):
 
 
 def test_pool_sets_the_options_of_shared_contexts_and_gives_the_callers_context_back(monkeypatch):
-    """engine.StreamPool.run: while several contexts are in flight they run K0 persistent, with a limit on the K0s in flight
-    and WITHOUT the look-ahead kernel's helpers (idle workgroups belong to the other calls then); afterwards the caller's own
-    context -- contexts[0], the one SpeedyStatSplit.parse uses -- is a lone context again.  (No GPU: recording contexts.)"""
+    """engine.StreamPool.run: while several contexts are in flight they are configured for a shared device (ONE option,
+    "shared_device" n: persistent K0, a limit on the K0s in flight, no look-ahead helpers -- include/poreseg.h); afterwards the
+    caller's own context -- contexts[0], the one SpeedyStatSplit.parse uses -- is a lone context again, also when a job
+    raised.  Options go through the context's lock.  (No GPU: recording contexts.)"""
+    import threading
     from pypore_amd import engine
 
     class Rec(object):
@@ -131,25 +133,99 @@ def test_pool_sets_the_options_of_shared_contexts_and_gives_the_callers_context_
             self.device = device
             self.opts = {}
             self.log = []
+            self.lock = threading.RLock()
+            self.handle = 1
 
         def set_option(self, name, value):
             self.opts[name] = value
             self.log.append((name, value))
     monkeypatch.setattr(engine, "Context", Rec)
     monkeypatch.setattr(engine, "_contexts", {})
-    for k in ("PORESEG_LAT_HELP", "PORESEG_K0_WAVES", "PORESEG_POOL_K0_WAVES", "PORESEG_POOL_K0_MAX", "PORESEG_POOL_SHARED"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(engine, "_live", {})
+    monkeypatch.setattr(engine, "DEFAULT_OPTIONS", {})
+    monkeypatch.setattr(engine, "POOL_OVERRIDES", {})
     pool = engine.StreamPool(0, 4)
     during = []
     out = pool.run(8, lambda cx, k, t: during.append((t, dict(cx.opts))) or k)
     assert out == list(range(8))
     for t, o in during:
-        assert o.get("lat_help") == 0 and o.get("k0_waves") == 1 and o.get("k0_admit") == 3, (t, o)
-    assert pool.contexts[0].opts["lat_help"] == 1 and pool.contexts[0].opts["k0_waves"] == 0      # the caller's context: lone again
-    assert all(c.opts["lat_help"] == 0 for c in pool.contexts[1:])
+        assert o.get("shared_device") == 4, (t, o)
+    assert pool.contexts[0].opts["shared_device"] == 1                                            # the caller's context: lone again
+    assert all(c.opts["shared_device"] == 4 for c in pool.contexts[1:])
     during.clear()
     pool.run(8, lambda cx, k, t: during.append((t, dict(cx.opts))) or k)                          # a second run sets context 0 again
-    assert all(o.get("lat_help") == 0 and o.get("k0_waves") == 1 for _, o in during)
+    assert all(o.get("shared_device") == 4 for _, o in during)
     pool.run(1, lambda cx, k, t: during.append((t, dict(cx.opts))) or k)                          # one job: nothing shared
-    assert during[-1][1]["lat_help"] == 1 and during[-1][1]["k0_waves"] == 0
+    assert during[-1][1]["shared_device"] == 1
+    # a job that raises: the caller's context is still given back
+    def boom(cx, k, t):
+        raise ValueError("job %d" % k)
+    with pytest.raises(ValueError):
+        pool.run(8, boom)
+    assert pool.contexts[0].opts["shared_device"] == 1
+    # experiments name further options (engine.POOL_OVERRIDES / the constructor): applied on top, only while shared
+    pool2 = engine.StreamPool(0, 4, overrides={"k0_admit": 2, "k0_waves": 2})
+    seen = []
+    pool2.run(8, lambda cx, k, t: seen.append(dict(cx.opts)) or k)
+    assert all(o["k0_admit"] == 2 and o["k0_waves"] == 2 and o["shared_device"] == 4 for o in seen)
     pool.close()
+    pool2.close()
+
+
+def test_helpers_follow_the_number_of_live_contexts_not_the_thread(monkeypatch):
+    """engine.context(): a program that does all its work on ONE worker thread keeps the look-ahead helpers (ADVICE r5);
+    once a second context is alive on the device all of them run without.  (No GPU: recording contexts.)"""
+    import threading
+    from pypore_amd import engine
+
+    class Rec(object):
+        def __init__(self, device):
+            self.device, self.opts, self.handle, self.lock = device, {}, 1, threading.RLock()
+
+        def set_option(self, name, value):
+            self.opts[name] = value
+    monkeypatch.setattr(engine, "Context", Rec)
+    monkeypatch.setattr(engine, "_contexts", {})
+    monkeypatch.setattr(engine, "_live", {})
+    monkeypatch.setattr(engine, "DEFAULT_OPTIONS", {})
+    got = {}
+
+    def work(name):
+        got[name] = engine.context(0)
+    th = threading.Thread(target=work, args=("a",))
+    th.start(); th.join()
+    assert "lat_help" not in got["a"].opts                                                        # alone on the device: library default (helpers on)
+    th = threading.Thread(target=work, args=("b",))
+    th.start(); th.join()
+    assert got["a"].opts.get("lat_help") == 0 and got["b"].opts.get("lat_help") == 0
+    main = engine.context(0)
+    assert main.opts.get("lat_help") == 0
+
+
+def test_env_variables_reach_a_context_only_through_apply_env_defaults(monkeypatch):
+    """The package reads no PORESEG_* variable on its own (round 6): a variable in the environment changes nothing until a
+    test / tool calls engine.apply_env_defaults()."""
+    import threading
+    from pypore_amd import engine
+
+    class Rec(object):
+        def __init__(self, device):
+            self.device, self.opts, self.handle, self.lock, self.tiling = device, {}, 1, threading.RLock(), None
+
+        def set_option(self, name, value):
+            self.opts[name] = value
+    monkeypatch.setenv("PORESEG_MODE", "2")
+    monkeypatch.setenv("PORESEG_STITCH", "host")
+    monkeypatch.setenv("PORESEG_TILE", "50000")
+    monkeypatch.setattr(engine, "DEFAULT_OPTIONS", {})
+    monkeypatch.setattr(engine, "DEFAULT_TILING", [0, 0])
+    monkeypatch.setattr(engine, "POOL_OVERRIDES", {})
+    opts, tiling, pool = engine.options_from_env()
+    assert opts == {"mode": 2, "stitch_host": 1} and tiling == [50000, 0] and pool == {}
+    assert engine.DEFAULT_OPTIONS == {} and engine.DEFAULT_TILING == [0, 0]
+    engine.apply_env_defaults()
+    assert engine.DEFAULT_OPTIONS == {"mode": 2, "stitch_host": 1} and engine.DEFAULT_TILING == [50000, 0]
+    src = open(engine.__file__).read() + open(engine._lib.__file__).read()
+    import re
+    reads = set(re.findall(r"environ(?:\.get)?[\[(]\s*\"(PORESEG_[A-Z0-9_]+)\"", src))
+    assert reads <= {"PORESEG_LIB"}, reads                                                       # (everything else goes through options_from_env's table)

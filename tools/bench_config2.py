@@ -4,6 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pypore_amd import _lib, engine, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 ctx = engine.context(0)
 n_ev, ln = 1024, 50000
 ends = []; lv = []

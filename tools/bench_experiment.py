@@ -10,6 +10,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from pypore_amd import abf, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 from pypore_amd.DataTypes import Experiment
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000

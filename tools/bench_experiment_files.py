@@ -5,6 +5,8 @@ import gc, os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pypore_amd import abf, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 from pypore_amd.DataTypes import Experiment
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 m = int(float(sys.argv[2])) if len(sys.argv) > 2 else 50_000_000

@@ -2,6 +2,8 @@ import sys, time, json, numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, ".")
 import torch
 from pypore_amd import synth, engine, _lib
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 ctx = engine.context(0)
 import os
 if os.environ.get('TILE'): ctx.set_tiling(int(os.environ['TILE']), 0)

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np, torch
 from pypore_amd import _lib, engine, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 160
 n = 100_000_000

@@ -2,6 +2,8 @@ import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from pypore_amd import _lib, engine, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 ctx = engine.context(0)
 n_ev, ln = int(sys.argv[1]), int(sys.argv[2])
 params = _lib.split_params(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import oracle
 from pypore_amd import _lib, engine, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 ctx = engine.context(0)
 rng = np.random.RandomState(4242)
 n_ev = int(sys.argv[1]) if len(sys.argv) > 1 else 4000

@@ -2,6 +2,8 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from pypore_amd import _lib, engine, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 n, seed = 100_000_000, 2024
 params = _lib.split_params(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
 pool = engine.StreamPool(0, 4)

@@ -3,6 +3,8 @@ import os, sys, time, tempfile, cProfile, pstats
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pypore_amd import abf, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 from pypore_amd.DataTypes import Experiment, File
 from pypore_amd.parsers import SpeedyStatSplit, lambda_event_parser
 

@@ -6,6 +6,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pypore_amd import _lib, engine, synth, pipeline
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 n = 100_000_000
 ctx = engine.context(0)
 ends, lv, _ = synth.file_trace_table(n, 7)

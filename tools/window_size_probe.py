@@ -6,6 +6,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pypore_amd import _lib, engine, synth
+from pypore_amd import engine as _ps_engine
+_ps_engine.apply_env_defaults()           # tools take their settings from PORESEG_* variables; the product reads none
 ctx = engine.context(0); n = 100_000_000
 d = synth.dwell_table(1, n, 1000, 20000); lv = synth.LEVEL_COUNTS[np.arange(len(d)) % 5].astype(np.int32)
 t = ctx.synth_trace(n, 1, np.cumsum(d), lv, dtype=torch.float32); off = np.array([0, n], dtype=np.int64)
