@@ -106,6 +106,8 @@ struct ps_ctx {
     bool gate_held = false;
     bool defer_sync = false;  // (internal) ps_filter_requantise_batch: the filter entry only queues its kernels -- no status clear, copy, sync
     int scan_lds_pad = 0;     // diagnostics (libporeseg_diag.so only: option scan_lds_pad): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
+    int k0_unaligned = 1;     // K0's fast route loads 16 bytes from sample-aligned addresses: probed once per device at ps_create (k0_unaligned_probe);
+                              // option k0_unaligned 0 restores the 16-byte condition of rounds 1-4 (tests)
     int debug = 0;            // option debug: the library says on stderr which seams gave up, which occupancy it found (prints only; results unchanged)
 #ifdef PS_DIAG
     // Diagnostics that return WRONG or stale results exist in libporeseg_diag.so only (make -C pypore_amd/csrc diag): the product
@@ -304,6 +306,7 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->prune = ctx->prune;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
     c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr; c->grp = nullptr; c->bs_wide = 0;
+    c->k0_unaligned = ctx->k0_unaligned;
     c->dbg = ctx->small.as<SmallLayout>()->stamp;
     c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
@@ -1111,6 +1114,36 @@ int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const in
 }
 }  // namespace
 
+namespace {
+// Do 16-byte global loads from 2- and 4-byte-aligned addresses return the right bytes on this device?  (They do on gfx950 --
+// tools/probes/unaligned_probe.hip, at 92 % of the aligned rate -- but the headline kernel must not rest on a stand-alone
+// probe run once on one box)  Once per device and process; -1 not probed yet, 0 no, 1 yes.
+std::mutex g_probe_mu;
+int g_unaligned_ok[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int k0_unaligned_probe(int device, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    int &ok = g_unaligned_ok[device & 15];
+    if (ok >= 0) return ok;
+    ok = 0;
+    unsigned char h[128];
+    for (int i = 0; i < 128; ++i) h[i] = static_cast<unsigned char>(37 * i + 11);
+    unsigned char *d = nullptr;
+    unsigned *bad = nullptr;
+    if (hipMalloc(&d, 256) != hipSuccess || hipMalloc(&bad, sizeof(unsigned)) != hipSuccess) { if (d) (void)hipFree(d); (void)hipGetLastError(); return ok; }
+    unsigned hb = 1;
+    if (hipMemcpyAsync(d, h, 128, hipMemcpyHostToDevice, st) == hipSuccess && hipMemsetAsync(bad, 0, sizeof(unsigned), st) == hipSuccess) {
+        hipLaunchKernelGGL(k0_unaligned_probe_kernel<2>, dim3(1), dim3(64), 0, st, d, 16, bad);     // int16: offsets 0, 2, .. 30 bytes
+        hipLaunchKernelGGL(k0_unaligned_probe_kernel<4>, dim3(1), dim3(64), 0, st, d, 16, bad);     // fp32: offsets 0, 4, .. 60 bytes
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&hb, bad, sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipStreamSynchronize(st) == hipSuccess)
+            ok = hb == 0 ? 1 : 0;
+    }
+    (void)hipFree(d); (void)hipFree(bad); (void)hipGetLastError();
+    return ok;
+}
+}  // namespace
+
 #ifdef PS_DIAG
 // libporeseg_diag.so only (make -C pypore_amd/csrc diag): a new context takes its settings from PORESEG_* variables, as every
 // build did until round 5.  The product library has no getenv: what a call returns depends on its arguments and on
@@ -1194,6 +1227,7 @@ int ps_create(int device, void *stream, ps_ctx **out)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     if (ctx->small.reserve(sizeof(SmallLayout) + SMALL_TAIL) != hipSuccess) { delete ctx; return PS_ERR_HIP; }
     ctx->lds_max_samples = (LDS_BYTES_MAX - 1024 * 8 - 256) / (static_cast<int>(sizeof(lds_t)) + 1);   // samples + block sums
+    ctx->k0_unaligned = k0_unaligned_probe(device, ctx->stream);
 #ifdef PS_DIAG
     diag_env(ctx);                                      // libporeseg_diag.so: the PORESEG_* variables of the experiments (tools/)
 #endif
@@ -1260,6 +1294,8 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
         ctx->k0_admit = value > 3 ? 3 : 0;
     }
     else if (n == "debug") ctx->debug = value != 0;
+    // k0_unaligned 0: K0's fast route from 16-byte-aligned addresses only (what a device whose probe fails gets); 1: whatever the probe said
+    else if (n == "k0_unaligned") ctx->k0_unaligned = value != 0 ? k0_unaligned_probe(ctx->device, ctx->stream) : 0;
     else if (n == "slots_pct" && value >= 1 && value <= 100) ctx->slots_pct = static_cast<int>(value);
     else if (n == "tree_jobs_per_wave" && value >= 0 && value <= 1024) ctx->tree_jobs_per_wave = static_cast<int>(value);
     else if (n == "noise_k_ppm" && value >= 0) ctx->noise_k = static_cast<float>(static_cast<double>(value) * 1.0e-6);

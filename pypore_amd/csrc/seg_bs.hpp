@@ -465,6 +465,31 @@ __device__ __attribute__((noinline)) K0Gen<DT> k0_block_general(BsCold k, const 
 // 82-register waves per SIMD were 54 % of all wave residency while issuing 12 % of the time).  A launch that covers every wave
 // block with a wave of its own (gridDim.x * K0_WAVES >= wave blocks) degenerates to the one-shot kernel of rounds 3 and 4.
 struct K0Src { int e; int fast; long long b_first; int64_t base; };
+// 16 bytes of samples from an address that is only SAMPLE-aligned (2 bytes for int16, 4 for fp32): the vector type says so, so
+// that the compiler may not assume 16-byte alignment (dereferencing an int4 * there is undefined behaviour) -- with
+// the target's unaligned access mode it is still ONE global_load_dwordx4 (checked in the ISA: tools/kernel_resources.py counts
+// them), and ps_create probes once per device that such a load returns the right bytes (poreseg.hip: k0_unaligned_probe).
+template <int A> struct K0Vec;
+template <> struct K0Vec<2> { typedef int type __attribute__((ext_vector_type(4), aligned(2))); };
+template <> struct K0Vec<4> { typedef int type __attribute__((ext_vector_type(4), aligned(4))); };
+template <int A> __device__ __forceinline__ int4 k0_load16(const char *p)
+{
+    const typename K0Vec<A>::type v = *reinterpret_cast<const typename K0Vec<A>::type *>(p);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+// the probe: 16-byte loads at every sample offset 0 .. 15 of a small pattern, against the same bytes fetched one by one
+template <int A>
+__global__ void k0_unaligned_probe_kernel(const unsigned char *buf, int n_off, unsigned *bad)
+{
+    const int o = threadIdx.x;
+    if (o >= n_off) return;
+    const int4 v = k0_load16<A>(reinterpret_cast<const char *>(buf) + o * A);
+    const unsigned char *q = buf + o * A;
+    unsigned w[4];
+    for (int k = 0; k < 4; ++k) w[k] = q[4 * k] | (q[4 * k + 1] << 8) | (q[4 * k + 2] << 16) | (static_cast<unsigned>(q[4 * k + 3]) << 24);
+    if (static_cast<unsigned>(v.x) != w[0] || static_cast<unsigned>(v.y) != w[1] || static_cast<unsigned>(v.z) != w[2] || static_cast<unsigned>(v.w) != w[3])
+        atomicOr(bad, 1u);
+}
 
 template <int DT>
 __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(DevCfg c, const int64_t *__restrict__ ev_start, const int64_t *__restrict__ ev_len,
@@ -508,6 +533,8 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
         //  this part at 92 % of the aligned rate -- tools/probes/unaligned_probe.hip -- and the events that a detector cuts
         //  out of an int16 file trace start at any sample: their blocks all took the general route, K0 146 us per 1e8 samples)
         s.fast = wb0 + K0_WB <= ev_boff[lo + 1] && 8 * (s.b_first + K0_WB) <= len_f && nb_total > 0;
+        // (a device whose probe failed -- none known -- takes the fast route from 16-byte-aligned addresses only, as until round 4)
+        if (!c.k0_unaligned && ((reinterpret_cast<uintptr_t>(c.samples) + static_cast<uintptr_t>((s.base + 8 * s.b_first) * ES)) & 15u) != 0) s.fast = 0;
         return s;
     };
     // the loads of a wave block: issued unconditionally -- a wave block of the general route fetches (and ignores) the first
@@ -523,7 +550,7 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
 #pragma unroll
         for (int k = 0; k < K0_BPT; ++k)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) raw[k][v] = *reinterpret_cast<const int4 *>(pb + (lo + static_cast<unsigned>(k * 64 * 8 * ES + 16 * v)));
+            for (int v = 0; v < NV; ++v) raw[k][v] = k0_load16<ES>(pb + (lo + static_cast<unsigned>(k * 64 * 8 * ES + 16 * v)));
     };
     auto process = [&](auto fast_tag, const long long wb0, const K0Src &src, const int4 (&raw)[K0_BPT][NV], const raw_t first) {
     constexpr bool FAST = decltype(fast_tag)::value;

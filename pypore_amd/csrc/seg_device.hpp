@@ -101,6 +101,7 @@ struct DevCfg {
     const void *grp;        // per group of 32 blocks (256 samples; narrow digest): the digest entry of its first block + (D1, D2) as fp32,
                             // the bridge amplitudes of the group bound (seg_bs.hpp); nullptr: no coarse pass
     int bs_wide;            // (host side) the digest is the 64-bit one: kernels compiled for DT | DT_WIDE
+    int k0_unaligned;       // 1: K0's fast route may load 16 bytes from sample-aligned addresses (probed at ps_create), 0: 16-byte-aligned only
     unsigned long long *dbg;  // diagnostics scratch (12 words) or nullptr
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };

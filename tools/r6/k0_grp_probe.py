@@ -26,7 +26,7 @@ ev_off = np.array([0, n], dtype=np.int64)
 outs = [torch.empty(n // 100 + 1, dtype=torch.int32, device="cuda") for _ in range(T)]
 job = lambda cx, k, t: cx.segment_batch(traces[t], ev_off, params, synth.QUANTUM, want_stats=False, out=outs[t])[0].numel()
 import gc; gc.collect(); gc.freeze()
-ref = pool.run(4 * T, job)
+ref = pool.run(4 * T, job)[-T:]                       # boundaries per context (job k runs on context k % T)
 
 
 def measure(flag, steps):
@@ -42,7 +42,7 @@ res20 = {0: [], 1: []}
 for p in range(PAIRS):
     for flag in ((0, 1) if p % 2 == 0 else (1, 0)):
         ms, r = measure(flag, K)
-        assert r[-T:] == ref[-T:], "boundary counts changed"
+        assert all(r[k] == ref[k % T] for k in range(len(r))), "boundary counts changed"
         res[flag].append(ms)
         ms20, _ = measure(flag, 20)
         res20[flag].append(ms20)
