@@ -253,6 +253,53 @@ def selftest_dist(args):
     loads = [sum(unit_len[f] for f in sh) for sh in shards]
     ok["files_shard_covers_every_unit_once"] = sorted(f for sh in shards for f in sh) == list(range(n_units))
     ok["files_shard_balanced"] = max(loads) <= 1.1 * (sum(loads) / world) + max(unit_len)
+    # dist.BoundaryGather with the C ABI's gather (backend "library", ps_gather_bounds: every rank sends `capacity` int32,
+    # slot r of the result at r * capacity) against the torch backend, batch by batch: the header, the in-place send of a
+    # buffer that already holds header + payload, a contribution that does not fit on ONE rank (every rank sees it in the
+    # gathered counts and takes the two-collective fall-back together), an empty contribution.  The transport here is a
+    # stand-in with ps_gather_bounds' contract over gloo (RCCL needs GPUs); the slot layout is the code that runs on them.
+    class GlooSlots(object):
+        world = dist.get_world_size()
+
+        def gather_bounds(self, send, recv, stream=None):
+            assert send.dtype == torch.int32 and recv.numel() == self.world * send.numel()
+            dist.all_gather_into_tensor(recv, send.contiguous())
+
+    cap = 64
+    bg_lib = pdist.BoundaryGather(cap, dev, backend="library", comm=GlooSlots())
+    bg_tor = pdist.BoundaryGather(cap, dev, backend="torch")
+    H = pdist.BoundaryGather.HEADER
+
+    def contribution(r, batch):
+        if batch == 0:
+            return torch.arange(5 + r, dtype=torch.int32) * 7 + r                       # fits
+        if batch == 1:
+            return torch.arange((cap + 9) if r == world - 1 else 3, dtype=torch.int32) - r    # the last rank overflows
+        if batch == 2:
+            return torch.zeros(0 if r % 2 else 4, dtype=torch.int32) + r                  # empty on odd ranks
+        buf = torch.zeros(cap + 16, dtype=torch.int32)                                  # header + payload already laid out
+        view = buf[H:H + 6 + r]
+        view.copy_(torch.arange(6 + r, dtype=torch.int32) * 3 - r)
+        return view
+    same, layout = True, True
+    for batch in range(4):
+        mine_b = contribution(rank, batch)
+        t_lib = bg_lib.submit(mine_b)
+        got_lib = [x.clone() for x in bg_lib.result(t_lib)]
+        t_tor = bg_tor.submit(mine_b.clone() if batch < 3 else contribution(rank, batch))
+        got_tor = [x.clone() for x in bg_tor.result(t_tor)]
+        want = [contribution(r, batch) for r in range(world)]
+        same = same and all(torch.equal(a, b) for a, b in zip(got_lib, got_tor))
+        layout = layout and all(torch.equal(a, b) for a, b in zip(got_lib, want))
+    # the raw rows (host=False): count in column 0, payload from HEADER on, an overflow visible as a count beyond the slot
+    t_lib = bg_lib.submit(contribution(rank, 1))
+    rows = bg_lib.result(t_lib, host=False)
+    counts_seen = [int(c) for c in rows[:, 0].tolist()]
+    ok["boundary_gather_library_equals_torch_backend"] = bool(same)
+    ok["boundary_gather_library_slot_layout"] = bool(layout) and counts_seen == [(cap + 9) if r == world - 1 else 3 for r in range(world)] \
+        and rows.shape == (world, cap) and max(counts_seen) > cap - H
+    bg_lib.close()
+    bg_tor.close()
     tmax, every = max_over_ranks(0.001 * (rank + 1), dev)
     ok["clock"] = abs(tmax - 0.001 * world) < 1e-12 and len(every) == world
     if rank == 0:

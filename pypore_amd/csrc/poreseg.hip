@@ -775,8 +775,11 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
             if (len == 0) continue;
             const int64_t vbase = vb_run;
             vb_run += len;
-            // tiles of one event share one length: the event is cut evenly (a 50k event with L = 40k: 2 x 25k)
-            const int64_t nt0 = (len + Lt - 1) / Lt;
+            // tiles of one event share one length: the event is cut evenly.  An event of up to 1.5 tile lengths stays ONE tile
+            // (round 6: a 50k event with L = 40k used to be 2 x 25k -- two chains of three windows, a seam, a bridge and a stitch
+            // entry for nothing: every event start is a true anchor.  BASELINE config 2, 1 024 x 50 000: 0.338-0.355 -> 0.309 ms
+            // for a lone call, 2 048 -> 1 024 tiles, 15 459 -> 14 435 windows; profiles/r06_experiments/r6_config2_tile.txt)
+            const int64_t nt0 = use_bs ? std::max<int64_t>(1, (len + Lt / 2) / Lt) : (len + Lt - 1) / Lt;
             const int64_t Le = std::min<int64_t>(((len + nt0 - 1) / nt0 + 7) & ~7LL, 0x7fffffff);
             const int64_t nt = (len + Le - 1) / Le;
             if (static_cast<int64_t>(jobs.size()) + nt > 0x7ffffff0) return RC_FALLBACK;

@@ -81,7 +81,12 @@ int ps_comm_init_all(int ndev, const int *devices, ps_comm **out)
     COMM_TRY_NCCL(ncclCommInitAll(comms.data(), ndev, devs.data()));
     for (int i = 0; i < ndev; ++i) {
         ps_comm *c = new (std::nothrow) ps_comm;
-        if (!c) return fail(PS_COMM_ERR_ARG, "out of memory");
+        if (!c) {
+            // nothing half-made is left behind: the ranks wrapped so far and every communicator go back, out[] is all NULL
+            for (int k = 0; k < i; ++k) { out[k]->comm = nullptr; delete out[k]; out[k] = nullptr; }
+            for (int k = 0; k < ndev; ++k) { (void)hipSetDevice(devs[k]); (void)ncclCommDestroy(comms[k]); }
+            return fail(PS_COMM_ERR_ARG, "out of memory");
+        }
         c->comm = comms[i]; c->world = ndev; c->rank = i; c->device = devs[i];
         out[i] = c;
     }

@@ -45,11 +45,14 @@ class _StreamDone(object):
     """wait() of a gather queued on a stream by the library (BoundaryGather backend "library"): an event on that stream."""
 
     def __init__(self, stream):
-        self.ev = torch.cuda.Event()
-        self.ev.record(stream)
+        self.ev = None
+        if stream is not None:                           # (None: a transport that completed synchronously -- CPU tensors in the self-test)
+            self.ev = torch.cuda.Event()
+            self.ev.record(stream)
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
+        if self.ev is not None:
+            torch.cuda.current_stream().wait_event(self.ev)
 
 
 class BoundaryGather:
@@ -65,21 +68,30 @@ class BoundaryGather:
     buffer's head is sent as it is (whatever lies behind the count's worth of payload is ignored by the receiver)."""
     HEADER = 4          # elements before the payload (16 bytes: the payload keeps its alignment)
 
-    def __init__(self, capacity, device, dtype=torch.int32, group=None, depth=2, backend="torch"):
+    def __init__(self, capacity, device, dtype=torch.int32, group=None, depth=2, backend="torch", comm=None):
         """backend "torch" (default): torch.distributed's all_gather on the group (RCCL on GPUs, gloo in the CPU tests);
         "library": the C ABI's own entry point, ps_gather_bounds of libporeseg_comm.so (include/poreseg_comm.h) -- the
-        same ncclAllGather underneath, on a communicator the library sets up (its id travels over the torch group once)."""
+        same ncclAllGather underneath, on a communicator the library sets up (its id travels over the torch group once).
+        comm: (library backend) an object with ps_gather_bounds' contract -- gather_bounds(send[capacity], recv[world *
+        capacity]), every rank's slot at rank * capacity -- to use instead of a new RCCL communicator: bench.py's
+        --selftest-dist passes one that moves CPU tensors over gloo, so that the slot layout of this backend (header,
+        in-place send, overflow and the fall-back all ranks take together) is exercised with 8 ranks and no GPU."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.cap = int(capacity)
         self.comm = None
+        self._own_comm = False
         if backend == "library":
-            from . import _comm
             assert dtype == torch.int32, "ps_gather_bounds gathers int32 boundaries"
-            ids = [_comm.unique_id() if dist.get_rank(group) == 0 else None]
-            dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            dev = torch.device(device)
-            self.comm = _comm.Comm.for_rank(self.world, dist.get_rank(group), ids[0], dev.index if dev.index is not None else torch.cuda.current_device())
+            if comm is not None:
+                self.comm = comm
+            else:
+                from . import _comm
+                ids = [_comm.unique_id() if dist.get_rank(group) == 0 else None]
+                dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                dev = torch.device(device)
+                self.comm = _comm.Comm.for_rank(self.world, dist.get_rank(group), ids[0], dev.index if dev.index is not None else torch.cuda.current_device())
+                self._own_comm = True
         else:
             assert backend == "torch", backend
         self.slots = [dict(send=torch.zeros(self.cap, dtype=dtype, device=device),
@@ -105,11 +117,23 @@ class BoundaryGather:
         s["local"] = local
         if self.comm is not None:
             self.comm.gather_bounds(send, s["recv"])         # on the current stream: ordered behind the kernels that wrote `send`
-            s["work"] = _StreamDone(torch.cuda.current_stream(send.device))
+            s["work"] = _StreamDone(torch.cuda.current_stream(send.device) if send.is_cuda else None)
         else:
             s["work"] = dist.all_gather_into_tensor(s["recv"], send, group=self.group, async_op=True)
         self.k += 1
         return self.k - 1
+
+    def close(self):
+        """Gives the library backend's communicator back (ps_comm_destroy); the torch backend has nothing to release."""
+        if self.comm is not None and self._own_comm:
+            self.comm.close()
+        self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def result(self, ticket, host=True):
         """Per-rank tensors of batch `ticket` (views into the slot: consume before `depth` more submits).
