@@ -186,6 +186,23 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
                       int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off,
                       ps_segstat *d_stats, uint8_t *d_is_spine);
 
+/* The EXACT route for float64 input that lies on no ADC grid (round 6).  The reference takes any double[:] (cparsers.pyx:53)
+ * and its decisions on such data depend on the rounding of its own prefix sums, c = np.cumsum(current) and c2 =
+ * np.cumsum(np.multiply(current, current)) (cparsers.pyx:110-111): strictly sequential fp64 additions.  This entry forms
+ * exactly those -- one chain per event, the events in parallel -- and scans every window of the recursion
+ * (cparsers.pyx:157-203) with the reference's own expressions on them (var_c, :31-38; gain = var_summed - (low + high);
+ * strict '>', first maximum): the same boundaries as the reference on the same input BY CONSTRUCTION, up to the logarithm's
+ * last bit (counters[11] counts nothing here; a tie within 1e-12 of a gain is as undecided as everywhere else).
+ *   d_current   float64 pA, device; event e = [h_ev_start[e], h_ev_start[e] + h_ev_len[e])
+ *   d_bounds / cap / h_bounds_off   as ps_segment_batch; no statistics (the caller has the float64 values)
+ * Cost: ~10-20 ns per sample and event for the chains (events run side by side), then one 512-thread workgroup per window
+ * with two fp64 logarithms per candidate: a 1e6-sample event takes tens of milliseconds where the re-quantised route
+ * (ps_requantise + ps_segment_batch) takes one.  Meant for the events that route flags (near ties) and for callers who
+ * want the reference's own arithmetic; pypore_amd: SpeedyStatSplit(off_grid="exact" / "exact_on_near_tie"). */
+int ps_segment_exact_f64(ps_ctx *ctx, const double *d_current, const int64_t *h_ev_start, const int64_t *h_ev_len,
+                         int32_t n_ev, const ps_split_params *params, int32_t *d_bounds, int64_t cap,
+                         int64_t *h_bounds_off);
+
 /* Upper bound on the number of breakpoints ps_segment_batch can emit for these events
  * (sum over events of len/min_width): a safe `cap`. */
 int64_t ps_bounds_capacity(const int64_t *h_ev_off, int32_t n_ev, int32_t min_width);

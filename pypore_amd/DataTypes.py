@@ -148,7 +148,20 @@ class Event(Segment):
         return segments
 
     def _parse_filtered(self, parser):
+        mode = parser.off_grid if isinstance(parser, SpeedyStatSplit) else None
+        if mode == "exact":
+            # the reference's own arithmetic on the float64 current itself (ps_segment_exact_f64): nothing is rounded
+            return self._adopt_filtered(parser.parse_exact(np.asarray(self.current, dtype=np.float64)))
         rounded, _, centre = self._on_fine_grid()
+        if mode == "exact_on_near_tie":
+            import warnings
+            from . import engine
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always", engine.NearTieWarning)
+                segs = parser.parse_batch([rounded], [centre])[0]
+            if any(issubclass(w.category, engine.NearTieWarning) for w in seen):
+                segs = parser.parse_exact(np.asarray(self.current, dtype=np.float64))
+            return self._adopt_filtered(segs)
         if isinstance(parser, SpeedyStatSplit):
             # (the level goes along: the device judges near ties against the noise of the reference's cumsums, which run on
             #  the uncentred current -- include/poreseg.h, ps_sample_format)
@@ -278,13 +291,22 @@ class File(Segment):
         for i, segs in zip(plain_idx, parser.parse_batch(currents) if batched else [parser.parse(c) for c in currents]):
             results[i] = segs
         by_step = {}
+        exact_modes = isinstance(parser, SpeedyStatSplit) and parser.off_grid in ("exact", "exact_on_near_tie")
         for i, ev in enumerate(self.events):
             if ev.__dict__.get("filtered"):
+                if exact_modes:                          # (the event decides for itself: Event._parse_filtered)
+                    results[i] = ev._parse_filtered(parser)
+                    continue
                 rounded, step, centre = ev._on_fine_grid()
                 by_step.setdefault(step, []).append((i, rounded, centre))
         for group in by_step.values():
             currents = [r for _, r, _ in group]
-            found = parser.parse_batch(currents, [c for _, _, c in group]) if batched else [parser.parse(c) for c in currents]
+            if batched and isinstance(parser, SpeedyStatSplit):
+                found = parser.parse_batch(currents, [c for _, _, c in group])       # (levels: this package's extension)
+            elif batched:
+                found = parser.parse_batch(currents)     # a user's parser with the one-argument parse_batch of earlier rounds
+            else:
+                found = [parser.parse(c) for c in currents]
             for (i, _, _), segs in zip(group, found):
                 results[i] = self.events[i]._adopt_filtered(segs)
         for ev, segs in zip(self.events, results):

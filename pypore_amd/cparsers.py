@@ -9,6 +9,15 @@ import numpy as np
 from . import _lib, engine
 from .core import Segment, segments_from_edges
 
+# What happens to float input that lies on NO ADC grid (the reference takes any float64 buffer, cparsers.pyx:53):
+#   "raise"              ValueError: nothing is rounded silently (default);
+#   "requantise"         centred and rounded on the device to the finest power-of-two grid that keeps the counts below 2**22, segmented
+#                        from exact integer sums (fast; equal to the reference except in windows decided within the rounding noise
+#                        of the reference's own cumsums -- engine.NearTieWarning says when: DESIGN.md 2);
+#   "exact"              the reference's own arithmetic: its sequential fp64 cumsums and var_c expressions on the device
+#                        (ps_segment_exact_f64) -- the reference's boundaries on the same input by construction, tens of ms per 1e6 samples;
+#   "exact_on_near_tie"  the fast route, and the exact one only for input on which the fast route counted a near tie.
+OFF_GRID_MODES = ("raise", "requantise", "exact", "exact_on_near_tie")
 FILTER_BATCH = True          # False: a file's events are filtered and re-quantised one library call each (A/B: tools/profile_filtered_file.py)
 
 
@@ -22,8 +31,8 @@ class FastStatSplit(object):
                  min_gain_per_sample=None, false_positive_rate=None,
                  prior_segments_per_second=None, sampling_freq=1.e5, cutoff_freq=None,
                  quantum=None, device=None, offset=None, off_grid="raise"):
-        if off_grid not in ("raise", "requantise"):
-            raise ValueError("off_grid must be 'raise' or 'requantise'")
+        if off_grid not in OFF_GRID_MODES:
+            raise ValueError("off_grid must be one of %s" % ", ".join(repr(m) for m in OFF_GRID_MODES))
         self.off_grid = off_grid
         self.min_width = int(min_width)
         self.max_width = int(max_width)
@@ -87,17 +96,35 @@ class FastStatSplit(object):
             src = currents[i]
             out[i] = [Segment(current=src[a:z_], start=a, duration=z_ - a, end=z_) for a, z_ in zip(edges, edges[1:])]
 
+        def exact(i):
+            """off_grid="exact": the reference's own prefix sums and expressions on the device (ps_segment_exact_f64)."""
+            segs = self.parse_exact_batch([currents[i]])[0]
+            out[i] = segs
+
+        def off_grid_route(i):
+            if self.off_grid == "exact":
+                exact(i)
+            elif self.off_grid == "exact_on_near_tie":
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore", engine.NearTieWarning)      # (acted upon right here)
+                    requantised(i)
+                if ctx.near_ties():
+                    exact(i)
+            else:
+                requantised(i)
+
         def run(idx, full_detect=False):
             try:
                 parts, q = upload(idx, full_detect)
             except ValueError:
-                if self.off_grid != "requantise" or self.quantum is not None:
+                if self.off_grid == "raise" or self.quantum is not None:
                     raise
                 if len(idx) > 1:                    # find the event(s) without a grid
                     for i in idx:
                         run([i], full_detect)
                 else:
-                    requantised(idx[0])
+                    off_grid_route(idx[0])
                 return
             kinds = {(p.tensor.dtype, p.quantum if p.tensor.dtype == torch.int16 else None) for p in parts}
             if len(kinds) > 1:                      # (float input that resolved to different grids: one call each)
@@ -116,8 +143,8 @@ class FastStatSplit(object):
                 bounds, boff, stats = ctx.segment_batch(samples, ev_off, self._params, q, offset_counts=dc)
             except ValueError:
                 if self.quantum is not None or full_detect:
-                    if self.off_grid == "requantise" and self.quantum is None and len(idx) == 1:
-                        requantised(idx[0])
+                    if self.off_grid != "raise" and self.quantum is None and len(idx) == 1:
+                        off_grid_route(idx[0])
                         return
                     raise
                 # the grid was detected on a subset of the samples and the device found a sample off it: search all
@@ -143,6 +170,42 @@ class FastStatSplit(object):
             groups.setdefault(("counts", g[1]) if g is not None else ("values",), []).append(i)
         for idx in groups.values():
             run(idx)
+        return out
+
+    def parse_exact_batch(self, currents):
+        """The exact route (ps_segment_exact_f64, include/poreseg.h) for a list of float64 currents (numpy arrays, or float64
+        CUDA tensors): the reference's boundaries on the same values by construction.  Returns one list of Segments per
+        current (views of the caller's arrays; of a tensor: stretches of its host copy), start / end in samples."""
+        import torch
+        ctx = engine.context(self.device)
+        dev = torch.device("cuda", ctx.device)
+        tensors, hosts = [], []
+        for cur in currents:
+            if isinstance(cur, torch.Tensor):
+                t = cur.to(dev, torch.float64).contiguous()
+                hosts.append(None)
+            else:
+                a = np.ascontiguousarray(np.asarray(cur), dtype=np.float64)
+                if a.ndim != 1:
+                    raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % a.ndim)
+                t = torch.from_numpy(a).to(dev)
+                hosts.append(cur)
+            tensors.append(t)
+        lens = np.array([t.numel() for t in tensors], dtype=np.int64)
+        starts = np.concatenate(([0], np.cumsum(lens)))[:-1]
+        out = []
+        if len(tensors) == 0:
+            return out
+        allt = tensors[0] if len(tensors) == 1 else torch.cat(tensors)
+        if allt.numel() == 0:
+            return [[Segment(current=(h if h is not None else np.zeros(0))[0:0], start=0, duration=0, end=0)] for h in hosts]
+        bounds, boff = ctx.segment_exact_f64(allt, starts, lens, self._params)
+        b = bounds.cpu().numpy()
+        for e, (t, h) in enumerate(zip(tensors, hosts)):
+            n = int(lens[e])
+            src = h if h is not None else t.cpu().numpy()
+            edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [n])).tolist()
+            out.append([Segment(current=src[a:z_], start=a, duration=z_ - a, end=z_) for a, z_ in zip(edges, edges[1:])])
         return out
 
     def parse_filtered_batch(self, currents, order=1, cutoff=2000., sampling_freq=1.e5):
@@ -219,14 +282,33 @@ class FastStatSplit(object):
         from .grid import Deferred
         filtered = [Deferred.from_tensor(y, off) for y, off in filtered]
         out = [None] * len(currents)
+
+        def exact_bounds(idx, lens):
+            """the reference's own arithmetic on the filtered currents THE USER SEES (the file's offset put back, as
+            Event.current has it): one ps_segment_exact_f64 for the group"""
+            ys = [filtered[i].tensor + filtered[i].offset if filtered[i].offset else filtered[i].tensor for i in idx]
+            allt = ys[0].contiguous() if len(ys) == 1 else torch.cat(ys)
+            starts = np.concatenate(([0], np.cumsum(lens)))[:-1]
+            bounds, boff = ctx.segment_exact_f64(allt, starts, lens, self._params)
+            return bounds.cpu().numpy(), boff
+
         for step, idx in by_step.items():
             lens = np.array([onto_grid[i].numel() for i in idx], dtype=np.int64)
             ev_off = np.concatenate(([0], np.cumsum(lens)))
-            samples = onto_grid[idx[0]] if len(idx) == 1 else torch.cat([onto_grid[i] for i in idx])
-            # (one level for the call: the largest of its events' -- the larger the level, the larger the reference's noise)
-            bounds, boff, _ = ctx.segment_batch(samples, ev_off, self._params, step, want_stats=False,
-                                                offset_counts=_dc_counts(max((levels[i] for i in idx), key=abs), step))
-            b = bounds.cpu().numpy()
+            if self.off_grid == "exact":
+                b, boff = exact_bounds(idx, lens)
+            else:
+                import warnings
+                samples = onto_grid[idx[0]] if len(idx) == 1 else torch.cat([onto_grid[i] for i in idx])
+                with warnings.catch_warnings():
+                    if self.off_grid == "exact_on_near_tie":
+                        warnings.simplefilter("ignore", engine.NearTieWarning)
+                    # (one level for the call: the largest of its events' -- the larger the level, the larger the reference's noise)
+                    bounds, boff, _ = ctx.segment_batch(samples, ev_off, self._params, step, want_stats=False,
+                                                        offset_counts=_dc_counts(max((levels[i] for i in idx), key=abs), step))
+                b = bounds.cpu().numpy()
+                if self.off_grid == "exact_on_near_tie" and ctx.near_ties():
+                    b, boff = exact_bounds(idx, lens)          # (the count is per call: the whole group is redone)
             for e, i in enumerate(idx):
                 cur = filtered[i]
                 edges = np.concatenate(([0], b[boff[e]:boff[e + 1]], [int(lens[e])])).tolist()

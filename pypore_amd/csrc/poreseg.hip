@@ -108,6 +108,8 @@ struct ps_ctx {
     int scan_lds_pad = 0;     // diagnostics (libporeseg_diag.so only: option scan_lds_pad): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
     int k0_unaligned = 1;     // K0's fast route loads 16 bytes from sample-aligned addresses: probed once per device at ps_create (k0_unaligned_probe);
                               // option k0_unaligned 0 restores the 16-byte condition of rounds 1-4 (tests)
+    int gather_fused = 1;     // 1 (round 6): the gather places its items from per-256-job count sums (gather_scan_kernel), no item_scan_kernel; 0: rounds 2-5
+    int download_by_kernel = 1;   // 1 (round 6): status block + per-event offsets go back by a kernel writing pinned memory, 0: hipMemcpyAsync
     int debug = 0;            // option debug: the library says on stderr which seams gave up, which occupancy it found (prints only; results unchanged)
 #ifdef PS_DIAG
     // Diagnostics that return WRONG or stale results exist in libporeseg_diag.so only (make -C pypore_amd/csrc diag): the product
@@ -149,6 +151,7 @@ struct ps_ctx {
     } tile_cache;
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, grp, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
+    DevBuf pre_c;             // exact route (ps_segment_exact_f64): c and c2 of the call's samples, 16 B per sample
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
     DevBuf bridges, bmeta, tile_i32, sp_off, spine_items, asm_hdr, ev_first_tile;
@@ -307,6 +310,7 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
     c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr; c->grp = nullptr; c->bs_wide = 0;
     c->k0_unaligned = ctx->k0_unaligned;
+    c->pre_c = nullptr; c->pre_c2 = nullptr;
     c->dbg = ctx->small.as<SmallLayout>()->stamp;
     c->rep_eval = ctx->rep_eval; c->rep_stage = ctx->rep_stage; c->rep_sum = ctx->rep_sum;
     return PS_OK;
@@ -555,11 +559,22 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
         if (lrc) return lrc;
     }
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    const bool fused = d_hdr != nullptr && ctx->gather_fused;      // (device stitch: job index == item index)
+    if (fused) {
+        const int64_t blocks = std::max<int64_t>((n_items + (1 << GS_LOG) - 1) >> GS_LOG, (static_cast<int64_t>(n_ev) + (1 << GS_LOG)) >> GS_LOG);
+        const unsigned gg = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(blocks, 1024)));
+        hipLaunchKernelGGL(gather_scan_kernel, dim3(gg), dim3(1 << GS_LOG), 0, ctx->stream, ctx->items.as<Item>(),
+                           ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(), ctx->tree_scratch.as<int32_t>(),
+                           static_cast<long long>(n_items), d_bounds, cap, ctx->d_is_spine, d_hdr, ctx->first_item.as<int64_t>(),
+                           n_ev, ctx->bounds_off.as<int64_t>());
+        HIP_TRY(ctx, hipGetLastError());
+    } else {
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->items.as<Item>(),
                        ctx->tree_counts.as<int32_t>(), n_items, ctx->item_pos.as<int64_t>(), d_hdr,
                        ctx->first_item.as<int64_t>(), n_ev, ctx->bounds_off.as<int64_t>());
     HIP_TRY(ctx, hipGetLastError());
-    if (n_items) {
+    }
+    if (n_items && !fused) {
         const unsigned gg = static_cast<unsigned>(d_hdr ? std::min<int64_t>(n_items, 16384) : n_items);
         hipLaunchKernelGGL(gather_kernel, dim3(gg), dim3(64), 0, ctx->stream,
                            ctx->items.as<Item>(), ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(),
@@ -586,7 +601,17 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     const bool one_copy = ctx->bounds_off.p == ctx->small.as<char>() + sizeof(SmallLayout);
     if (one_copy) {
         HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout) + evb));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout) + evb, hipMemcpyDeviceToHost, ctx->stream));
+        void *h_dev = nullptr;                         // the pinned block as the device sees it (else: plain copy)
+        if (ctx->download_by_kernel && hipHostGetDevicePointer(&h_dev, ctx->h_small.p, 0) != hipSuccess) { h_dev = nullptr; (void)hipGetLastError(); }
+        if (h_dev) {
+            static_assert(sizeof(SmallLayout) % 8 == 0, "the status block is copied in 8-byte words");
+            const long long nw = static_cast<long long>((sizeof(SmallLayout) + evb) / 8);
+            hipLaunchKernelGGL(download_kernel, dim3(static_cast<unsigned>(std::min<long long>((nw + 255) / 256, 64))), dim3(256), 0, ctx->stream,
+                               ctx->small.as<unsigned long long>(), static_cast<unsigned long long *>(h_dev), nw);
+            HIP_TRY(ctx, hipGetLastError());
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout) + evb, hipMemcpyDeviceToHost, ctx->stream));
+        }
     } else {
         HIP_TRY(ctx, ctx->h_meta.reserve(evb));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta.p, ctx->bounds_off.p, evb, hipMemcpyDeviceToHost, ctx->stream));
@@ -849,7 +874,7 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
     HIP_TRY(ctx, ctx->sp_off.reserve((nj + 1) * sizeof(long long)));
     HIP_TRY(ctx, ctx->spine_items.reserve(std::max<int64_t>(1, max_items) * sizeof(int4)));
     HIP_TRY(ctx, ctx->tree_jobs.reserve(std::max<int64_t>(1, max_items) * sizeof(TreeJob)));
-    HIP_TRY(ctx, ctx->tree_counts.reserve(std::max<int64_t>(1, max_items) * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx->tree_counts.reserve((std::max<int64_t>(1, max_items) + (max_items >> GS_LOG) + 2) * sizeof(int32_t)));   // (+ the sums per 256 jobs: gather_scan_kernel)
     HIP_TRY(ctx, ctx->items.reserve(std::max<int64_t>(1, max_items) * sizeof(Item)));
     HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(max_items) + 1) * sizeof(int64_t)));
     HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(tscratch_bound) * sizeof(int32_t)));
@@ -1092,7 +1117,7 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
         const int64_t ts2 = total_len / mw + items_cap + 1;
         HIP_TRY(ctx, ctx->spine_items.reserve(static_cast<size_t>(items_cap) * sizeof(int4)));
         HIP_TRY(ctx, ctx->tree_jobs.reserve(static_cast<size_t>(items_cap) * sizeof(TreeJob)));
-        HIP_TRY(ctx, ctx->tree_counts.reserve(static_cast<size_t>(items_cap) * sizeof(int32_t)));
+        HIP_TRY(ctx, ctx->tree_counts.reserve((static_cast<size_t>(items_cap) + (static_cast<size_t>(items_cap) >> GS_LOG) + 2) * sizeof(int32_t)));
         HIP_TRY(ctx, ctx->items.reserve(static_cast<size_t>(items_cap) * sizeof(Item)));
         HIP_TRY(ctx, ctx->item_pos.reserve((static_cast<size_t>(items_cap) + 1) * sizeof(int64_t)));
         HIP_TRY(ctx, ctx->tree_scratch.reserve(static_cast<size_t>(ts2) * sizeof(int32_t)));
@@ -1250,7 +1275,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
                       &ctx->ev_boff, &ctx->blk_mm, &ctx->grp, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
                       &ctx->align_in, &ctx->align_scratch, &ctx->bridge_ext, &ctx->ext_slot, &ctx->ext_list,
-                      &ctx->lat_state, &ctx->lat_seam, &ctx->lat_res};
+                      &ctx->lat_state, &ctx->lat_seam, &ctx->lat_res, &ctx->pre_c};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1296,6 +1321,8 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
         ctx->lat_help = sh ? 0 : 1;
         ctx->k0_admit = value > 3 ? 3 : 0;
     }
+    else if (n == "gather_fused") ctx->gather_fused = value != 0;
+    else if (n == "download_by_kernel") ctx->download_by_kernel = value != 0;
     else if (n == "debug") ctx->debug = value != 0;
     // k0_unaligned 0: K0's fast route from 16-byte-aligned addresses only (what a device whose probe fails gets); 1: whatever the probe said
     else if (n == "k0_unaligned") ctx->k0_unaligned = value != 0 ? k0_unaligned_probe(ctx->device, ctx->stream) : 0;
@@ -1381,10 +1408,35 @@ int ps_segment_batch_ex(ps_ctx *ctx, const void *d_samples, const ps_sample_form
                              d_stats, d_is_spine);
 }
 
+static int segment_events_impl(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                               const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, const ps_split_params *params,
+                               int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
+                               uint8_t *d_is_spine, bool d_f64);
+
 int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
                       const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, const ps_split_params *params,
                       int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
                       uint8_t *d_is_spine)
+{
+    return segment_events_impl(ctx, d_samples, fmt, ev_start, ev_len, n_ev, params, d_bounds, cap, h_bounds_off, d_stats, d_is_spine, false);
+}
+
+// The exact route for float64 input on no ADC grid (include/poreseg.h): the reference's own prefix sums -- numpy's sequential
+// cumsums, one chain per event (cumsum_ref_kernel) -- and every window scanned with the reference's expressions on them
+// (scan_exact_prefix), under the same recursion kernels and device stitch as every other call (LDS-window pipeline: one
+// workgroup per window).  Nothing is re-quantised, no sample is read after the cumsums.
+int ps_segment_exact_f64(ps_ctx *ctx, const double *d_current, const int64_t *h_ev_start, const int64_t *h_ev_len, int32_t n_ev,
+                         const ps_split_params *params, int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off)
+{
+    if (!ctx) return PS_ERR_ARG;
+    const ps_sample_format fmt = {PS_DTYPE_F32, 0, 1.0};        // (unused by the scans of this route: they read c and c2 only)
+    return segment_events_impl(ctx, d_current, &fmt, h_ev_start, h_ev_len, n_ev, params, d_bounds, cap, h_bounds_off, nullptr, nullptr, true);
+}
+
+static int segment_events_impl(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt,
+                               const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, const ps_split_params *params,
+                               int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
+                               uint8_t *d_is_spine, bool d_f64)
 {
     if (!ctx) return PS_ERR_ARG;
     ctx->d_is_spine = d_is_spine;
@@ -1416,11 +1468,30 @@ int ps_segment_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format
     if (ctx->k0_shared && hipStreamQuery(ctx->stream) != hipSuccess) { ctx->stream_idle = false; (void)hipGetLastError(); }
     if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
     if (ctx->stitch_host) HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));   // (the device-stitch path clears it with its upload)
+    if (d_f64) {
+        // exact route: c = cumsum(x), c2 = cumsum(x * x) per event, laid out like the samples (event e at ev_start[e])
+        int64_t sample_end = 0;
+        for (int e = 0; e < n_ev; ++e) sample_end = std::max(sample_end, ev_start[e] + ev_len[e]);
+        const size_t evb = static_cast<size_t>(std::max(1, n_ev)) * sizeof(int64_t);
+        HIP_TRY(ctx, ctx->pre_c.reserve(std::max<size_t>(16, 2 * static_cast<size_t>(sample_end) * sizeof(double))));
+        HIP_TRY(ctx, ctx->det_cand.reserve(2 * evb));
+        HIP_TRY(ctx, ctx->h_hdr.reserve(2 * evb));
+        int64_t *h_ev = ctx->h_hdr.as<int64_t>();
+        for (int e = 0; e < n_ev; ++e) { h_ev[e] = ev_start[e]; h_ev[n_ev + e] = ev_len[e]; }
+        if (n_ev > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->det_cand.p, h_ev, 2 * static_cast<size_t>(n_ev) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+            double *C = ctx->pre_c.as<double>(), *C2 = C + sample_end;
+            hipLaunchKernelGGL(cumsum_ref_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(n_ev, 65535))), dim3(64), 0, ctx->stream,
+                               static_cast<const double *>(d_samples), ctx->det_cand.as<int64_t>(), ctx->det_cand.as<int64_t>() + n_ev, n_ev, C, C2);
+            HIP_TRY(ctx, hipGetLastError());
+            cfg.pre_c = C; cfg.pre_c2 = C2;
+        }
+    }
 
     if (!ctx->stitch_host) {
         // block-sum scan: candidates must avoid the ragged ends of a window (min_width >= 8) and a window must fit
         // the single-wave sweep (at most 64 digest chunks: W <= 64 512); otherwise the LDS-window kernels take the call
-        bool use_bs = ctx->scan_bs && mw >= 8 && W <= 63 * 1024 && ctx->mode != MODE_EXACT;
+        bool use_bs = ctx->scan_bs && mw >= 8 && W <= 63 * 1024 && ctx->mode != MODE_EXACT && !d_f64;
         // Counts too wide for the 32-bit digest (K0 says so: RC_WIDE): the call is redone on the 64-bit digest, and if
         // that refuses too (|k - m| >= 2^23) on the LDS-window kernels.  The next 16 calls on the same grid start where
         // this one ended (counters[7]: 1 = 64-bit digest, 2 = LDS-window scan).

@@ -72,6 +72,7 @@ constexpr int EXT_MAX = 16384;     // further anchors of an extended seam when f
 constexpr int EXT_SLOTS = 64;
 constexpr int EXT_MAX_MANY = 2048; // ... and when many do (a batch of events with a failed seam each): the side buffer holds
 constexpr int EXT_ROUNDS = 4;      // EXT_SLOTS * EXT_MAX anchors either way; the stride is fixed by the first round of a call
+constexpr int GS_LOG = 8;          // gather_scan_kernel: items per workgroup (256); tree jobs add their counts to blk[job >> GS_LOG]
 constexpr int QMAX = 256;          // blocks of candidates queued for full evaluation per window
 constexpr int PBLK = 8;            // candidates per pruning block      // anchors of the downstream tile cached in LDS for membership tests        // buffered outputs per job (int2 anchors / 2x int boundaries)
 
@@ -102,6 +103,8 @@ struct DevCfg {
                             // the bridge amplitudes of the group bound (seg_bs.hpp); nullptr: no coarse pass
     int bs_wide;            // (host side) the digest is the 64-bit one: kernels compiled for DT | DT_WIDE
     int k0_unaligned;       // 1: K0's fast route may load 16 bytes from sample-aligned addresses (probed at ps_create), 0: 16-byte-aligned only
+    const double *pre_c;    // exact route for float64 input on no grid (ps_segment_exact_f64): the reference's own prefix sums, c = cumsum(x) and
+    const double *pre_c2;   // c2 = cumsum(x * x) per event, strictly sequential like numpy's (cparsers.pyx:110-111); nullptr on every other route
     unsigned long long *dbg;  // diagnostics scratch (12 words) or nullptr
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
@@ -417,6 +420,90 @@ __device__ int scan_exact(const DevCfg &c, const lds_t *ys, int64_t g0, int ps, 
         a1 += k; a2 += k * k;
     }
     return block_argmax<NT>(best, bi, sh, best_gain_out);
+}
+
+// ---- exact scan from the reference's OWN prefix sums: cparsers.pyx:31-38 and :157-178 to the letter -----------------
+// For float64 input on no ADC grid the reference's decisions depend on the rounding of its sequential cumsums
+// (c = np.cumsum(current), c2 = np.cumsum(current * current), cparsers.pyx:110-111): exact sums of a re-quantised copy decide
+// near ties differently.  This route reads c and c2 as cumsum_ref_kernel left them -- the same additions in
+// the same order -- and evaluates var_c with the reference's expressions: (c2[e-1] - c2[s-1]) / (e - s) - ((c[e-1] - c[s-1])
+// / (e - s)) ** 2, the start == 0 branch without a subtraction, gain = var_summed - (low + high), strict '>', first maximum.
+// C, C2: the event's arrays (C[i] = sum of x[0..i]).  No FMA contraction (the reference build has none); x ** 2 is pow(x, 2.0),
+// which glibc rounds correctly: the same double as x * x.  The only difference left is the logarithm's last bit (section 2).
+__device__ __forceinline__ double ref_var_c(const double *C, const double *C2, int start, int end)
+{
+#pragma clang fp contract(off)
+    if (start == end) return 0.0;
+    if (start == 0) {
+        const double en = static_cast<double>(end);
+        const double m = C[end - 1] / en;
+        const double v = C2[end - 1] / en;
+        const double mm = m * m;
+        return v - mm;
+    }
+    const double dn = static_cast<double>(end - start);
+    const double d2 = C2[end - 1] - C2[start - 1];
+    const double d1 = C[end - 1] - C[start - 1];
+    const double v = d2 / dn;
+    const double m = d1 / dn;
+    const double mm = m * m;
+    return v - mm;
+}
+
+template <int NT>
+__device__ int scan_exact_prefix(const DevCfg &c, int64_t base, int ps, int n, int cand_lo, int cand_hi, double thresh,
+                                 SharedT<NT> &sh, double *best_gain_out)
+{
+#pragma clang fp contract(off)
+    const double *C = c.pre_c + base, *C2 = c.pre_c2 + base;
+    const int start = ps, end = ps + n;
+    ps_sync<NT>();
+    const double var_summed = static_cast<double>(n) * log(ref_var_c(C, C2, start, end));
+    double best = thresh;
+    int bi = -1;
+    for (int i = cand_lo + static_cast<int>(ps_tid<NT>()); i <= cand_hi; i += NT) {
+        const double low = static_cast<double>(i - start) * log(ref_var_c(C, C2, start, i));
+        const double high = static_cast<double>(end - i) * log(ref_var_c(C, C2, i, end));
+        const double sm = low + high;
+        const double gain = var_summed - sm;
+        if (gain > best) { best = gain; bi = i; }      // (ascending i per thread, strict '>': the thread's first maximum)
+    }
+    return block_argmax<NT>(best, bi, sh, best_gain_out);
+}
+
+// c = cumsum(x), c2 = cumsum(x * x) of every event, exactly as numpy forms them: one strictly sequential chain of fp64
+// additions per event (add.accumulate; np.multiply rounds the squares first).  One wave per event: the lanes move 512 values
+// at a time through LDS, lane 0 runs the two chains.  ~10-20 ns per sample and event, events in parallel: the price of the
+// reference's own rounding -- this route is for events the fast route flags (near ties) or for callers who ask for it.
+__global__ __launch_bounds__(64) void cumsum_ref_kernel(const double *__restrict__ x, const int64_t *__restrict__ ev_start,
+                                                        const int64_t *__restrict__ ev_len, int n_ev, double *C, double *C2)
+{
+#pragma clang fp contract(off)
+    constexpr int TRIP = 512;
+    __shared__ double xs[TRIP], cs[TRIP], c2s[TRIP];
+    const int lane = threadIdx.x;
+    for (int e = blockIdx.x; e < n_ev; e += gridDim.x) {
+        const int64_t base = ev_start[e], len = ev_len[e];
+        double c = 0.0, c2 = 0.0;
+        for (int64_t b = 0; b < len; b += TRIP) {
+            const int m = static_cast<int>(len - b < TRIP ? len - b : TRIP);
+            for (int k = lane; k < m; k += 64) xs[k] = x[base + b + k];
+            ps_sync<64>();
+            if (lane == 0) {
+#pragma unroll 8
+                for (int j = 0; j < m; ++j) {
+                    const double v = xs[j];
+                    const double vv = v * v;
+                    c = c + v;                                // (numpy's first element is x[0] itself: 0.0 + x[0], the same double -- but for the
+                    c2 = c2 + vv;                             //  sign of a zero, which no later expression sees)
+                    cs[j] = c; c2s[j] = c2;
+                }
+            }
+            ps_sync<64>();
+            for (int k = lane; k < m; k += 64) { C[base + b + k] = cs[k]; C2[base + b + k] = c2s[k]; }
+            ps_sync<64>();
+        }
+    }
 }
 
 // ---- fp32 screen ---------------------------------------------------------------------------------
@@ -973,6 +1060,10 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     if constexpr (NT == 64) {                          // single-wave workgroup: block-sum scan (seg_bs.hpp)
         if (c.bsum != nullptr && scores == nullptr && best_gain_out == nullptr)
             return scan_window_bs<DT, ROWSKIP>(c, er, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
+    }
+    if (c.pre_c != nullptr) {                          // exact route (ps_segment_exact_f64): the reference's own prefix sums, no samples read
+        wk.exact += 1;
+        return scan_exact_prefix<NT>(c, base, ps, n, cand_lo, cand_hi, thresh, sh, best_gain_out);
     }
     if (n > c.lds_cap) {                               // window larger than LDS: exact path from HBM
         wk.exact += 1;
@@ -1685,7 +1776,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
 // One job, by the NT threads that share `sh` (a workgroup, or one wave of a multi-wave workgroup when NT == 64).
 template <int NT, int DT, bool BSONLY = false>
 __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob &job, long long ji, int32_t *scratch,
-                                        int2 *spill, int32_t *counts, SharedT<NT> &sh, unsigned &bad, Work &wk)
+                                        int2 *spill, int32_t *counts, SharedT<NT> &sh, unsigned &bad, Work &wk, int32_t *blk = nullptr)
 {
     const int tid = ps_tid<NT>();
     int32_t *out = scratch + job.out_off;
@@ -1748,7 +1839,9 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
     // (the counts are zero before the kernel runs -- assemble_items_kernel, or a memset on the host-stitch path -- and
     //  most jobs find nothing: no store then, and nothing for the fence below to wait for -- a store's round trip at the
     //  end of every job is 1-2 us in front of the next job's loads)
-    if (tid == 0 && counts && cnt) counts[ji] = cnt;
+    // (blk: the sum of the counts per 256 jobs -- what gather_scan_kernel needs to place a block of items without a scan kernel
+    //  in front of it; a few hundred atomics per call, on jobs that found something)
+    if (tid == 0 && counts && cnt) { counts[ji] = cnt; if (blk) atomicAdd(&blk[ji >> GS_LOG], cnt); }
     ps_sync<NT>();                                     // obuf / stack are reused by the next job
     return cnt;
 }
@@ -1784,7 +1877,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? PS_BS_MINW : 4)) PS_SCAN_REGS void 
         // (all fields in one round trip: otherwise the compiler fetches out_cap, tests it, and only then the rest)
         asm volatile("" : : "s"(job.base), "s"(job.start), "s"(job.end), "s"(job.j0), "s"(job.out_off), "s"(job.m), "s"(job.boff));
         if (job.out_cap == 0) continue;                // spine anchor without a left subtree (device stitch)
-        tree_job<NT, DT>(c, ys, job, ji, scratch, spill, counts, sh, bad, wk);
+        tree_job<NT, DT>(c, ys, job, ji, scratch, spill, counts, sh, bad, wk, hdr ? counts + n_jobs_host : nullptr);
     }
     flush(bad, wk, status, work, 2);
 }
@@ -1831,7 +1924,7 @@ __global__ __launch_bounds__(64 * TREE_W, PS_BS_MINW) PS_SCAN_REGS void tree_mw_
             if (ji >= n_jobs) break;
         }
         const TreeJob job = jobs[ji];
-        if (job.out_cap != 0) tree_job<64, DT>(c, nullptr, job, ji, scratch, spill, counts, sh, bad, wk);
+        if (job.out_cap != 0) tree_job<64, DT>(c, nullptr, job, ji, scratch, spill, counts, sh, bad, wk, hdr ? counts + n_jobs_host : nullptr);
         if (!dyn) {
             int kk = 0;
             if (ps_tid<64>() == 0) kk = atomicAdd(&next_k, 1);
@@ -1956,7 +2049,7 @@ __global__ __launch_bounds__(64 * PAR_W, 2) void tree_par_kernel(DevCfg c, const
                 for (int k = 0; k < cnt; ++k) rank += Q.out[k] < v ? 1 : 0;
                 out[rank] = v;
             }
-            if (threadIdx.x == 0 && counts && cnt) counts[ji] = cnt;
+            if (threadIdx.x == 0 && counts && cnt) { counts[ji] = cnt; if (hdr) atomicAdd(&counts[n_jobs_host + (ji >> GS_LOG)], cnt); }
         }
         __syncthreads();                               // the queue is reused by the next job
     }
@@ -2087,6 +2180,83 @@ __global__ __launch_bounds__(64) void gather_kernel(const Item *items, const Tre
 
 
 
+// ---- gather fused with its scan (round 6; device-stitch path: job index == item index) ------------------------------
+// The position of item i in the result is i + (sum of the subtree counts before it).  The subtree kernels leave the sum of the
+// counts per GS = 256 jobs in blk[] (a few hundred atomics per call: most jobs find nothing), so a workgroup places ITS 256
+// items from the block sums before it and a scan of its own 256 values -- no single-workgroup scan kernel between the
+// subtrees and the gather (item_scan_kernel waited ~100 us for a CU with sixteen free wave slots when sixteen calls were in
+// flight).  The per-event offsets bounds_off[e] = pos[first_item[e]] come out of the same sums, one thread each.
+__global__ __launch_bounds__(256) void gather_scan_kernel(const Item *items, const TreeJob *jobs, const int32_t *counts,
+                                                          const int32_t *scratch, long long n_items_host, int32_t *bounds,
+                                                          int64_t cap, uint8_t *is_spine, const AsmHeader *hdr,
+                                                          const int64_t *first_item, int32_t n_ev, int64_t *bounds_off)
+{
+    constexpr int GS = 1 << GS_LOG;
+    __shared__ long long wsum[GS / 64];
+    __shared__ int ws[GS / 64];
+    const bool failed = hdr && hdr->fail;              // failed / refused stitch: first_item is not valid either
+    const long long n_items = dev_count(hdr, n_items_host);
+    const int32_t *blk = counts + n_items_host;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (long long e = blockIdx.x * static_cast<long long>(GS) + tid; e <= n_ev; e += gridDim.x * static_cast<long long>(GS)) {
+        long long p = 0;
+        if (!failed) {
+            const long long fi = first_item[e];
+            const long long b = fi >> GS_LOG;
+            p = fi;
+            for (long long k = 0; k < b; ++k) p += blk[k];
+            for (long long j = b << GS_LOG; j < fi; ++j) p += items[j].job < 0 ? 0 : counts[j];
+        }
+        bounds_off[e] = p;
+    }
+    const long long nb = (n_items + GS - 1) >> GS_LOG;
+    for (long long b = blockIdx.x; b < nb; b += gridDim.x) {
+        long long part = 0;
+        for (long long k = tid; k < b; k += GS) part += blk[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_down(part, d);
+        const long long i = (b << GS_LOG) + tid;
+        const bool have = i < n_items;
+        Item it = {-1, 0};
+        int cnt = 0;
+        if (have) { it = items[i]; if (it.job >= 0) cnt = counts[it.job]; }
+        const int v = have ? cnt + 1 : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        if (lane == 0) wsum[wave] = part;
+        if (lane == 63) ws[wave] = inc;
+        __syncthreads();
+        long long p = (b << GS_LOG) + inc - v;
+#pragma unroll
+        for (int w = 0; w < GS / 64; ++w) { p += wsum[w]; if (w < wave) p += ws[w]; }
+        __syncthreads();                               // wsum / ws are rewritten by the next block
+        const int32_t *src = cnt ? scratch + jobs[it.job].out_off : nullptr;
+        // subtrees with many boundaries (filtered events: hundreds): the wave copies them together, one after the other
+        unsigned long long big = __ballot(cnt > 16);
+        while (big) {
+            const int l = __builtin_ctzll(big);
+            big &= big - 1ull;
+            const long long pl = __shfl(p, l);
+            const int cl = __shfl(cnt, l);
+            const int32_t *sl = reinterpret_cast<const int32_t *>(__shfl(reinterpret_cast<unsigned long long>(src), l));
+            for (int k = lane; k < cl; k += 64)
+                if (pl + k < cap) { bounds[pl + k] = sl[k]; if (is_spine) is_spine[pl + k] = 0; }
+        }
+        if (cnt <= 16)
+            for (int k = 0; k < cnt; ++k)
+                if (p + k < cap) { bounds[p + k] = src[k]; if (is_spine) is_spine[p + k] = 0; }
+        if (have && p + cnt < cap) { bounds[p + cnt] = it.anchor; if (is_spine) is_spine[p + cnt] = 1; }
+    }
+}
+
+// The call's status block and per-event offsets go back to the host by a KERNEL that writes the pinned buffer (like the
+// upload: no hand-over to a copy engine between the last kernel and the host's wake-up).
+__global__ __launch_bounds__(256) void download_kernel(const unsigned long long *src, unsigned long long *dst_host, long long n_words)
+{
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n_words; i += gridDim.x * 256LL) dst_host[i] = src[i];
+}
+
 // ---- device-side stitch: true spine, tree jobs and items from the tile lists and bridges ----------
 // exclusive scan of two values over one 1024-thread workgroup chunk with running carries
 __device__ __forceinline__ void chunk_exscan2(long long v1, long long v2, long long &e1, long long &e2,
@@ -2211,6 +2381,8 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     const int2 *ext = nullptr, const int *ext_slot = nullptr, int ext_stride = EXT_MAX)
 {
     const long long n_items = dev_count(hdr, n_items_host);
+    // (the sums of the counts per 256 jobs live behind the counts: counts[n_items_host + b], gather_scan_kernel)
+    for (long long b = blockIdx.x * 256LL + threadIdx.x; b <= (n_items >> GS_LOG); b += gridDim.x * 256LL) counts[n_items_host + b] = 0;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n_items; i += gridDim.x * 256LL) {
     int lo = 0, hi = n_tiles - 1;
     while (lo < hi) {

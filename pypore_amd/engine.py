@@ -250,6 +250,24 @@ class Context(object):
         return bounds[:total], boff, (stats[:total + n_ev] if want_stats else None)
 
     @_serialised
+    def segment_exact_f64(self, current, ev_start, ev_len, params):
+        """ps_segment_exact_f64: events [start, start + len) of a float64 CUDA tensor (pA, on no grid) segmented from the
+        reference's own sequential prefix sums (include/poreseg.h).  Returns (bounds int32 CUDA tensor, bounds_off)."""
+        assert current.is_cuda and current.is_contiguous() and current.dim() == 1 and current.dtype == torch.float64
+        ev_start = np.ascontiguousarray(ev_start, dtype=np.int64)
+        ev_len = np.ascontiguousarray(ev_len, dtype=np.int64)
+        n_ev = ev_start.size
+        cap = int(np.sum(ev_len // int(params.min_width) + 1)) if n_ev else 0
+        bounds = torch.empty(max(cap, 1), dtype=torch.int32, device=current.device)
+        boff = np.zeros(n_ev + 1, dtype=np.int64)
+        P64 = ctypes.POINTER(ctypes.c_int64)
+        torch.cuda.current_stream(current.device).synchronize()
+        _lib.check(self.L.ps_segment_exact_f64(self.handle, ctypes.c_void_p(current.data_ptr()), ev_start.ctypes.data_as(P64),
+                                               ev_len.ctypes.data_as(P64), n_ev, ctypes.byref(params),
+                                               ctypes.c_void_p(bounds.data_ptr()), cap, boff.ctypes.data_as(P64)), self.handle)
+        return bounds[:int(boff[-1])], boff
+
+    @_serialised
     def best_single_split(self, samples, quantum, offset_counts=0):
         fmt = _lib.SampleFormat(_lib.PS_DTYPE_F32 if samples.dtype == torch.float32 else _lib.PS_DTYPE_I16,
                                 int(offset_counts), float(quantum))

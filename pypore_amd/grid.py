@@ -117,8 +117,9 @@ class Deferred(object):
                                                          # Deferred sits in event <-> segment cycles, so the cyclic collector may run its
                                                          # __del__ -> _unpark on THIS thread at any allocation inside _park
     _by_device = {}                                      # device index -> bytes parked there
-    _cap_cache = {}                                      # device index -> [calls until the next look at the device, cap]
-    CAP_REFRESH = 64                                     # _park asks the driver for the free memory once per this many calls
+    _cap_cache = {}                                      # device index -> [calls until the next look at the device, cap, bytes parked at that look]
+    CAP_REFRESH = 64                                     # _park asks the driver for the free memory once per this many calls ...
+    CAP_REFRESH_BYTES = 1 << 30                          # ... and whenever the parked bytes have grown by this much since the last look
 
     @classmethod
     def _device_cap(cls, dev_key, refresh=False):
@@ -126,7 +127,9 @@ class Deferred(object):
         free.  Memory that torch's caching allocator holds but has not handed out counts as free (it is: the next tensor
         comes out of it).  The driver is asked once per CAP_REFRESH calls, and again whenever a request was refused."""
         ent = cls._cap_cache.get(dev_key)
-        if ent is not None and ent[0] > 0 and not refresh:
+        parked = cls._by_device.get(dev_key, 0)
+        # (several ranks or threads share a GPU: "less than a tenth free" must not be 64 parks old once a GiB has gone in)
+        if ent is not None and ent[0] > 0 and not refresh and parked - ent[2] < cls.CAP_REFRESH_BYTES:
             ent[0] -= 1
             return min(cls.DEVICE_BYTES_MAX, ent[1])
         limit = cls.DEVICE_BYTES_MAX
@@ -137,7 +140,7 @@ class Deferred(object):
             limit = 0 if free < total // 10 else total // 4
         except Exception:
             pass
-        cls._cap_cache[dev_key] = [cls.CAP_REFRESH, limit]
+        cls._cap_cache[dev_key] = [cls.CAP_REFRESH, limit, parked]
         return min(cls.DEVICE_BYTES_MAX, limit)
 
     @classmethod

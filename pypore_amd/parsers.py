@@ -121,7 +121,11 @@ class SpeedyStatSplit(parser):
     describe the ADC grid of float input (pA per count, pA at count 0; found automatically when omitted), `device`
     picks the GPU, `off_grid` says what happens to float input that lies on NO grid (the reference takes any float64
     buffer, cparsers.pyx:53): "raise" (default) ValueError -- nothing is rounded silently --, "requantise" rounds it
-    on the device to the finest power-of-two grid that keeps the counts below 2**22."""
+    on the device to the finest power-of-two grid that keeps the counts below 2**22, "exact" segments it with
+    the reference's own arithmetic -- its sequential fp64 cumsums and var_c expressions, on the device: the reference's
+    boundaries on the same input by construction, tens of milliseconds per 1e6 samples --, "exact_on_near_tie" takes the fast
+    route and the exact one only where that counted a near tie.  The last two also apply to FILTERED events (Event.parse,
+    File.parse_events), whose current lies on no grid either."""
 
     def __init__(self, min_width=100, max_width=1000000, window_width=10000,
                  min_gain_per_sample=None, false_positive_rate=None,
@@ -135,8 +139,9 @@ class SpeedyStatSplit(parser):
         self.false_positive_rate = false_positive_rate
         self.sampling_freq = sampling_freq
         self.cutoff_freq = cutoff_freq
-        if off_grid not in ("raise", "requantise"):
-            raise ValueError("off_grid must be 'raise' or 'requantise'")
+        from .cparsers import OFF_GRID_MODES
+        if off_grid not in OFF_GRID_MODES:
+            raise ValueError("off_grid must be one of %s" % ", ".join(repr(m) for m in OFF_GRID_MODES))
         self._grid = dict(quantum=quantum, device=device, offset=offset, off_grid=off_grid)
 
     def _fast(self, cutoff=True):
@@ -151,6 +156,14 @@ class SpeedyStatSplit(parser):
         """All events of a file in one device call (extension; same result as [parse(c) for c in currents]).  levels: the
         level in pA that was subtracted from each event upstream (Event.parse of a filtered event), or None."""
         return self._fast().parse_batch(currents, levels)
+
+    def parse_exact(self, current):
+        """The exact route for one float64 current (extension; cparsers.FastStatSplit.parse_exact_batch)."""
+        return self._fast().parse_exact_batch([current])[0]
+
+    @property
+    def off_grid(self):
+        return self._grid["off_grid"]
 
     def parse_filtered_batch(self, currents, order=1, cutoff=2000., sampling_freq=None):
         """event.filter(order, cutoff); event.parse(self) for many events, on the device from end to end (extension)."""

@@ -30,7 +30,12 @@ SECOND = 1.e5
 # one of them raises NearTieWarning (the windows in question are decided within the noise of the reference's own cumsums).
 _D = {"FS001", "FS002", "FS003", "FS018", "FS019", "FS041", "FS042", "FS043", "FS049", "FS051", "FS065", "FS080", "FS081",
       "FS082", "FS083"}
-KNOWN_DIFFERING = {"filtered": _D, "filtered_scipy": _D, "offgrid": set()}
+KNOWN_DIFFERING = {"filtered": _D, "filtered_scipy": _D, "offgrid": set(),
+                   # Round 6, the exact route (off_grid="exact": ps_segment_exact_f64 -- the reference's own sequential cumsums and
+                   # var_c expressions on the device): NOTHING may differ on the reference's own input, there is no allow-list
+                   "filtered_scipy_exact": set(), "offgrid_exact": set(),
+                   # ... nor when the exact route is taken only for input the fast route flags (every differing event is flagged)
+                   "filtered_scipy_exact_on_near_tie": set(), "offgrid_exact_on_near_tie": set()}
 
 
 def _seg_params(case):
@@ -62,11 +67,13 @@ def run_case(case, route):
     from pypore_amd import engine
     from pypore_amd.DataTypes import Event, File
     from pypore_amd.parsers import SpeedyStatSplit
+    mode = "exact_on_near_tie" if route.endswith("_exact_on_near_tie") else "exact" if route.endswith("_exact") else "requantise"
+    route = route.replace("_exact_on_near_tie", "").replace("_exact", "")
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         if case["op"] == "offgrid":
             x = synth.offgrid_trace(case["n"], case["seed"], case["sigma"], case["lo"], case["hi"])
-            segs = SpeedyStatSplit(off_grid="requantise", **_seg_params(case)).parse(x)
+            segs = SpeedyStatSplit(off_grid=mode, **_seg_params(case)).parse(x)
             got = np.array([s.start for s in segs[1:]], dtype=np.int64)
         elif route == "filtered":
             # the product's workflow: the device filters (Event.filter), then Event.parse of the filtered event
@@ -74,21 +81,21 @@ def run_case(case, route):
             f = File(current=x, timestep=1000. / SECOND)
             ev = Event(current=x, start=0., end=len(x) / SECOND, duration=len(x) / SECOND, second=SECOND, file=f)
             ev.filter(order=case["order"], cutoff=case["cutoff"])
-            ev.parse(SpeedyStatSplit(**_seg_params(case)))
+            ev.parse(SpeedyStatSplit(**_seg_params(case)) if mode == "requantise" else SpeedyStatSplit(off_grid=mode, **_seg_params(case)))
             got = np.array([int(round(s.start * SECOND)) for s in ev.segments[1:]], dtype=np.int64)
         else:
             # the reference's own input: scipy's filtfilt on the host, segmented as float64 on no grid
             import scipy.signal as signal
             (b, a) = signal.bessel(case["order"], case["cutoff"] / (SECOND / 2.), btype='low', analog=0, output='ba')
             y = signal.filtfilt(b, a, _event_current(case))
-            segs = SpeedyStatSplit(off_grid="requantise", **_seg_params(case)).parse(y)
+            segs = SpeedyStatSplit(off_grid=mode, **_seg_params(case)).parse(y)
             got = np.array([s.start for s in segs[1:]], dtype=np.int64)
     near = any(issubclass(m.category, engine.NearTieWarning) for m in w)
     return got, near
 
 
 def compare(route):
-    op = "offgrid" if route == "offgrid" else "filtered"
+    op = "offgrid" if route.startswith("offgrid") else "filtered"
     rep = dict(route=route, cases=0, boundaries=0, differing_boundaries=0, differing_cases=[], near_tie_cases=[])
     for case in MAN["cases"]:
         if case["op"] != op:
@@ -128,3 +135,46 @@ def test_sample_against_the_compiled_reference(route):
     # reference's own sums
     silent = [c["name"] for c in rep["differing_cases"] if not c["near_tie_warned"]]
     assert not silent, silent
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["filtered_scipy_exact", "offgrid_exact", "filtered_scipy_exact_on_near_tie", "offgrid_exact_on_near_tie"])
+def test_exact_route_equals_the_compiled_reference_without_an_allow_list(route):
+    """a route that is the reference's BY CONSTRUCTION for float64 input on no grid -- its own sequential
+    cumsums (cparsers.pyx:110-111) and var_c expressions (:31-38), formed on the device (ps_segment_exact_f64).  All 104
+    filtered events (the reference's own input: scipy's filtfilt) and all 52 off-grid traces of the sample: every boundary the
+    compiled reference found, no case excepted -- also when the exact route is taken only where the fast one counted a near
+    tie (the fast route's 15 differing events are all flagged)."""
+    rep = compare(route)
+    assert rep["cases"] >= 50
+    assert rep["differing_boundaries"] == 0 and not rep["differing_cases"], (rep["differing_boundaries"], rep["boundaries"], rep["differing_cases"][:5])
+    if route.endswith("_exact"):
+        assert not rep["near_tie_cases"]                 # (nothing to warn about: the decisions ARE the reference's)
+
+
+@pytest.mark.gpu
+def test_exact_route_on_device_filtered_events_equals_the_oracle_on_the_same_current():
+    """The product's own workflow (Event.filter on the device, then Event.parse) with off_grid="exact".  The device's filter
+    differs from scipy's by 1e-13 (a scan, re-associated), and the reference's near ties are decided by the last bits of its
+    cumsums over exactly its input: what "the reference's result" means for a device-filtered current is the reference on THAT
+    current -- the pinned oracle (oracle/statsplit_oracle.c == compiled cparsers.pyx on every golden) run on ev.current.
+    Every fourth filtered case of the sample (26 events, 1e5-1e6 samples): identical boundaries; against the goldens recorded
+    on scipy's output the differences are counted and reported, as for the fast route."""
+    import oracle
+    from pypore_amd.DataTypes import Event, File
+    from pypore_amd.parsers import SpeedyStatSplit
+    cases = [c for c in MAN["cases"] if c["op"] == "filtered"][::4]
+    assert len(cases) >= 25
+    vs_golden = 0
+    for case in cases:
+        x = _event_current(case)
+        f = File(current=x, timestep=1000. / SECOND)
+        ev = Event(current=x, start=0., end=len(x) / SECOND, duration=len(x) / SECOND, second=SECOND, file=f)
+        ev.filter(order=case["order"], cutoff=case["cutoff"])
+        ev.parse(SpeedyStatSplit(off_grid="exact", **_seg_params(case)))
+        got = np.array([int(round(s.start * SECOND)) for s in ev.segments[1:]], dtype=np.int64)
+        ref = oracle.parse(np.asarray(ev.current, dtype=np.float64), **_seg_params(case))
+        np.testing.assert_array_equal(got, ref, err_msg=case["name"])
+        vs_golden += int(np.setxor1d(got, NPZ[case["name"]].astype(np.int64)).size)
+    print("exact route on device-filtered events: 0 differences against the oracle on the same current; %d boundaries beside the "
+          "goldens recorded on scipy's output (%d cases)" % (vs_golden, len(cases)))
