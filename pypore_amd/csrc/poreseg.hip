@@ -1054,7 +1054,7 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
             hipLaunchKernelGGL(assemble_items_kernel, dim3(ag), dim3(256), 0,
                                ctx->stream, ctx->spine_jobs.as<SpineJob>(), static_cast<int>(nj), ctx->spine_meta.as<int4>(),
                                ctx->spine_scratch.as<int2>(), ctx->bridges.as<int2>(), ti + 3 * njp,
-                               ctx->sp_off.as<long long>(), 0LL, mw, W, ctx->tree_jobs.as<TreeJob>(),
+                               ctx->sp_off.as<long long>(), static_cast<long long>(items_cap), mw, W, ctx->tree_jobs.as<TreeJob>(),
                                ctx->items.as<Item>(), ctx->tree_counts.as<int32_t>(), d_hdr, cfg.bsum != nullptr ? cfg.ev_info : nullptr,
                                ctx->bridge_ext.as<int2>(), ctx->ext_slot.as<int>(), ext_stride);
             HIP_TRY(ctx, hipGetLastError());
