@@ -33,6 +33,7 @@ _ENV_OPTIONS = {
     "PORESEG_UPLOAD": "upload_by_kernel", "PORESEG_TIMING": "timing", "PORESEG_TREE_MW": "tree_mw",
     "PORESEG_TREE_JPW": "tree_jobs_per_wave", "PORESEG_SLOTS_PCT": "slots_pct", "PORESEG_BRIDGE_EXT": "bridge_ext",
     "PORESEG_LAT_HELP": "lat_help", "PORESEG_BRIDGE_BUDGET": "bridge_budget", "PORESEG_DEBUG": "debug",
+    "PORESEG_GATHER_FUSED": "gather_fused", "PORESEG_DOWNLOAD": "download_by_kernel", "PORESEG_K0_UNALIGNED": "k0_unaligned",
     # libporeseg_diag.so only (PORESEG_LIB=.../libporeseg_diag.so): stale or partial results, never the product
     "PORESEG_DBG_PHASE": "dbg_phase", "PORESEG_DBG_K0_NOGRP": "dbg_k0_nogrp", "PORESEG_SCAN_LDS_PAD": "scan_lds_pad",
 }
