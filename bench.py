@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 PARAMS = dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10.,
               sampling_freq=1e5)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")     # written by tools/profile_round.sh from the PMC passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")     # written by tools/profile_round.sh from the PMC passes
 METRIC = "Msamples/sec segmented (SpeedyStatSplit, 10^8-sample trace); %HBM roofline"
 
 
@@ -767,14 +767,17 @@ def main():
                                               "achieved": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / 1e9, 1) if kern["blocksum_ms"] > 0 else None,
                                               "frac": round(k0_bytes / (kern["blocksum_ms"] * 1e-3) / HBM_PEAK, 4) if kern["blocksum_ms"] > 0 else None},
                          "traffic_per_kernel": traffic["per_kernel"] if traffic else None,
-                         # what bounds the path is instruction issue, not memory: the call's wave-level
-                         # vector instructions (SQ_INSTS_VALU of the same PMC passes) at 4 cycles each on 1 024 SIMDs
+                         # the call's wave-level vector instructions (SQ_INSTS_VALU of the same PMC passes) at 4 cycles each on
+                         # 1 024 SIMDs -- reported beside the roofline (DESIGN.md 6 says what bounds the path)
                          "issue_bound": None if not (traffic and traffic.get("valu_per_kernel")) else {
                              "wave_instructions": int(sum(traffic["valu_per_kernel"].values())),
                              "ms_at_valu_peak": round(sum(traffic["valu_per_kernel"].values()) * 4 / (1024 * 2.4e9) * 1e3, 4),
                              "frac_of_valu_peak": round(sum(traffic["valu_per_kernel"].values()) * 4 / (1024 * 2.4e9) * 1e3 / ms_per_step, 4),
                              "per_kernel": traffic["valu_per_kernel"], "source": traffic.get("valu_source"),
-                             "note": "256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz"},
+                             "note": "256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz; an accounting figure, not the "
+                                     "bound: removing 6.8 M of K0's instructions does not move the step (round 6, "
+                                     "profiles/r06_experiments/r6_k0_grp_probe.txt; DESIGN.md 6: K0 is bound by HBM, and what it costs the "
+                                     "scan kernels is register residency)"},
                          # the secondary bound is instruction issue -- candidate positions the windows of one step
                          # cover (every one is decided: evaluated or excluded by a bound) per second of the job's clock
                          "evaluations_per_s": round(tm["candidates"] * world / (ms_per_step * 1e-3), 1) if wl != "files" else None,

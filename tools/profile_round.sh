@@ -9,7 +9,7 @@
 #   <tag>_pmc_summary.txt       PMC passes (tools/pmc_run.sh, --streams 1: instruction counts, traffic of one call at a time)
 #   <tag>_pmc16_summary.txt     the same passes with sixteen calls in flight on sixteen DISTINCT traces (--streams 16, the bench's
 #                               default): what the headline configuration fetches; <tag>_pmc_traffic.json: HBM bytes per launch from both
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$PWD
 export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out
@@ -28,6 +28,7 @@ for s in 16 1; do
 done
 cd $ROOT
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_20.json 2>> gpurun_out/${TAG}_bench.err
 bash tools/pmc_run.sh ${TAG}_pmc 1 > /dev/null 2>&1
 bash tools/pmc_run.sh ${TAG}_pmc16 16 > /dev/null 2>&1
 python3 - $TAG <<'PY'
@@ -57,7 +58,7 @@ for line in open('gpurun_out/%s_pmc_summary.txt' % tag):
     elif m.group(1) == 'write': per[k]['write_kib'] = d['WRITE_SIZE']
     elif 'SQ_INSTS_VALU' in d: per[k]['valu'] = d['SQ_INSTS_VALU']
 names = ['blocksum_kernel', 'spine_kernel', 'bridge_kernel', 'bridge_la_kernel', 'tree_kernel', 'tree_mw_kernel', 'assemble_tiles_kernel',
-         'assemble_items_kernel', 'item_scan_kernel', 'gather_kernel', 'upload_kernel']
+         'assemble_items_kernel', 'item_scan_kernel', 'gather_kernel', 'gather_scan_kernel', 'download_kernel', 'upload_kernel']
 pk = {k: (2 * per[k].get('fetch_kib', 0) + per[k].get('write_kib', 0)) * 1024 for k in names if k in per}
 pk4 = {k: (2 * per4[k].get('fetch_kib', 0) + per4[k].get('write_kib', 0)) * 1024 for k in names if k in per4}
 json.dump({"source": "profiles/%s_pmc_summary.txt: FETCH_SIZE (KiB) x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE (KiB) per "
