@@ -103,6 +103,7 @@ struct ps_ctx {
                               // allow -- faster for a call that has the chip to itself (1e9 samples: K0 0.91 against 0.98 ms)
     float noise_k = 0.1f;     // near-tie accounting of the wide route (DevCfg::noise_k; PORESEG_NOISE_K)
     int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
+    int k0_sets = 2;          // register sets of a persistent K0 wave (seg_bs.hpp: blocksum_kernel<DT, NS>); 3 / 4 in the diagnostic library only (rejected)
     bool gate_held = false;
     bool defer_sync = false;  // (internal) ps_filter_requantise_batch: the filter entry only queues its kernels -- no status clear, copy, sync
     int scan_lds_pad = 0;     // diagnostics (libporeseg_diag.so only: option scan_lds_pad): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
@@ -951,10 +952,10 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
         }
         const unsigned k0_full = static_cast<unsigned>((nb_pad / K0_WB + K0_WAVES - 1) / K0_WAVES);
         // (a wave block of int16 samples is half the bytes: twice the waves keep the same bytes in flight)
-        const unsigned k0_per_cu = static_cast<unsigned>(ctx->k0_waves) * (f32 ? 1u : 2u);
+        const unsigned k0_per_cu = static_cast<unsigned>(ctx->k0_waves) * ((f32 || (ctx->k0_sets > 2 && !wide)) ? 1u : 2u);   // (k0_sets > 2: diagnostic library only)
         const unsigned k0_grid = ctx->k0_waves > 0 ? std::min(k0_full, k0_per_cu * static_cast<unsigned>(ctx->n_cu) * (4u / K0_WAVES)) : k0_full;
         const size_t k0_lds = 0;
-#define PS_K0(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV>), dim3(k0_grid), dim3(64 * K0_WAVES), k0_lds, fs, cfg,       \
+#define PS_K0N(DTV, NSV) hipLaunchKernelGGL((blocksum_kernel<DTV, NSV>), dim3(k0_grid), dim3(64 * K0_WAVES), k0_lds, fs, cfg,       \
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
                                     reinterpret_cast<unsigned *>(&sm->status), k0_grp)
@@ -966,10 +967,18 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
         const bool skip_k0 = false;
         uint4 *const k0_grp = const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp));
 #endif
+#define PS_K0(DTV) PS_K0N(DTV, 2)
         if (skip_k0) { }
         else if (wide) { if (f32) PS_K0(PS_DTYPE_F32 | DT_WIDE); else PS_K0(PS_DTYPE_I16 | DT_WIDE); }
+#ifdef PS_DIAG
+        // (measured and rejected, round 6 -- docs/ROUND_6.md: fatter K0 waves hold fewer registers per byte in flight, but a lone K0
+        //  wave per SIMD cannot issue fast enough beside four scan waves; the instances exist in the diagnostic library only)
+        else if (ctx->k0_sets == 3 && ctx->k0_waves > 0) { if (f32) PS_K0N(PS_DTYPE_F32, 3); else PS_K0N(PS_DTYPE_I16, 6); }
+        else if (ctx->k0_sets == 4 && ctx->k0_waves > 0) { if (f32) PS_K0N(PS_DTYPE_F32, 4); else PS_K0N(PS_DTYPE_I16, 8); }
+#endif
         else           { if (f32) PS_K0(PS_DTYPE_F32); else PS_K0(PS_DTYPE_I16); }
 #undef PS_K0
+#undef PS_K0N
         HIP_TRY(ctx, hipGetLastError());
         cfg.bsum = ctx->bsum.p;
         cfg.ev_info = ctx->ev_info.as<int4>();
@@ -1332,6 +1341,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
 #ifdef PS_DIAG
     else if (n == "dbg_phase" && value >= 0 && value <= 2) ctx->dbg_phase = static_cast<int>(value);
     else if (n == "dbg_k0_nogrp") ctx->dbg_k0_nogrp = value != 0;
+    else if (n == "k0_sets" && value >= 2 && value <= 4) ctx->k0_sets = static_cast<int>(value);
     else if (n == "scan_lds_pad" && value >= 0 && value <= 65536) ctx->scan_lds_pad = static_cast<int>(value);
     else if (n == "rep_eval" && value >= 1) ctx->rep_eval = static_cast<int>(value);
     else if (n == "rep_stage" && value >= 1) ctx->rep_stage = static_cast<int>(value);

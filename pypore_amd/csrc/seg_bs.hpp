@@ -491,8 +491,15 @@ __global__ void k0_unaligned_probe_kernel(const unsigned char *buf, int n_off, u
         atomicOr(bad, 1u);
 }
 
-template <int DT>
-__global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(DevCfg c, const int64_t *__restrict__ ev_start, const int64_t *__restrict__ ev_len,
+// Round 6: NS register sets.  What K0 costs the scan kernels of the other calls in flight is the REGISTER FILE it holds while its
+// bytes travel (tools/r6/residency_probe.py: waves that only hold registers slow the scans by ~0.02 ms per step per 100
+// registers held per SIMD), and a wave's ~64 working registers are overhead: with two sets a wave holds 128 registers for 8 KB
+// in flight, and three such waves per SIMD (three admitted K0s) saturate HBM -- 384 registers.  With NS = 4 sets ONE wave holds
+// 192 registers for 24 KB in flight: the same bytes in half the registers.  MEASURED AND REJECTED (docs/ROUND_6.md): one K0
+// wave per SIMD cannot issue its ~660 instructions per 8 KB fast enough beside four scan waves (0.168 -> 0.24 ms per step with
+// one K0 admitted, 0.176-0.19 with two or three) -- the product launches NS = 2; 3 and 4 exist in libporeseg_diag.so.
+template <int DT, int NS = 2>
+__global__ __launch_bounds__(64 * K0_WAVES, (NS > 2 ? 2 : PS_K0_MINW)) void blocksum_kernel(DevCfg c, const int64_t *__restrict__ ev_start, const int64_t *__restrict__ ev_len,
                                                                 const int64_t *__restrict__ ev_boff, int n_ev, int64_t n_samples, void *bs_out,
                                                                 int4 *ev_info, int4 *chunk_tot, unsigned *status, uint4 *grp_out)
 {
@@ -778,38 +785,46 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
     // Pass 1, the wave blocks of the fast route: two sets of load registers, used in turn -- the next wave block's samples
     // travel while this one is worked on.  Wave blocks of the general route (an out-of-line call: registers that are live
     // across it would be spilled, and the compiler then parks the whole second set on the stack) are left to pass 2.
-    int4 rawA[K0_BPT][NV], rawB[K0_BPT][NV];
-    raw_t firstA, firstB;
+    int4 raw[NS][K0_BPT][NV];
+    raw_t first[NS];
+    K0Src src[NS];
     unsigned long long general = 0;                    // iterations of this wave that were not fast (uniform; from the 64th on: looked at again)
     int it = 0;
     const long long wv0 = wv;
     // (a wave block that is skipped here still "reads" its registers: on every path the loads of a set are then known to be
     //  complete before the set is requested again -- otherwise the compiler waits in the middle of the next request)
-    auto retire = [&](const int4 (&raw)[K0_BPT][NV], const raw_t first) {
+    auto retire = [&](const int4 (&rw)[K0_BPT][NV], const raw_t fs) {
 #pragma unroll
         for (int k = 0; k < K0_BPT; ++k)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) asm volatile("" :: "v"(raw[k][v].x), "v"(raw[k][v].y), "v"(raw[k][v].z), "v"(raw[k][v].w));
-        asm volatile("" :: "v"(first));
+            for (int v = 0; v < NV; ++v) asm volatile("" :: "v"(rw[k][v].x), "v"(rw[k][v].y), "v"(rw[k][v].z), "v"(rw[k][v].w));
+        asm volatile("" :: "v"(fs));
     };
-    K0Src sA = classify(wv * K0_WB, 0), sB = sA;
-    issue(sA, rawA, firstA);
+    // prologue: sets 0 .. NS-2 hold this wave's first NS-1 wave blocks (wv, wv + nwv, ...); set NS-1 is requested in the loop
+    int e_hint = 0;
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q) {
+        const long long wq = wv + q * nwv;
+        if (wq < n_wb) { src[q] = classify(wq * K0_WB, e_hint); e_hint = src[q].e; }
+        else { src[q] = src[0]; src[q].fast = 0; }     // (beyond the call: the dummy lines)
+        issue(src[q], raw[q], first[q]);
+    }
+    bool last = false;
 #pragma unroll 1
-    for (;;) {
-        const bool moreB = wv + nwv < n_wb;
-        if (moreB) sB = classify((wv + nwv) * K0_WB, sA.e); else sB.fast = 0;
-        issue(sB, rawB, firstB);                       // (unconditional, like the loads inside: a last wave block requests the dummy lines)
-        if (sA.fast) process(std::true_type{}, wv * K0_WB, sA, rawA, firstA);
-        else { general |= 1ull << min(it, 63); retire(rawA, firstA); }
-        if (!moreB) break;
-        wv += nwv; ++it;
-        const bool moreA = wv + nwv < n_wb;
-        if (moreA) sA = classify((wv + nwv) * K0_WB, sB.e); else sA.fast = 0;
-        issue(sA, rawA, firstA);
-        if (sB.fast) process(std::true_type{}, wv * K0_WB, sB, rawB, firstB);
-        else { general |= 1ull << min(it, 63); retire(rawB, firstB); }
-        if (!moreA) break;
-        wv += nwv; ++it;
+    while (!last) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (last) break;
+            constexpr int NSm1 = NS - 1;
+            const int f = (q + NSm1) % NS;              // the set that was worked on last: free again (compile-time after unrolling)
+            const long long wn = wv + static_cast<long long>(NSm1) * nwv;
+            if (wn < n_wb) { src[f] = classify(wn * K0_WB, e_hint); e_hint = src[f].e; } else src[f].fast = 0;
+            issue(src[f], raw[f], first[f]);            // (unconditional, like the loads inside: beyond the call the dummy lines)
+            if (src[q].fast) process(std::true_type{}, wv * K0_WB, src[q], raw[q], first[q]);
+            else { general |= 1ull << min(it, 63); retire(raw[q], first[q]); }
+            if (wv + nwv >= n_wb) last = true;
+            else { wv += nwv; ++it; }
+        }
     }
     // Pass 2, the general route: the wave blocks at the ends of events, unaligned events, the last wave block of the call
     if (general) {
@@ -820,7 +835,7 @@ __global__ __launch_bounds__(64 * K0_WAVES, PS_K0_MINW) void blocksum_kernel(Dev
             if (it < 63 && !((general >> it) & 1ull)) continue;
             const K0Src sg = classify(wv * K0_WB, e_lo);
             e_lo = sg.e;
-            if (!sg.fast) process(std::false_type{}, wv * K0_WB, sg, rawA, firstA);
+            if (!sg.fast) process(std::false_type{}, wv * K0_WB, sg, raw[0], first[0]);
         }
     }
     if (bad) atomicOr(status, bad);

@@ -28,7 +28,7 @@ POOL_OVERRIDES = {}
 _ENV_OPTIONS = {
     "PORESEG_MODE": "mode", "PORESEG_SPINE_NT": "spine_nt", "PORESEG_TREE_NT": "tree_nt", "PORESEG_PRUNE": "prune",
     "PORESEG_SCAN_BS": "scan_bs", "PORESEG_GROUPS": "groups", "PORESEG_TREE_PAR": "tree_par", "PORESEG_K0_WAVES": "k0_waves",
-    "PORESEG_K0_SHARED": "k0_shared", "PORESEG_K0_MAX": "k0_admit", "PORESEG_WIDE_BS": "wide_bs",
+    "PORESEG_K0_SHARED": "k0_shared", "PORESEG_K0_MAX": "k0_admit", "PORESEG_K0_SETS": "k0_sets", "PORESEG_WIDE_BS": "wide_bs",
     "PORESEG_BRIDGE_SINGLE": "bridge_single", "PORESEG_TREE_TAIL": "tree_tail_pct", "PORESEG_FILTER_FUSED": "filter_fused",
     "PORESEG_UPLOAD": "upload_by_kernel", "PORESEG_TIMING": "timing", "PORESEG_TREE_MW": "tree_mw",
     "PORESEG_TREE_JPW": "tree_jobs_per_wave", "PORESEG_SLOTS_PCT": "slots_pct", "PORESEG_BRIDGE_EXT": "bridge_ext",

@@ -17,31 +17,35 @@ __global__ __launch_bounds__(64) void squat_kernel(const volatile int *flag, uns
 {
     hold<REGS>();
     if (threadIdx.x == 0) atomicAdd(alive, 1ull);
-    for (int spin = 0; spin < 200000000; ++spin) {           // (a guard: ~ tens of seconds)
-        if (__hip_atomic_load(const_cast<const int *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        __builtin_amdgcn_s_sleep(64);
+    for (int spin = 0; spin < 200000; ++spin) {             // (a guard: ~3 s -- the first version waited 400 s for a flag it never saw)
+        // (the flag lives in DEVICE memory: the first version polled pinned host memory from 1 024+ waves and choked the host link --
+        //  the calls' own uploads and result copies crawled, 0.11 -> 4 ms per step, which had nothing to do with registers)
+        if (__hip_atomic_load(const_cast<const int *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+#pragma unroll
+        for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
     }
     hold<REGS>();
 }
 
-static int *g_flag = nullptr;
+static int *g_flag = nullptr;          // device memory
+static hipStream_t g_stop_stream = nullptr;
 static unsigned long long *g_alive = nullptr;
 static hipStream_t g_stream = nullptr;
 
 extern "C" int squat_start(int waves_per_simd, int regs)
 {
     if (!g_flag) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&g_flag), sizeof(int), hipHostMallocMapped) != hipSuccess) return -1;
+        if (hipMalloc(reinterpret_cast<void **>(&g_flag), sizeof(int)) != hipSuccess) return -1;
+        if (hipStreamCreateWithFlags(&g_stop_stream, hipStreamNonBlocking) != hipSuccess) return -1;
         if (hipMalloc(reinterpret_cast<void **>(&g_alive), sizeof(unsigned long long)) != hipSuccess) return -1;
         if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return -1;
     }
-    *g_flag = 0;
+    (void)hipMemsetAsync(g_flag, 0, sizeof(int), g_stream);
     (void)hipMemsetAsync(g_alive, 0, sizeof(unsigned long long), g_stream);
     hipDeviceProp_t p;
     (void)hipGetDeviceProperties(&p, 0);
     const unsigned grid = static_cast<unsigned>(p.multiProcessorCount) * 4u * static_cast<unsigned>(waves_per_simd);
-    int *dflag = nullptr;
-    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&dflag), g_flag, 0) != hipSuccess) return -2;
+    int *dflag = g_flag;
     if (grid == 0) return 0;
     switch (regs) {
     case 64: hipLaunchKernelGGL(squat_kernel<64>, dim3(grid), dim3(64), 0, g_stream, dflag, g_alive); break;
@@ -58,13 +62,15 @@ extern "C" int squat_start(int waves_per_simd, int regs)
 extern "C" long long squat_alive(void)
 {
     unsigned long long v = 0;
-    if (!g_alive || hipMemcpy(&v, g_alive, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!g_alive || hipMemcpyAsync(&v, g_alive, sizeof v, hipMemcpyDeviceToHost, g_stop_stream) != hipSuccess || hipStreamSynchronize(g_stop_stream) != hipSuccess) return -1;
     return static_cast<long long>(v);
 }
 
 extern "C" int squat_stop(void)
 {
     if (!g_flag) return 0;
-    __atomic_store_n(g_flag, 1, __ATOMIC_SEQ_CST);
+    static const int one = 1;
+    if (hipMemcpyAsync(g_flag, &one, sizeof(int), hipMemcpyHostToDevice, g_stop_stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(g_stop_stream) != hipSuccess) return -1;
     return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : -1;
 }
