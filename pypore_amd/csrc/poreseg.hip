@@ -1303,6 +1303,35 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo)
     return PS_OK;
 }
 
+#ifdef PS_DIAG
+// (diagnostic library, round 6 experiment) the context's own stream re-created on a subset of the compute units: `count` CUs
+// starting at bit `first` of the device's CU mask, every `stride`-th bit, or all the others (hipExtStreamCreateWithCUMask); count 0:
+// an ordinary stream again.  What it showed (tools/r6/cu_mask_probe.py, docs/ROUND_6.md): contiguous masks work (64 CUs = two
+// XCDs: K0 at 1.9 TB/s), a pool of sixteen masked streams + masked front streams for K0 does not (every masked stream is a
+// hardware queue of its own: 0.67 ms per step) -- K0 on CUs of its own is not reachable through stream masks.
+static int diag_mask_stream(ps_ctx *ctx, hipStream_t *st, int first, int count, int stride, bool invert)
+{
+    if (ctx->n_cu <= 0) {
+        hipDeviceProp_t prop;
+        ctx->n_cu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(*st));
+    HIP_TRY(ctx, hipStreamDestroy(*st));
+    *st = nullptr;
+    if (count <= 0) { HIP_TRY(ctx, hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return PS_OK; }
+    const int words = (ctx->n_cu + 31) / 32;
+    std::vector<uint32_t> mask(static_cast<size_t>(words), invert ? 0xffffffffu : 0u);
+    for (int k = 0; k < count; ++k) {
+        const int b = first + k * std::max(1, stride);
+        if (b < 0 || b >= ctx->n_cu) continue;
+        if (invert) mask[b >> 5] &= ~(1u << (b & 31)); else mask[b >> 5] |= 1u << (b & 31);
+    }
+    if (ctx->n_cu & 31) mask[words - 1] &= (1u << (ctx->n_cu & 31)) - 1u;
+    HIP_TRY(ctx, hipExtStreamCreateWithCUMask(st, static_cast<uint32_t>(words), mask.data()));
+    return PS_OK;
+}
+#endif
+
 int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx || !name) return PS_ERR_ARG;
@@ -1341,6 +1370,10 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
 #ifdef PS_DIAG
     else if (n == "dbg_phase" && value >= 0 && value <= 2) ctx->dbg_phase = static_cast<int>(value);
     else if (n == "dbg_k0_nogrp") ctx->dbg_k0_nogrp = value != 0;
+    // cu_mask: value = first | count << 12 | stride << 24 | invert << 32: the context's OWN stream on those CUs only (count 0: all)
+    else if (n == "cu_mask" && ctx->own_stream)
+        return diag_mask_stream(ctx, &ctx->stream, static_cast<int>(value & 0xfff), static_cast<int>((value >> 12) & 0xfff),
+                                static_cast<int>((value >> 24) & 0xff), ((value >> 32) & 1) != 0);
     else if (n == "k0_sets" && value >= 2 && value <= 4) ctx->k0_sets = static_cast<int>(value);
     else if (n == "scan_lds_pad" && value >= 0 && value <= 65536) ctx->scan_lds_pad = static_cast<int>(value);
     else if (n == "rep_eval" && value >= 1) ctx->rep_eval = static_cast<int>(value);
