@@ -115,8 +115,9 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * kernels of all such contexts run back to back (they are bound by HBM: side by side they only share it) and the
  * context's own stream takes over behind an event; 0 (default) everything on the context's stream -- a host that keeps
  * several contexts busy (engine.StreamPool) sets it for the duration of its runs (measured slower: nothing sets it);
- * "k0_admit" M > 0: at most M calls of this device have their K0 in flight at a time (a call waits for a permit before
- * it queues K0; the permit comes back when K0's event has completed), 0 (default) no limit -- engine.StreamPool sets 3;
+ * "k0_admit" M > 0: at most M calls of this device have their K0 in flight at a time -- enforced on the device (round 6): a
+ * call queues a wait for the K0 of the call M tickets before it in front of its own K0 (hipStreamWaitEvent); the host thread
+ * never waits --, 0 (default) no limit; engine.StreamPool sets 3 ("shared_device");
  * "bridge_ext" 1 (default): seams whose bridge ran out of anchors (256 without meeting a downstream tile's chain:
  * densely stepped data) and open tiles entered exactly at their start are continued on the device -- up to four rounds,
  * 16 384 more anchors per seam -- before the call falls back to the host stitch, 0 straight to the host stitch;

@@ -104,7 +104,8 @@ struct ps_ctx {
     float noise_k = 0.1f;     // near-tie accounting of the wide route (DevCfg::noise_k; PORESEG_NOISE_K)
     int k0_admit = 0;         // > 0: at most this many calls of the device have their K0 in flight (K0Gate); 0: no limit
     int k0_sets = 2;          // register sets of a persistent K0 wave (seg_bs.hpp: blocksum_kernel<DT, NS>); 3 / 4 in the diagnostic library only (rejected)
-    bool gate_held = false;
+    bool chain_held = false;  // this call has a ticket of the device's K0 chain (K0Chain) and has not recorded its event yet
+    unsigned long long chain_ticket = 0;
     bool defer_sync = false;  // (internal) ps_filter_requantise_batch: the filter entry only queues its kernels -- no status clear, copy, sync
     int scan_lds_pad = 0;     // diagnostics (libporeseg_diag.so only: option scan_lds_pad): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
     int k0_unaligned = 1;     // K0's fast route loads 16 bytes from sample-aligned addresses: probed once per device at ps_create (k0_unaligned_probe);
@@ -218,67 +219,48 @@ FrontStream *front_for(ps_ctx *ctx)
     return f;
 }
 
-// K0 admission (ps_ctx::k0_admit): at most that many calls of a device have their K0 in flight at a time.  K0 is bound by HBM:
-// T of them side by side only share the same bytes per second, and all of them -- with every call's scan kernels behind
-// them -- finish late together.  A call reserves a slot before it queues K0 and publishes the event it records behind K0; the
-// slot comes back when that event has completed, which ANY thread that waits at the gate finds out (hipEventQuery) -- not the
-// holder: a holder that the host's scheduler parks between two launches must not keep the others out (the first version,
-// where the holder waited for its own event and then gave the slot back, produced a run at twice the usual time now and then).
-struct K0Gate {
-    struct Slot { const ps_ctx *owner; hipEvent_t ev; bool recorded; };
+// K0 admission (ps_ctx::k0_admit): at most M calls of a device have their K0 in flight at a time.  K0 is bound by HBM: T of them
+// side by side only share the same bytes per second, and all of them -- with every call's scan kernels behind them -- finish late
+// together (sixteen contexts: 0.188 -> 0.175 ms per step with M = 3, round 5).  Round 6: ON THE DEVICE.  The calls of a device
+// take tickets; call t queues, in front of its K0, a wait for the event recorded behind the K0 of call t - M (hipStreamWaitEvent:
+// a barrier packet in its own queue).  Round 5's gate had host threads poll hipEventQuery every 25 us under one mutex and could
+// spin forever on a faulted device; here the host thread never waits, so there is nothing to time out or to leak: a
+// call that fails between its ticket and its record leaves a ticket nobody finds recorded, and whoever looks for it does not
+// wait.  Same step time as the polling gate (0.1709 against 0.1690 ms, 5 interleaved pairs: profiles/r06_experiments).
+struct K0Chain {
+    static constexpr int RING = 64;
     std::mutex mu;
-    std::vector<Slot> slots;
+    hipEvent_t ev[RING] = {};
+    unsigned long long gen[RING];                       // ticket whose K0 the event was last recorded behind (+1; 0: never)
+    unsigned long long next = 0;
+    bool made = false;
 };
-K0Gate g_gate[16];
-void gate_drop(K0Gate &g, const ps_ctx *owner)
+K0Chain g_chain[16];
+int chain_enter(ps_ctx *ctx, int device, int max_in_flight, hipStream_t st, unsigned long long *ticket)
 {
-    for (size_t i = 0; i < g.slots.size();)
-        if (g.slots[i].owner == owner) g.slots.erase(g.slots.begin() + static_cast<long>(i)); else ++i;
-}
-// Returns PS_OK with a permit held, or PS_ERR_HIP when the device reports an error for a K0 event (a fault or a hang: the slot
-// is given back, the error goes to the caller -- nobody spins on a dead device).  The wait is bounded: a caller that has not
-// been admitted after GATE_WAIT_MS goes ahead WITHOUT a permit (admission is a throughput measure, never a correctness one).
-constexpr int GATE_WAIT_MS = 250;
-int gate_enter(ps_ctx *ctx, int device, int max_in_flight, hipEvent_t ev, bool *held)
-{
-    K0Gate &g = g_gate[device & 15];
-    *held = false;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spin = 0;; ++spin) {
-        hipError_t bad = hipSuccess;
-        {
-            std::lock_guard<std::mutex> lk(g.mu);
-            if (spin == 0) gate_drop(g, ctx);          // (a slot of this context's previous call: that call has ended)
-            for (size_t i = 0; i < g.slots.size();) {
-                hipError_t q = g.slots[i].recorded ? hipEventQuery(g.slots[i].ev) : hipErrorNotReady;
-                if (q == hipSuccess) g.slots.erase(g.slots.begin() + static_cast<long>(i));
-                else if (q != hipErrorNotReady) { bad = q; g.slots.erase(g.slots.begin() + static_cast<long>(i)); }   // (device error: the slot goes back)
-                else ++i;
-            }
-            (void)hipGetLastError();                   // (hipErrorNotReady of the queries)
-            if (bad == hipSuccess && static_cast<int>(g.slots.size()) < max_in_flight) { g.slots.push_back({ctx, ev, false}); *held = true; return PS_OK; }
-        }
-        if (bad != hipSuccess)
-            return fail(ctx, PS_ERR_HIP, "K0 admission: hipEventQuery failed: %s (%s:%d)", hipGetErrorString(bad), __FILE__, __LINE__);
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(GATE_WAIT_MS)) return PS_OK;   // (no permit: go ahead)
-        // (a K0 takes 100-300 us: a look every few tens of microseconds is plenty, and thirteen waiting threads that hammer
-        //  the runtime with queries get in the way of the three that are launching)
-        std::this_thread::sleep_for(std::chrono::microseconds(25));
+    K0Chain &c = g_chain[device & 15];
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.made) {
+        for (int i = 0; i < K0Chain::RING; ++i) { HIP_TRY(ctx, hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming)); c.gen[i] = 0; }
+        c.made = true;
     }
+    const unsigned long long t = c.next++;
+    *ticket = t;
+    const int m = std::min(max_in_flight, K0Chain::RING / 2);
+    if (t >= static_cast<unsigned long long>(m)) {
+        const unsigned long long w = t - static_cast<unsigned long long>(m);
+        if (c.gen[w % K0Chain::RING] == w + 1) HIP_TRY(ctx, hipStreamWaitEvent(st, c.ev[w % K0Chain::RING], 0));
+    }
+    return PS_OK;
 }
-void gate_publish(const ps_ctx *ctx, int device)     // K0's event has been recorded
+int chain_publish(ps_ctx *ctx, int device, hipStream_t st, unsigned long long ticket)     // K0 has been queued on st
 {
-    K0Gate &g = g_gate[device & 15];
-    std::lock_guard<std::mutex> lk(g.mu);
-    for (auto &sl : g.slots) if (sl.owner == ctx) sl.recorded = true;
+    K0Chain &c = g_chain[device & 15];
+    std::lock_guard<std::mutex> lk(c.mu);
+    HIP_TRY(ctx, hipEventRecord(c.ev[ticket % K0Chain::RING], st));
+    c.gen[ticket % K0Chain::RING] = ticket + 1;
+    return PS_OK;
 }
-void gate_leave(const ps_ctx *ctx, int device)       // the call has ended (or failed): whatever it still holds goes back
-{
-    K0Gate &g = g_gate[device & 15];
-    std::lock_guard<std::mutex> lk(g.mu);
-    gate_drop(g, ctx);
-}
-
 // status word + work counters live in ctx->small: [0] status (u32, padded to 8), [1..3] work, [4] dense count
 // (hdr: the stitch header lives behind the counters so that one copy brings both back)
 // (SMALL_TAIL bytes behind it hold the per-event offsets of small batches, so that one copy brings everything back)
@@ -959,7 +941,11 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
                                     ctx->ev_off.as<int64_t>(), ctx->ev_len.as<int64_t>(), ctx->ev_boff.as<int64_t>(), n_ev, sample_end, \
                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(),                                   \
                                     reinterpret_cast<unsigned *>(&sm->status), k0_grp)
-        if (ctx->k0_admit > 0 && !front) { const int grc = gate_enter(ctx, ctx->device, ctx->k0_admit, ctx->ev_front[1], &ctx->gate_held); if (grc) return grc; }
+        if (ctx->k0_admit > 0 && !front) {
+            const int grc = chain_enter(ctx, ctx->device, ctx->k0_admit, fs, &ctx->chain_ticket);
+            if (grc) return grc;
+            ctx->chain_held = true;
+        }
 #ifdef PS_DIAG
         const bool skip_k0 = ctx->dbg_phase == 1 && reuse;     // diagnostics: the previous call's digest
         uint4 *const k0_grp = (ctx->dbg_k0_nogrp && reuse) ? nullptr : const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp));
@@ -985,9 +971,10 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
         cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
     }
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], fs));
-    if (ctx->gate_held) {                              // K0 is behind this event: whoever waits at the gate sees it complete
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_front[1], fs));
-        gate_publish(ctx, ctx->device);
+    if (ctx->chain_held) {                             // K0 is behind this event: the call M tickets later waits for it on the device
+        ctx->chain_held = false;
+        const int crc = chain_publish(ctx, ctx->device, fs, ctx->chain_ticket);
+        if (crc) return crc;
     }
 #ifdef PS_DIAG
     if (ctx->dbg_phase == 2) {                           // diagnostics: K0 only
@@ -1140,13 +1127,13 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
     if (ctx->timing >= 2 && hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]) == hipSuccess) ctx->ms[4] = ms;     // device stitch incl. header sync
     return rc;
 }
-// (whatever way the call ends: a K0 permit that is still held goes back)
+// (whatever way the call ends: a ticket of the K0 chain that was not recorded is forgotten)
 int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
                         std::chrono::steady_clock::time_point t_begin)
 {
     const int rc = device_stitch_batch_(ctx, cfg_in, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
-    if (ctx->gate_held) { ctx->gate_held = false; gate_leave(ctx, ctx->device); }
+    ctx->chain_held = false;
     return rc;
 }
 }  // namespace

@@ -18,7 +18,7 @@ n = 100_000_000
 params = _lib.split_params(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10., sampling_freq=1e5)
 pool = engine.StreamPool(0, T)
 ctx0 = pool.contexts[0]
-defaults = {"gather_fused": 1, "download_by_kernel": 1, "k0_unaligned": 1, "k0_sets": 2, "k0_admit": 3, "k0_waves": 1, "lat_help": 0, "cu_split": 0}
+defaults = {"gather_fused": 1, "download_by_kernel": 1, "k0_unaligned": 1, "k0_sets": 2, "k0_admit": 3, "k0_waves": 1, "lat_help": 0, "k0_chain": 1}
 traces = []
 for t in range(T):
     sd = 2024 + 1000 * t
@@ -31,18 +31,13 @@ import gc; gc.collect(); gc.freeze()
 ref = pool.run(4 * T, job)[-T:]
 
 
-POOL_OPTS = ("k0_sets", "k0_admit", "k0_waves", "lat_help", "k0_shared", "cu_split")
+POOL_OPTS = ("k0_sets", "k0_admit", "k0_waves", "lat_help", "k0_shared", "k0_chain")
 
 
 def apply(setting):
     full = {k: setting.get(k, defaults.get(k, 0)) for k in names}
     # options of a shared chip go through the pool (it re-configures its contexts around every run); the others are set directly
-    # (cu_split first: it sets k0_waves / k0_admit itself, explicit values of the setting then override them)
-    pool.overrides = dict(sorted(((k, v) for k, v in full.items() if k in POOL_OPTS), key=lambda kv: kv[0] != "cu_split"))
-    if "cu_split" in full and full["cu_split"] > 0:
-        for k in ("k0_waves", "k0_admit"):
-            if k not in setting:
-                pool.overrides.pop(k, None)
+    pool.overrides = {k: v for k, v in full.items() if k in POOL_OPTS}
     pool._shared_now.clear()
     for cx in pool.contexts:
         for k, v in full.items():
