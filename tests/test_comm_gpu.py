@@ -68,3 +68,48 @@ def test_comm_library_world_of_one():
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     out = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "comm ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+CHILD2 = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+import torch
+from pypore_amd import _comm
+n = torch.cuda.device_count()
+assert n >= 2
+cap = 1024
+cs = _comm.Comm.all(2)                                   # ps_comm_init_all: one process drives both GPUs (ncclCommInitAll)
+assert [(c.world, c.rank) for c in cs] == [(2, 0), (2, 1)]
+send, recv = [], []
+for r in range(2):
+    torch.cuda.set_device(r)
+    s = torch.zeros(cap, dtype=torch.int32, device="cuda:%%d" %% r)
+    s[0] = 3 + r
+    s[_comm.HEADER:_comm.HEADER + 3 + r] = torch.arange(3 + r, dtype=torch.int32, device=s.device) * (r + 1) + 7
+    send.append(s); recv.append(torch.full((2 * cap,), -1, dtype=torch.int32, device=s.device))
+hs = (ctypes.c_void_p * 2)(*[c.handle for c in cs])
+sp = (ctypes.c_void_p * 2)(*[t.data_ptr() for t in send]); rp = (ctypes.c_void_p * 2)(*[t.data_ptr() for t in recv])
+st = (ctypes.c_void_p * 2)(*[torch.cuda.current_stream(r).cuda_stream for r in range(2)])
+_comm.check(_comm.lib().ps_gather_bounds_all(hs, 2, sp, rp, cap, st))
+for r in range(2):
+    torch.cuda.synchronize(r)
+    rows = recv[r].view(2, cap).cpu()
+    for q in range(2):                                   # every rank holds every rank's slot: count in element 0, payload from HEADER on
+        assert int(rows[q, 0]) == 3 + q and torch.equal(rows[q, _comm.HEADER:_comm.HEADER + 3 + q], send[q][_comm.HEADER:_comm.HEADER + 3 + q].cpu())
+for c in cs:
+    c.close()
+print("comm2 ok")
+"""
+
+
+def test_comm_library_two_ranks_in_one_process():
+    """the library's gather with MORE than one rank -- ps_comm_init_all over two GPUs driven by one process, the
+    grouped all-gather, every rank ends up with every rank's slot.  Needs two GPUs (skipped on the one-GPU boxes the builder
+    has; the driver's multi-chip run is where it executes)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "-c", CHILD2 % ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "comm2 ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
