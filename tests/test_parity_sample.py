@@ -178,3 +178,42 @@ def test_exact_route_on_device_filtered_events_equals_the_oracle_on_the_same_cur
         vs_golden += int(np.setxor1d(got, NPZ[case["name"]].astype(np.int64)).size)
     print("exact route on device-filtered events: 0 differences against the oracle on the same current; %d boundaries beside the "
           "goldens recorded on scipy's output (%d cases)" % (vs_golden, len(cases)))
+
+
+@pytest.mark.gpu
+def test_exact_route_edge_cases_against_the_oracle():
+    """ps_segment_exact_f64 where the reference's arithmetic turns odd: noise-free float64 steps (variances of exactly 0: -inf
+    logarithms, inf and NaN gains -- cparsers.pyx:169-177 takes `gain > min_gain`, so +inf wins and NaN never does), events
+    shorter than two minimum widths, an empty event, min_width 1, a window wider than the event; several events per call at odd
+    offsets.  The oracle is the same C doubles on the host."""
+    import torch
+    import oracle
+    from pypore_amd import _lib, engine
+    ctx = engine.context(0)
+    rng = np.random.RandomState(3)
+    third = 1.0 / 3.0
+    flat = np.concatenate([np.full(700, 10 * third), np.full(900, 7 * third), np.full(650, 11 * third)])          # exact steps, no noise
+    noisy = np.concatenate([rng.normal(50.1, 0.7, 5000), rng.normal(20.3, 0.7, 3000), rng.normal(35.7, 0.2, 4000)])
+    mostly_flat = np.concatenate([np.full(3000, 0.1), rng.normal(0.1, 1e-9, 2000), np.full(2500, 0.7)])
+    cases = [
+        (dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10.), [flat, noisy, mostly_flat]),
+        (dict(min_width=1, max_width=500, window_width=50, prior_segments_per_second=100.), [noisy[:900], flat[:400]]),
+        (dict(min_width=100, max_width=1000000, window_width=10000, prior_segments_per_second=10.), [noisy[:150], np.zeros(0), noisy[:201], noisy[:5000]]),
+        (dict(min_width=250, max_width=3000, window_width=1000, min_gain_per_sample=0.02), [noisy, flat]),
+    ]
+    for kw, evs in cases:
+        kw = dict(kw, sampling_freq=1e5)
+        starts, pos = [], 3
+        for x in evs:
+            starts.append(pos); pos += x.size + 5
+        buf = np.full(pos + 8, np.nan)                       # whatever lies between the events must not matter
+        for x, a in zip(evs, starts):
+            buf[a:a + x.size] = x
+        b, off = ctx.segment_exact_f64(torch.from_numpy(buf).cuda(), np.array(starts), np.array([x.size for x in evs]), _lib.split_params(**kw))
+        b = b.cpu().numpy()
+        for e, x in enumerate(evs):
+            ref = oracle.parse(x, **kw) if x.size else np.zeros(0, np.int32)
+            np.testing.assert_array_equal(b[off[e]:off[e + 1]], ref, err_msg="%s event %d (%d samples)" % (kw, e, x.size))
+    # no events at all
+    b, off = ctx.segment_exact_f64(torch.zeros(8, dtype=torch.float64, device="cuda"), np.zeros(0, np.int64), np.zeros(0, np.int64), _lib.split_params())
+    assert b.numel() == 0 and list(off) == [0]
