@@ -544,7 +544,7 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     const bool fused = d_hdr != nullptr && ctx->gather_fused;      // (device stitch: job index == item index)
     if (fused) {
-        const int64_t blocks = std::max<int64_t>((n_items + (1 << GS_LOG) - 1) >> GS_LOG, (static_cast<int64_t>(n_ev) + (1 << GS_LOG)) >> GS_LOG);
+        const int64_t blocks = (n_items >> GS_LOG) + 1;
         const unsigned gg = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(blocks, 1024)));
         hipLaunchKernelGGL(gather_scan_kernel, dim3(gg), dim3(1 << GS_LOG), 0, ctx->stream, ctx->items.as<Item>(),
                            ctx->tree_jobs.as<TreeJob>(), ctx->tree_counts.as<int32_t>(), ctx->tree_scratch.as<int32_t>(),

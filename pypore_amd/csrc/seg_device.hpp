@@ -2185,7 +2185,9 @@ __global__ __launch_bounds__(64) void gather_kernel(const Item *items, const Tre
 // counts per GS = 256 jobs in blk[] (a few hundred atomics per call: most jobs find nothing), so a workgroup places ITS 256
 // items from the block sums before it and a scan of its own 256 values -- no single-workgroup scan kernel between the
 // subtrees and the gather (item_scan_kernel waited ~100 us for a CU with sixteen free wave slots when sixteen calls were in
-// flight).  The per-event offsets bounds_off[e] = pos[first_item[e]] come out of the same sums, one thread each.
+// flight).  The per-event offsets bounds_off[e] = pos[first_item[e]] are written by the workgroup whose block holds
+// the event's first item (first_item ascends: two binary searches per block; a first version summed per event -- up to 255
+// dependent loads each -- and cost BASELINE config 2's 1 024 events 25 us).
 __global__ __launch_bounds__(256) void gather_scan_kernel(const Item *items, const TreeJob *jobs, const int32_t *counts,
                                                           const int32_t *scratch, long long n_items_host, int32_t *bounds,
                                                           int64_t cap, uint8_t *is_spine, const AsmHeader *hdr,
@@ -2194,22 +2196,18 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const Item *items, con
     constexpr int GS = 1 << GS_LOG;
     __shared__ long long wsum[GS / 64];
     __shared__ int ws[GS / 64];
+    __shared__ long long pos_s[GS];
+    __shared__ int ev_lo_s, ev_hi_s;
     const bool failed = hdr && hdr->fail;              // failed / refused stitch: first_item is not valid either
     const long long n_items = dev_count(hdr, n_items_host);
     const int32_t *blk = counts + n_items_host;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (long long e = blockIdx.x * static_cast<long long>(GS) + tid; e <= n_ev; e += gridDim.x * static_cast<long long>(GS)) {
-        long long p = 0;
-        if (!failed) {
-            const long long fi = first_item[e];
-            const long long b = fi >> GS_LOG;
-            p = fi;
-            for (long long k = 0; k < b; ++k) p += blk[k];
-            for (long long j = b << GS_LOG; j < fi; ++j) p += items[j].job < 0 ? 0 : counts[j];
-        }
-        bounds_off[e] = p;
+    if (failed) {
+        for (long long e = blockIdx.x * static_cast<long long>(GS) + tid; e <= n_ev; e += gridDim.x * static_cast<long long>(GS)) bounds_off[e] = 0;
+        return;
     }
-    const long long nb = (n_items + GS - 1) >> GS_LOG;
+    // (the block that holds index n_items -- one past the last item -- runs too: events that start there, and the total)
+    const long long nb = (n_items >> GS_LOG) + 1;
     for (long long b = blockIdx.x; b < nb; b += gridDim.x) {
         long long part = 0;
         for (long long k = tid; k < b; k += GS) part += blk[k];
@@ -2226,11 +2224,21 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const Item *items, con
         for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
         if (lane == 0) wsum[wave] = part;
         if (lane == 63) ws[wave] = inc;
+        // the events whose first item lies in this block: first_item ascends with the event index (two binary searches)
+        if (tid < 2) {
+            const long long key = (b + tid) << GS_LOG;
+            int lo = 0, hi = n_ev + 1;                  // first e in [0, n_ev] with first_item[e] >= key
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (first_item[mid] < key) lo = mid + 1; else hi = mid; }
+            if (tid == 0) ev_lo_s = lo; else ev_hi_s = lo;
+        }
         __syncthreads();
         long long p = (b << GS_LOG) + inc - v;
 #pragma unroll
         for (int w = 0; w < GS / 64; ++w) { p += wsum[w]; if (w < wave) p += ws[w]; }
-        __syncthreads();                               // wsum / ws are rewritten by the next block
+        pos_s[tid] = p;                                // (threads beyond the last item: the position one past it -- their v is 0)
+        __syncthreads();
+        for (int e = ev_lo_s + tid; e < ev_hi_s; e += GS) bounds_off[e] = pos_s[first_item[e] - (b << GS_LOG)];
+        __syncthreads();                               // wsum / ws / pos_s are rewritten by the next block
         const int32_t *src = cnt ? scratch + jobs[it.job].out_off : nullptr;
         // subtrees with many boundaries (filtered events: hundreds): the wave copies them together, one after the other
         unsigned long long big = __ballot(cnt > 16);

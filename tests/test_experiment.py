@@ -205,3 +205,35 @@ def test_experiment_currents_are_written_out_only_when_read(tmp_path):
     one.filter(1, 2000)
     np.testing.assert_array_equal(one.current, got)
     exp.delete()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["exact", "exact_on_near_tie"])
+def test_default_workflow_with_the_exact_route_equals_the_oracle_event_by_event(tmp_path, mode):
+    """Experiment.parse (detector at 90 pA, first-order 2 kHz Bessel filter) with a segmenter built for the reference's own
+    arithmetic on filtered events, SpeedyStatSplit(off_grid="exact" / "exact_on_near_tie"): File.parse_events filters on the
+    device and segments the filtered float64 currents through ps_segment_exact_f64 (one call per group of events; with
+    "exact_on_near_tie" only the groups whose fast run counted a near tie).  Every event's boundaries equal the oracle's on the
+    filtered current the user sees (ev.current, the file's offset included) -- with and without cutoff_freq in the segmenter
+    (without it a smooth current is cut every ~130 samples and near ties are common: the exact route is what decides them
+    like the reference) -- and equal what event.filter(); event.parse() gives one event at a time."""
+    counts, _ = synth.file_trace_counts(1_200_000, 52)
+    path = os.path.join(str(tmp_path), "exact.abf")
+    abf.write_abf(path, counts.astype(np.int16), adc_range=10.0, adc_resolution=32768, instrument_scale=0.0005,
+                  signal_gain=20.0, instrument_offset=1.25, signal_offset=0.5)
+    for seg_kw in (dict(prior_segments_per_second=10, cutoff_freq=2000.), dict(prior_segments_per_second=10)):
+        exp = Experiment([path])
+        exp.parse(segmenter=SpeedyStatSplit(off_grid=mode, **seg_kw), verbose=False)
+        file = exp.files[0]
+        assert file.n >= 1
+        for ev in file.events:
+            assert ev.filtered and ev.n >= 1
+            got = [int(round(s.start * file.second)) for s in ev.segments[1:]]
+            ref = oracle.parse(np.asarray(ev.current, dtype=np.float64), **seg_kw)
+            np.testing.assert_array_equal(got, ref, err_msg="%s %s" % (mode, seg_kw))
+            a, n = int(round(ev.start * file.second)), len(ev.current)
+            one = Event(current=file.current[a:a + n], start=ev.start, end=ev.end, duration=ev.duration, second=file.second, file=file)
+            one.filter(1, 2000)
+            one.parse(SpeedyStatSplit(off_grid=mode, **seg_kw))
+            assert [int(round(s.start * file.second)) for s in one.segments[1:]] == got
+        exp.delete()
