@@ -831,11 +831,24 @@ def main():
             fres = pool.run(kf, fstep)
             torch.cuda.synchronize()
             tf = (time.perf_counter() - t1) / kf
+
+            def fstep2(cx, k, t):                        # the two calls of rounds 3-5 (two passes over the samples), for comparison
+                return pipeline.segment_file_trace(ftraces[t], synth.QUANTUM, params, threshold=90.0, ctx=cx, single_pass=False)[2]
+
+            fres2 = pool.run(2 * T, fstep2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pool.run(kf, fstep2)
+            torch.cuda.synchronize()
+            tf2 = (time.perf_counter() - t1) / kf
+            same_two = bool(torch.equal(fres[-1], fres2[(kf - 1) % T]))     # (job k runs on trace k % T)
             out["int16_file"] = {
                 "workload": "BASELINE config 3: one %.0e-sample int16 .abf-shaped trace per stream @100 kHz, lambda_event_parser("
                             "threshold=90) -> per-event SpeedyStatSplit, end to end on the GPU, %d batches in flight" % (n, T),
                 "ms_per_step": round(tf * 1e3, 4), "value": round(n / tf / 1e6, 2), "unit": "Msamples/s", "steps": kf,
                 "boundaries": int(fres[-1].numel()),
+                "route": "ps_detect_segment_trace: one pass over the samples (K0 over the whole trace serves the detector and every event)",
+                "two_calls_ms_per_step": round(tf2 * 1e3, 4), "two_calls_same_boundaries": same_two,
                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": 2 * n, "achieved": round(2 * n / tf / 1e9, 2),
                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(2 * n / tf / HBM_PEAK, 5)}}
             del ftraces

@@ -131,6 +131,10 @@ int ps_set_tiling(ps_ctx *ctx, int64_t tile_len, int64_t halo);
  * "shared_device" n: ONE call for a host that keeps n contexts busy on one device (a pool of host threads, one context
  * each): n > 1 sets k0_waves 1, lat_help 0 and, for n > 3, k0_admit 3 -- the measured settings of a shared chip
  * (INTEGRATION.md has the table) --, n <= 1 restores the defaults of a lone context (k0_waves 0, lat_help 1, k0_admit 0);
+ * "single_pass" 1 (default): ps_detect_segment_trace streams a file trace once (see there), 0: it makes the two calls;
+ * "gather_fused" 1 (default): the gather places its items from per-256-job count sums (no scan kernel in front of it), 0: rounds
+ * 2-5's item scan + gather; "download_by_kernel" 1 (default): the status block returns by a kernel writing pinned memory;
+ * "k0_unaligned" 0: K0's fast route only from 16-byte-aligned addresses (1: whatever the probe at ps_create said);
  * "debug" 1: the library reports on stderr which occupancy it found and which seams gave up (prints only);
  * "slots_pct" 1..100 (default 100) share of the resident wave slots the single-wave scan kernels are launched on;
  * "tree_jobs_per_wave" (default 4) subtree kernel: jobs / this many of its slots work, between half and all of them;
@@ -245,6 +249,23 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
                      double threshold, int64_t min_duration, double min_current,
                      int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out);
 
+/* File.parse + Event.parse for every event of a whole file trace in ONE call and ONE pass over its samples (round 6):
+ * ps_detect_events followed by ps_segment_events on the events it found, with the same results -- events (h_starts,
+ * h_lengths, *n_events_out as ps_detect_events), boundaries (d_bounds / cap / h_bounds_off[n_events + 1] as ps_segment_events;
+ * h_bounds_off must have room for ev_cap + 1 entries), optional statistics.  The block-sum kernel K0 runs once over the whole
+ * trace (blocks aligned to the trace) and judges every 8-sample block against the threshold on its way (2 bits per block: all
+ * below, all at or above, mixed; min / max per 1 024 samples); the detector reads those bits -- 1/64 of the samples' bytes --
+ * and the samples of the mixed blocks only; the events -- which start at any sample -- are segmented from the same digest in
+ * coordinates shifted by (start mod 8).  Replaces the loop `for event in file.parse(lambda_event_parser(threshold)): event.parse(SpeedyStatSplit(...))`
+ * (parsers.py:124-155, DataTypes.py:589-602, 978-984).  Takes the two calls by itself when the block-sum scan does not apply
+ * (min_width < 8, window_width > 64 512, options "scan_bs" 0 / "mode" 1 / "stitch_host" 1 / "single_pass" 0) or when a count of
+ * the trace lies 2^14 or more from its first one (ps_get_timings counters[7] = 3 then). */
+int ps_detect_segment_trace(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                            double threshold, int64_t min_duration, double min_current,
+                            const ps_split_params *params,
+                            int64_t *h_starts, int64_t *h_lengths, int64_t ev_cap, int64_t *n_events_out,
+                            int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats);
+
 /* Replaces Event.filter (DataTypes.py:258-274): scipy.signal.bessel(order, cutoff / (sampling_freq / 2), btype='low',
  * analog=0) applied with scipy.signal.filtfilt (forward and backward, odd extension by padlen = 3 (order + 1), initial
  * state lfilter_zi * first value).  order 1 (the reference's default): the scan / fused-halo kernels; orders 2..8: one
@@ -312,7 +333,8 @@ int ps_align_batch(ps_ctx *ctx, const double *h_model_means, const double *h_mod
  * bridge / subtree kernels, [11] near ties: windows decided among fp64 contenders whose margin -- winner against the best
  * other candidate, or against min_gain -- is below 1e-9 * max(1, |gain|).  The device logarithm is not glibc's bit for bit
  * (gains differ by ~1e-11), so the reference could have decided such a window the other way; exact ties are decided like
- * the reference (first maximum wins, cparsers.pyx:175-177) and counted too; [12] chunk results (16 windows each) that the
+ * the reference (first maximum wins, cparsers.pyx:175-177) and counted too; -1 = not counted: the call ran on the
+ * LDS-window kernels (min_width < 8, option "scan_bs" 0 / "stitch_host" 1, counters[7] = 2, ps_segment_exact_f64); [12] chunk results (16 windows each) that the
  * look-ahead kernel's helpers published (option "lat_help"), [13] published chunks that a seam's owner took instead of
  * scanning them. */
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters);

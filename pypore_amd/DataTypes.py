@@ -159,7 +159,8 @@ class Event(Segment):
             with warnings.catch_warnings(record=True) as seen:
                 warnings.simplefilter("always", engine.NearTieWarning)
                 segs = parser.parse_batch([rounded], [centre])[0]
-            if any(issubclass(w.category, engine.NearTieWarning) for w in seen):
+            # (near_ties() < 0: the call ran where near ties are not counted -- option scan_bs 0, min_width < 8)
+            if any(issubclass(w.category, engine.NearTieWarning) for w in seen) or engine.context(parser._grid["device"]).near_ties() < 0:
                 segs = parser.parse_exact(np.asarray(self.current, dtype=np.float64))
             return self._adopt_filtered(segs)
         if isinstance(parser, SpeedyStatSplit):

@@ -16,7 +16,7 @@ PS_DTYPE_F64 = 2          # float64 pA on no grid: ps_filter_bessel input only
 PS_ALIGN_OK, PS_ALIGN_VALUE_ERROR, PS_ALIGN_INDEX_ERROR, PS_ALIGN_ZERO_DIVISION, PS_ALIGN_UNDEFINED = 0, 1, 2, 3, 4
 
 EXPORTS = ["ps_version", "ps_device_count", "ps_create", "ps_destroy", "ps_last_error", "ps_set_tiling", "ps_set_option",
-           "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_segment_batch_ex", "ps_segment_events", "ps_segment_exact_f64", "ps_detect_events", "ps_bounds_capacity",
+           "ps_synchronize", "ps_min_gain", "ps_segment_batch", "ps_segment_batch_ex", "ps_segment_events", "ps_segment_exact_f64", "ps_detect_events", "ps_detect_segment_trace", "ps_bounds_capacity",
            "ps_best_single_split", "ps_score_window", "ps_get_timings", "ps_synth_trace", "ps_filter_bessel",
            "ps_requantise", "ps_filter_requantise_batch", "ps_align_batch", "ps_audit_bounds", "ps_counters"]
 
@@ -66,6 +66,8 @@ def lib():
     L.ps_segment_events.argtypes = [vp, vp, P(SampleFormat), P(i64), P(i64), i32, P(SplitParams), vp, i64, P(i64), vp, vp]
     L.ps_segment_exact_f64.argtypes = [vp, vp, P(i64), P(i64), i32, P(SplitParams), vp, i64, P(i64)]
     L.ps_detect_events.argtypes = [vp, vp, P(SampleFormat), i64, dbl, i64, dbl, P(i64), P(i64), i64, P(i64)]
+    L.ps_detect_segment_trace.argtypes = [vp, vp, P(SampleFormat), i64, dbl, i64, dbl, P(SplitParams), P(i64), P(i64), i64, P(i64),
+                                          vp, i64, P(i64), vp]
     L.ps_bounds_capacity.argtypes = [P(i64), i32, i32]
     L.ps_bounds_capacity.restype = i64
     L.ps_best_single_split.argtypes = [vp, vp, P(SampleFormat), i64, P(dbl), P(i32)]

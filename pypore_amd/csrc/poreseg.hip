@@ -110,6 +110,7 @@ struct ps_ctx {
     int scan_lds_pad = 0;     // diagnostics (libporeseg_diag.so only: option scan_lds_pad): unused dynamic LDS per single-wave scan workgroup -- caps the scan waves per SIMD
     int k0_unaligned = 1;     // K0's fast route loads 16 bytes from sample-aligned addresses: probed once per device at ps_create (k0_unaligned_probe);
                               // option k0_unaligned 0 restores the 16-byte condition of rounds 1-4 (tests)
+    int single_pass = 1;      // 1 (round 6): ps_detect_segment_trace runs K0 once over the whole trace (detector + every event from one digest), 0: the two calls
     int gather_fused = 1;     // 1 (round 6): the gather places its items from per-256-job count sums (gather_scan_kernel), no item_scan_kernel; 0: rounds 2-5
     int download_by_kernel = 1;   // 1 (round 6): status block + per-event offsets go back by a kernel writing pinned memory, 0: hipMemcpyAsync
     int debug = 0;            // option debug: the library says on stderr which seams gave up, which occupancy it found (prints only; results unchanged)
@@ -153,6 +154,8 @@ struct ps_ctx {
     } tile_cache;
     DevBuf bsum, ev_info, chunk_mabs, ev_boff, blk_mm, grp, filt_fwd, filt_agg, filt_zin, up_dev;
     DevBuf align_in, align_scratch;
+    DevBuf ev_info_tr;        // single-pass file route (ps_detect_segment_trace): (centre, phase, first block) of the events cut out of a trace-aligned digest
+    DevBuf blk_cls, cls_mm;   // ... K0's verdict per block against the detector's threshold (2 bits), min / max per 128 blocks
     DevBuf pre_c;             // exact route (ps_segment_exact_f64): c and c2 of the call's samples, 16 B per sample
     int stitch_host = 0;      // 1: host stitch with halo tiles (the fallback path) always
     DevBuf ev_len, det_counts, det_tics, det_cand;
@@ -292,6 +295,7 @@ int make_cfg(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, in
     c->prune = ctx->prune;
     c->lds_cap = std::max(1, std::min(W, ctx->lds_max_samples));
     c->bsum = nullptr; c->ev_info = nullptr; c->chunk_tot = nullptr; c->blk_mm = nullptr; c->grp = nullptr; c->bs_wide = 0;
+    c->blk_cls = nullptr; c->cls_mm = nullptr; c->cls_kthr = 0;
     c->k0_unaligned = ctx->k0_unaligned;
     c->pre_c = nullptr; c->pre_c2 = nullptr;
     c->dbg = ctx->small.as<SmallLayout>()->stamp;
@@ -649,7 +653,9 @@ int finish_batch(ps_ctx *ctx, const DevCfg &cfg, size_t n_tj, int64_t n_items, i
     ctx->counters[6] = static_cast<int64_t>(hs.work2 >> 32);                                                   // of which full fp64 window scans (block-sum scan)
 #ifndef PS_STAMP
     for (int k = 0; k < 3; ++k) ctx->counters[8 + k] = static_cast<int64_t>(hs.life[3 * k + 1]);              // window scans of the spine / bridge / subtree kernels
-    ctx->counters[11] = static_cast<int64_t>(hs.stamp[0]);                                                     // near-tie decisions (seg_bs.hpp: bs_decide)
+    // near-tie decisions (seg_bs.hpp: bs_decide); -1: not counted -- the call ran on the LDS-window kernels, which decide every window
+    // by one fp64 scan and keep no margins (a caller that redoes near ties on the exact route redoes such a call)
+    ctx->counters[11] = cfg.bsum ? static_cast<int64_t>(hs.stamp[0]) : -1;
 #endif
     ctx->counters[12] = static_cast<int64_t>(hs.lat_ctl[4]);                                                   // look-ahead helpers: chunk results published
     ctx->counters[13] = static_cast<int64_t>(hs.lat_ctl[5]);                                                   // ... and taken by an owner instead of scanning
@@ -745,9 +751,12 @@ template <int NT, int DT> int launch_bridge(ps_ctx *ctx, const DevCfg &cfg, unsi
 // tree jobs, items) -- no host round trip before the final synchronisation.
 // Returns RC_FALLBACK when a seam could not be bridged on the device (rare); the caller then runs
 // the host-stitch pipeline, which repairs seams one by one.
+// digest_ready (round 6, ps_detect_segment_trace): the digest of the WHOLE trace is already in the context's buffers (K0 ran over
+// it as one event, trace-aligned blocks): no K0 here; the events get (centre of the trace, phase, first block) from
+// ev_info_trace_kernel and the scans run in shifted coordinates (seg_bs.hpp: scan_window_ph).
 int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
-                        std::chrono::steady_clock::time_point t_begin)
+                        std::chrono::steady_clock::time_point t_begin, bool digest_ready = false)
 {
     DevCfg cfg = cfg_in;
     const bool use_bs = bs_mode != 0;                  // 1: block-sum scan on the 32-bit digest, 2: on the 64-bit (wide) digest
@@ -907,7 +916,17 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
     SmallLayout *sm = ctx->small.as<SmallLayout>();
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
     if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[7], fs));
-    if (use_bs && nj) {
+    if (use_bs && nj && digest_ready) {
+        HIP_TRY(ctx, ctx->ev_info_tr.reserve(static_cast<size_t>(std::max(1, n_ev)) * sizeof(int4)));
+        hipLaunchKernelGGL(ev_info_trace_kernel, dim3(static_cast<unsigned>(std::min(64, (n_ev + 255) / 256))), dim3(256), 0, fs,
+                           ctx->ev_off.as<int64_t>(), n_ev, ctx->ev_info.as<int4>(), ctx->ev_info_tr.as<int4>());
+        HIP_TRY(ctx, hipGetLastError());
+        cfg.bsum = ctx->bsum.p;
+        cfg.ev_info = ctx->ev_info_tr.as<int4>();
+        cfg.chunk_tot = ctx->chunk_mabs.as<int4>();
+        cfg.grp = ctx->groups ? ctx->grp.p : nullptr;
+        cfg.blk_mm = d_stats ? ctx->blk_mm.as<int>() : nullptr;
+    } else if (use_bs && nj) {
         // K0: chunk-prefixed block sums (one streaming pass), per-event centre m, totals + max|k| per 256 blocks
         const int64_t nb_total = tc.nb_total;
         // (a wave of K0 takes 256 blocks; the digest arrays are padded to whole waves, +1: the end boundary)
@@ -1130,9 +1149,9 @@ int device_stitch_batch_(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const i
 // (whatever way the call ends: a ticket of the K0 chain that was not recorded is forgotten)
 int device_stitch_batch(ps_ctx *ctx, const DevCfg &cfg_in, int bs_mode, const int64_t *ev_start, const int64_t *ev_len, int32_t n_ev, int mw, int W,
                         int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats,
-                        std::chrono::steady_clock::time_point t_begin)
+                        std::chrono::steady_clock::time_point t_begin, bool digest_ready = false)
 {
-    const int rc = device_stitch_batch_(ctx, cfg_in, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin);
+    const int rc = device_stitch_batch_(ctx, cfg_in, bs_mode, ev_start, ev_len, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin, digest_ready);
     ctx->chain_held = false;
     return rc;
 }
@@ -1271,7 +1290,7 @@ void ps_destroy(ps_ctx *ctx)
                       &ctx->det_counts, &ctx->det_tics, &ctx->det_cand, &ctx->bsum, &ctx->ev_info, &ctx->chunk_mabs,
                       &ctx->ev_boff, &ctx->blk_mm, &ctx->grp, &ctx->filt_fwd, &ctx->filt_agg, &ctx->filt_zin, &ctx->up_dev,
                       &ctx->align_in, &ctx->align_scratch, &ctx->bridge_ext, &ctx->ext_slot, &ctx->ext_list,
-                      &ctx->lat_state, &ctx->lat_seam, &ctx->lat_res, &ctx->pre_c};
+                      &ctx->lat_state, &ctx->lat_seam, &ctx->lat_res, &ctx->pre_c, &ctx->ev_info_tr};
     for (DevBuf *b : bufs) b->release();
     ctx->h_meta.release(); ctx->h_dense.release(); ctx->h_small.release(); ctx->h_up.release(); ctx->h_hdr.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1346,6 +1365,7 @@ int ps_set_option(ps_ctx *ctx, const char *name, int64_t value)
         ctx->lat_help = sh ? 0 : 1;
         ctx->k0_admit = value > 3 ? 3 : 0;
     }
+    else if (n == "single_pass") ctx->single_pass = value != 0;
     else if (n == "gather_fused") ctx->gather_fused = value != 0;
     else if (n == "download_by_kernel") ctx->download_by_kernel = value != 0;
     else if (n == "debug") ctx->debug = value != 0;
@@ -1852,56 +1872,15 @@ int ps_audit_bounds(ps_ctx *ctx, const void *d_samples, const ps_sample_format *
 }
 
 // Replaces lambda_event_parser.parse with the default rules (parsers.py:124-155).
-int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
-                     double threshold, int64_t min_duration, double min_current,
-                     int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out)
+namespace {
+// The detector after its streaming pass: edges (sample positions where the mask flips) -> pieces longer than min_duration
+// (parsers.py:133) -> their extremes (piece_minmax_kernel: whole 4 096-sample chunks from the table the streaming pass left in
+// det_counts, the ragged ends from the samples) -> the rules min > min_current, max < threshold (:134-135).
+int events_from_edges(ps_ctx *ctx, const DevCfg &cfg, int64_t n, std::vector<int> &tics, double threshold, int64_t min_duration,
+                      double min_current, int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out)
 {
-    if (!ctx) return PS_ERR_ARG;
-    if (!n_events_out || n < 0 || n > 0x7fffffff || cap < 0 || (cap > 0 && (!h_starts || !h_lengths)))
-        return fail(ctx, PS_ERR_ARG, "bad argument");
-    *n_events_out = 0;
-    if (n == 0) return PS_OK;
-    if (!d_samples) return fail(ctx, PS_ERR_ARG, "d_samples is NULL");
-    DevCfg cfg;
-    int rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int nb = static_cast<int>((n + DET_CHUNK - 1) / DET_CHUNK);
     const bool f32 = cfg.dtype == PS_DTYPE_F32;
-    SmallLayout *sm = ctx->small.as<SmallLayout>();
-    unsigned *d_ntics = reinterpret_cast<unsigned *>(&sm->dense);
-    HIP_TRY(ctx, ctx->det_counts.reserve(static_cast<size_t>(nb) * sizeof(int2)));
-    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
-    size_t tics_cap = std::max<size_t>(ctx->det_tics.cap / sizeof(int), 1u << 16);
-    std::vector<int> tics;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        HIP_TRY(ctx, ctx->det_tics.reserve(tics_cap * sizeof(int)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
-        if (f32) hipLaunchKernelGGL((edge_scan_kernel<PS_DTYPE_F32>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold,
-                                    ctx->det_tics.as<int>(), d_ntics, static_cast<unsigned>(tics_cap), ctx->det_counts.as<int2>(),
-                                    reinterpret_cast<unsigned *>(&sm->status));
-        else     hipLaunchKernelGGL((edge_scan_kernel<PS_DTYPE_I16>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold,
-                                    ctx->det_tics.as<int>(), d_ntics, static_cast<unsigned>(tics_cap), ctx->det_counts.as<int2>(),
-                                    reinterpret_cast<unsigned *>(&sm->status));
-        HIP_TRY(ctx, hipGetLastError());
-        // speculative copy of the first edges together with the count: one sync in the common case
-        const size_t spec = std::min<size_t>(tics_cap, 4096);
-        HIP_TRY(ctx, ctx->h_dense.reserve(std::max(spec, static_cast<size_t>(1)) * sizeof(int)));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.p, ctx->det_tics.p, spec * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
-        rc = check_status(ctx, static_cast<unsigned>(hs.status));
-        if (rc) return rc;
-        const size_t ne = static_cast<unsigned>(hs.dense);
-        if (ne > tics_cap) { tics_cap = ne + 1024; continue; }          // list overflowed: rerun with room for all edges
-        tics.resize(ne);
-        if (ne <= spec) std::memcpy(tics.data(), ctx->h_dense.p, ne * sizeof(int));
-        else HIP_TRY(ctx, hipMemcpy(tics.data(), ctx->det_tics.p, ne * sizeof(int), hipMemcpyDeviceToHost));
-        break;
-    }
     std::sort(tics.begin(), tics.end());
-    // pieces between consecutive edges; keep the ones longer than min_duration (parsers.py:133)
     std::vector<int2> cand;
     int a = 0;
     for (size_t p = 0; p <= tics.size(); ++p) {
@@ -1934,6 +1913,201 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
     *n_events_out = kept;
     if (kept > cap) return fail(ctx, PS_ERR_CAPACITY, "event capacity %lld < %lld", static_cast<long long>(cap), static_cast<long long>(kept));
     return PS_OK;
+}
+
+// One streaming pass that leaves the edge list in `tics` and min / max per DET_CHUNK samples in det_counts.  by_blocks = false:
+// edge_scan_kernel over the samples; true (ps_detect_segment_trace): edge_blocks_kernel over the per-block extremes K0 left.
+int detect_edges(ps_ctx *ctx, const DevCfg &cfg, int64_t n, double threshold, bool by_blocks, std::vector<int> &tics,
+                 unsigned *status_out)
+{
+    const int nb = static_cast<int>((n + DET_CHUNK - 1) / DET_CHUNK);
+    const bool f32 = cfg.dtype == PS_DTYPE_F32;
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    unsigned *d_ntics = reinterpret_cast<unsigned *>(&sm->dense);
+    HIP_TRY(ctx, ctx->det_counts.reserve(static_cast<size_t>(nb) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->h_small.reserve(sizeof(SmallLayout)));
+    size_t tics_cap = std::max<size_t>(ctx->det_tics.cap / sizeof(int), 1u << 16);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(ctx, ctx->det_tics.reserve(tics_cap * sizeof(int)));
+        // (by_blocks: K0 ran just before on this stream and its status bits -- off grid, counts too wide -- are still wanted; the
+        //  edge count is still zero from the call's setup kernel on the first attempt)
+        if (!by_blocks) HIP_TRY(ctx, hipMemsetAsync(ctx->small.p, 0, sizeof(SmallLayout), ctx->stream));
+        else if (attempt > 0) HIP_TRY(ctx, hipMemsetAsync(&sm->dense, 0, sizeof(unsigned long long), ctx->stream));
+        const unsigned cls_grid = static_cast<unsigned>((((n + 7) / 8 + 63) / 64 + CLS_NT - 1) / CLS_NT);
+#define PS_EDGE(DTV)                                                                                                                        \
+        do {                                                                                                                                \
+            if (by_blocks) hipLaunchKernelGGL((edge_cls_kernel<DTV>), dim3(cls_grid), dim3(CLS_NT), 0, ctx->stream, cfg, n, threshold,      \
+                                              ctx->blk_cls.as<unsigned char>(), ctx->cls_mm.as<int2>(), ctx->ev_info.as<int4>(),            \
+                                              ctx->det_tics.as<int>(), d_ntics, static_cast<unsigned>(tics_cap),                            \
+                                              ctx->det_counts.as<int2>(), reinterpret_cast<unsigned *>(&sm->status));                       \
+            else hipLaunchKernelGGL((edge_scan_kernel<DTV>), dim3(nb), dim3(DET_NT), 0, ctx->stream, cfg, n, threshold,                     \
+                                    ctx->det_tics.as<int>(), d_ntics, static_cast<unsigned>(tics_cap), ctx->det_counts.as<int2>(),          \
+                                    reinterpret_cast<unsigned *>(&sm->status));                                                             \
+        } while (0)
+        if (f32) PS_EDGE(PS_DTYPE_F32); else PS_EDGE(PS_DTYPE_I16);
+#undef PS_EDGE
+        HIP_TRY(ctx, hipGetLastError());
+        // speculative copy of the first edges together with the count: one sync in the common case
+        const size_t spec = std::min<size_t>(tics_cap, 4096);
+        HIP_TRY(ctx, ctx->h_dense.reserve(std::max(spec, static_cast<size_t>(1)) * sizeof(int)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->small.p, sizeof(SmallLayout), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dense.p, ctx->det_tics.p, spec * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const SmallLayout hs = *ctx->h_small.as<SmallLayout>();
+        if (status_out) *status_out = static_cast<unsigned>(hs.status);
+        if (by_blocks && (static_cast<unsigned>(hs.status) & ST_WIDE_RANGE)) return PS_OK;      // (the caller takes the other route)
+        const int rc = check_status(ctx, static_cast<unsigned>(hs.status));
+        if (rc) return rc;
+        const size_t ne = static_cast<unsigned>(hs.dense);
+        if (ne > tics_cap) { tics_cap = ne + 1024; continue; }          // list overflowed: rerun with room for all edges
+        tics.resize(ne);
+        if (ne <= spec) std::memcpy(tics.data(), ctx->h_dense.p, ne * sizeof(int));
+        else HIP_TRY(ctx, hipMemcpy(tics.data(), ctx->det_tics.p, ne * sizeof(int), hipMemcpyDeviceToHost));
+        break;
+    }
+    return PS_OK;
+}
+}  // namespace
+
+int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                     double threshold, int64_t min_duration, double min_current,
+                     int64_t *h_starts, int64_t *h_lengths, int64_t cap, int64_t *n_events_out)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!n_events_out || n < 0 || n > 0x7fffffff || cap < 0 || (cap > 0 && (!h_starts || !h_lengths)))
+        return fail(ctx, PS_ERR_ARG, "bad argument");
+    *n_events_out = 0;
+    if (n == 0) return PS_OK;
+    if (!d_samples) return fail(ctx, PS_ERR_ARG, "d_samples is NULL");
+    DevCfg cfg;
+    int rc = make_cfg(ctx, d_samples, fmt, 1, 1, 2, 0.0, &cfg);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<int> tics;
+    rc = detect_edges(ctx, cfg, n, threshold, false, tics, nullptr);
+    if (rc) return rc;
+    return events_from_edges(ctx, cfg, n, tics, threshold, min_duration, min_current, h_starts, h_lengths, cap, n_events_out);
+}
+
+// File.parse + Event.parse for a whole file trace with ONE pass over its samples (round 6).  The two calls
+// ps_detect_events + ps_segment_events stream the samples twice: once for the detector's edges and extremes, once -- the 92 %
+// of them that lie in events -- for K0's block sums.  Here K0 runs over the WHOLE trace as one event (its blocks aligned to the
+// trace, per-block extremes on), the detector reads those 4 bytes per block instead of the samples (edge_blocks_kernel), and the
+// events it cuts out -- they start at any sample -- are segmented from the same digest: an event that starts ph = start mod 8
+// samples into a block is scanned in coordinates shifted by ph (EvRef::ph, scan_window_ph).  Same events, same boundaries, same
+// statistics as the two calls (tests/test_gpu_parity.py::test_single_pass_file_route...).  Falls back to the two calls by itself
+// when the block-sum scan does not apply (min_width < 8, W > 64 512, options) or the trace's counts leave the 32-bit digest
+// about its first sample (|k - k_0| >= 2^14: the sums are centred on the trace's first sample here, not on each event's).
+int ps_detect_segment_trace(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,
+                            double threshold, int64_t min_duration, double min_current, const ps_split_params *params,
+                            int64_t *h_starts, int64_t *h_lengths, int64_t ev_cap, int64_t *n_events_out,
+                            int32_t *d_bounds, int64_t cap, int64_t *h_bounds_off, ps_segstat *d_stats)
+{
+    if (!ctx) return PS_ERR_ARG;
+    if (!n_events_out || !params || !h_bounds_off || n < 0 || n > 0x7fffffff - 16 || ev_cap < 0 || cap < 0 ||
+        (ev_cap > 0 && (!h_starts || !h_lengths)) || (cap > 0 && !d_bounds))
+        return fail(ctx, PS_ERR_ARG, "bad argument");
+    *n_events_out = 0;
+    h_bounds_off[0] = 0;
+    if (n == 0) return PS_OK;
+    if (!d_samples) return fail(ctx, PS_ERR_ARG, "d_samples is NULL");
+    const auto t_begin = std::chrono::steady_clock::now();
+    double min_gain = 0;
+    int rc = ps_min_gain(params, &min_gain);
+    if (rc) return fail(ctx, rc, "reference assertion failed (cparsers.pyx:69-76)");
+    const int mw = params->min_width, maxw = params->max_width, W = params->window_width;
+    if (mw < 1 || W < 2) return fail(ctx, PS_ERR_ARG, "min_width must be >= 1 and window_width >= 2");
+    DevCfg cfg;
+    rc = make_cfg(ctx, d_samples, fmt, mw, maxw, W, min_gain, &cfg);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto two_calls = [&]() -> int {
+        int r2 = ps_detect_events(ctx, d_samples, fmt, n, threshold, min_duration, min_current, h_starts, h_lengths, ev_cap, n_events_out);
+        if (r2) return r2;
+        return ps_segment_events(ctx, d_samples, fmt, h_starts, h_lengths, static_cast<int32_t>(*n_events_out), params, d_bounds, cap,
+                                 h_bounds_off, d_stats, nullptr);
+    };
+    const bool use_bs = ctx->scan_bs && mw >= 8 && W <= 63 * 1024 && ctx->mode != MODE_EXACT && !ctx->stitch_host && ctx->single_pass &&
+                        !(ctx->wide_skip > 0 && fmt->quantum == ctx->wide_quantum);
+    if (!use_bs) return two_calls();
+    for (double &m : ctx->ms) m = 0;
+    for (int64_t &c : ctx->counters) c = 0;
+    ctx->d_is_spine = nullptr;
+    if (ctx->timing >= 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
+    // ---- K0 over the whole trace: one event [0, n), blocks aligned to the trace, per-block extremes on -------------------------
+    const bool f32 = cfg.dtype == PS_DTYPE_F32;
+    SmallLayout *sm = ctx->small.as<SmallLayout>();
+    const int64_t nb_total = (n + 7) / 8, nb_pad = k0_padded_blocks(nb_total);
+    HIP_TRY(ctx, ctx->bsum.reserve(std::max<size_t>(16384, static_cast<size_t>(nb_pad) * sizeof(uint2))));
+    HIP_TRY(ctx, ctx->ev_info.reserve(sizeof(int4)));
+    HIP_TRY(ctx, ctx->chunk_mabs.reserve(static_cast<size_t>(nb_pad / BS_CHUNK + 1) * sizeof(int4)));
+    if (d_stats) HIP_TRY(ctx, ctx->blk_mm.reserve(static_cast<size_t>(nb_pad) * sizeof(int)));
+    if (ctx->groups) HIP_TRY(ctx, ctx->grp.reserve(static_cast<size_t>(nb_pad / BS_GRP + 1) * sizeof(uint4)));
+    HIP_TRY(ctx, ctx->blk_cls.reserve(static_cast<size_t>(nb_pad / 4 + 64)));
+    HIP_TRY(ctx, ctx->cls_mm.reserve(static_cast<size_t>(nb_pad / BS_CHUNK + 2) * sizeof(int2)));
+    HIP_TRY(ctx, ctx->det_cand.reserve(4 * sizeof(int64_t)));
+    // below(k) <=> double(k) * q < threshold (below_thr): monotone in k, so there is ONE integer kthr with below(k) <=> k < kthr
+    int kthr;
+    {
+        const double q = cfg.q;
+        double kk = std::ceil(threshold / q);
+        kk = std::max(-2147483000.0, std::min(2147483000.0, kk));
+        long long k = static_cast<long long>(kk);
+        while (k > -2147483000LL && !(static_cast<double>(k - 1) * q < threshold)) --k;
+        while (k < 2147483000LL && static_cast<double>(k) * q < threshold) ++k;
+        kthr = static_cast<int>(k);
+    }
+    // (one launch: the status block cleared, the table of the call's one event -- the whole trace -- written)
+    hipLaunchKernelGGL(trace_setup_kernel, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<unsigned long long *>(ctx->small.p),
+                       static_cast<int>(sizeof(SmallLayout) / sizeof(unsigned long long)), ctx->det_cand.as<long long>(),
+                       static_cast<long long>(n), static_cast<long long>(nb_total));
+    HIP_TRY(ctx, hipGetLastError());
+    cfg.grp = ctx->groups ? ctx->grp.p : nullptr;
+    cfg.blk_mm = d_stats ? ctx->blk_mm.as<int>() : nullptr;
+    cfg.blk_cls = ctx->blk_cls.as<unsigned char>();
+    cfg.cls_mm = ctx->cls_mm.as<int2>();
+    cfg.cls_kthr = kthr;
+    if (ctx->n_cu <= 0) {
+        hipDeviceProp_t prop;
+        ctx->n_cu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    {
+        const unsigned k0_full = static_cast<unsigned>((nb_pad / K0_WB + K0_WAVES - 1) / K0_WAVES);
+        const unsigned k0_per_cu = static_cast<unsigned>(ctx->k0_waves) * (f32 ? 1u : 2u);
+        const unsigned k0_grid = ctx->k0_waves > 0 ? std::min(k0_full, k0_per_cu * static_cast<unsigned>(ctx->n_cu) * (4u / K0_WAVES)) : k0_full;
+        const int64_t *d_ev = ctx->det_cand.as<int64_t>();
+        if (ctx->k0_admit > 0) {
+            const int grc = chain_enter(ctx, ctx->device, ctx->k0_admit, ctx->stream, &ctx->chain_ticket);
+            if (grc) return grc;
+        }
+#define PS_K0T(DTV) hipLaunchKernelGGL((blocksum_kernel<DTV, 2>), dim3(k0_grid), dim3(64 * K0_WAVES), 0, ctx->stream, cfg, d_ev, d_ev + 1, d_ev + 2, 1, n, \
+                                     ctx->bsum.p, ctx->ev_info.as<int4>(), ctx->chunk_mabs.as<int4>(), reinterpret_cast<unsigned *>(&sm->status),          \
+                                     const_cast<uint4 *>(static_cast<const uint4 *>(cfg.grp)))
+        if (f32) PS_K0T(PS_DTYPE_F32); else PS_K0T(PS_DTYPE_I16);
+#undef PS_K0T
+        HIP_TRY(ctx, hipGetLastError());
+        if (ctx->k0_admit > 0) { const int crc = chain_publish(ctx, ctx->device, ctx->stream, ctx->chain_ticket); if (crc) return crc; }
+    }
+    // ---- the detector on K0's verdicts per block ----------------------------------------------------------------------------
+    std::vector<int> tics;
+    unsigned st = 0;
+    rc = detect_edges(ctx, cfg, n, threshold, true, tics, &st);
+    if (rc) return rc;
+    if (st & ST_WIDE_RANGE) { ctx->counters[7] = 3; const int r2 = two_calls(); ctx->counters[7] = 3; return r2; }    // counts too wide about the trace's first sample
+    rc = events_from_edges(ctx, cfg, n, tics, threshold, min_duration, min_current, h_starts, h_lengths, ev_cap, n_events_out);
+    if (rc) return rc;
+    const int32_t n_ev = static_cast<int32_t>(*n_events_out);
+    if (n_ev == 0) return PS_OK;
+    for (int e = 0; e < n_ev; ++e)
+        if (h_lengths[e] > 0x7fffffff - 2LL * W - 16) return fail(ctx, PS_ERR_ARG, "event %d length %lld out of range", e, static_cast<long long>(h_lengths[e]));
+    // ---- every event from the trace's digest ----------------------------------------------------------------------------------
+    cfg.bsum = ctx->bsum.p;
+    cfg.blk_cls = nullptr;
+    rc = device_stitch_batch(ctx, cfg, 1, h_starts, h_lengths, n_ev, mw, W, d_bounds, cap, h_bounds_off, d_stats, t_begin, true);
+    if (rc == RC_FALLBACK || rc == RC_WIDE) {          // (a seam the device could not mend: the two calls, with the host stitch behind them)
+        return ps_segment_events(ctx, d_samples, fmt, h_starts, h_lengths, n_ev, params, d_bounds, cap, h_bounds_off, d_stats, nullptr);
+    }
+    return rc;
 }
 
 int ps_get_timings(const ps_ctx *ctx, double *ms, int32_t n_ms, int64_t *counters, int32_t n_counters)

@@ -677,6 +677,24 @@ __global__ __launch_bounds__(64 * K0_WAVES, (NS > 2 ? 2 : PS_K0_MINW)) void bloc
         bs[0] = make_uint4(ent[0].x, ent[0].y, ent[1].x, ent[1].y);
         bs[1] = make_uint4(ent[2].x, ent[2].y, ent[3].x, ent[3].y);
         if (c.blk_mm) *reinterpret_cast<int4 *>(c.blk_mm + gb4) = make_int4(t[0].z, t[1].z, t[2].z, t[3].z);
+        if (c.blk_cls) {
+            // single-pass file route (the call's one event is the whole trace): the detector's verdict on this lane's four blocks,
+            // 2 bits each, and the extremes of the blocks inside the trace per half wave (seg_device.hpp: edge_cls_kernel)
+            unsigned b2 = 0;
+            const int ythr = c.cls_kthr - load_count<DT>(c, ev_start[0], b2);
+            unsigned cb = 0;
+            int cmn = 0x7fffffff, cmx = -0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < K0_BPT; ++j) {
+                const int lo_j = static_cast<int>(static_cast<short>(t[j].z & 0xffff)), hi_j = t[j].z >> 16;
+                cb |= (hi_j < ythr ? 1u : lo_j >= ythr ? 0u : 2u) << (2 * j);
+                if (gb4 + j < nb_total) { cmn = min(cmn, lo_j); cmx = max(cmx, hi_j); }
+            }
+            c.blk_cls[gb4 >> 2] = static_cast<unsigned char>(cb);
+            cmn = -half_max_i32(-cmn);
+            cmx = half_max_i32(cmx);
+            if ((lane & 31) == 31) c.cls_mm[chunk] = make_int2(cmn, cmx);
+        }
 #if PS_K0_AMP == 2
         if (grp_out) {
             // group record (round 4, second form): the eight lanes 8 g .. 8 g + 7 hold the group's 32 blocks.  Per block b the sum of
@@ -1908,6 +1926,19 @@ __device__ int scan_window_bs(const DevCfg &c, const EvRef &er, int64_t base, in
     return result;
 }
 
+// The window [ps, pe) of an event whose digest is aligned to the TRACE (EvRef::ph = (event start) mod 8 != 0): the same scan in the
+// coordinates of the 8-aligned stretch that starts ph samples before the event -- every position shifted by ph, the sample base
+// by -ph, the event's first block er.boff = floor(start / 8).  All of scan_window_bs is relative arithmetic (n = pe - ps, n_l =
+// J - ps, candidates, the ragged head and tail), so nothing else changes; ph = 0 is the identity.
+template <int DT, bool ROWSKIP = true, bool AUDIT = false>
+__device__ __forceinline__ int scan_window_ph(const DevCfg &c, const EvRef &er, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
+                                              double thresh, SharedT<64> &sh, unsigned &bad, Work &wk)
+{
+    const int ph = er.ph;
+    const int r = scan_window_bs<DT, ROWSKIP, AUDIT>(c, er, base - ph, ps + ph, pe + ph, cand_lo + ph, cand_hi + ph, thresh, sh, bad, wk);
+    return r >= 0 ? r - ph : r;
+}
+
 // ---- K2 from the K0 digest: per-segment statistics without a second pass over the samples ------------------
 // Segment.mean/std/min/max (core.py:209-223).  One wave per segment (workgroups stride over the segments):
 // S1, S2 of the full blocks inside the segment from the chunk prefix and the chunk totals, min/max from the per-block
@@ -1935,14 +1966,16 @@ __global__ __launch_bounds__(64) void segstat_bs_kernel(DevCfg c, const int64_t 
         const int64_t boff = bounds_off[e];
         const int cnt = static_cast<int>(bounds_off[e + 1] - boff);
         const int sidx = static_cast<int>(g - boff - e);
-        const int a = sidx == 0 ? 0 : bounds[boff + sidx - 1];
-        const int b = sidx == cnt ? static_cast<int>(ev_len[e]) : bounds[boff + sidx];
-        const int64_t base = ev_start[e];
+        int a = sidx == 0 ? 0 : bounds[boff + sidx - 1];
+        int b = sidx == cnt ? static_cast<int>(ev_len[e]) : bounds[boff + sidx];
+        int64_t base = ev_start[e];
         const int4 info = c.ev_info[e];
         const int m = info.x;
         const long long eb = (static_cast<long long>(static_cast<unsigned>(info.w)) << 32) | static_cast<unsigned>(info.z);
         const int n = b - a;
         if (a < 0 || b < a || b > ev_len[e]) continue;                     // (never with valid boundaries)
+        // (a trace-aligned digest: the event starts info.y samples into its first block -- shifted coordinates, see scan_window_ph)
+        a += info.y; b += info.y; base -= info.y;
         double s1 = 0.0, s2 = 0.0;                 // sums of y = k - m and y^2 (exact integers)
         int mn = 0x7fffffff, mx = static_cast<int>(0x80000000);
         const int b0 = (a + 7) >> 3, b1 = b >> 3;  // full blocks [b0, b1) of the event

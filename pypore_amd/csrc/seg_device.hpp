@@ -99,6 +99,12 @@ struct DevCfg {
     const int4 *ev_info;    // per event: (m, -, block offset lo, block offset hi)
     const int4 *chunk_tot;  // per chunk of 128 blocks: (S1, max |k-m|, S2 as int64); wide digest: two entries (S1, S2 as int64), (max |k-m|, -, -, -)
     int *blk_mm;            // per block: min / max of k-m as two int16 (written by K0 when statistics are wanted) or nullptr
+    // single-pass file route (ps_detect_segment_trace): K0 over the whole trace also judges every block against the detector's
+    // threshold -- 2 bits per block (0 all at or above, 1 all below, 2 mixed), one byte per lane -- and leaves min / max of k-m
+    // per 128-block chunk; the edge kernel reads those 1/64 of the samples' bytes instead of the samples (nullptr: not asked for)
+    unsigned char *blk_cls;
+    int2 *cls_mm;
+    int cls_kthr;           // below(k) <=> k < cls_kthr (counts; the host derives it from the detector's own predicate, below_thr)
     const void *grp;        // per group of 32 blocks (256 samples; narrow digest): the digest entry of its first block + (D1, D2) as fp32,
                             // the bridge amplitudes of the group bound (seg_bs.hpp); nullptr: no coarse pass
     int bs_wide;            // (host side) the digest is the 64-bit one: kernels compiled for DT | DT_WIDE
@@ -109,7 +115,12 @@ struct DevCfg {
     int rep_eval, rep_stage, rep_sum;   // diagnostics: repeat a phase to measure its marginal cost (normally 1)
 };
 
-struct EvRef { int m; long long boff; };   // what a block-sum window scan needs of its event: centre m (the first count), first block
+// What a block-sum window scan needs of its event: the centre m of the digest's sums, the global index of the block that holds the
+// event's first sample, and -- round 6 -- the PHASE ph = (event start) mod 8 when the digest's blocks are aligned to the TRACE, not to
+// the event (ps_detect_segment_trace: one K0 pass over a whole file trace serves the detector and every event cut out of it).
+// ph = 0 on every other route.  A window [ps, pe) of such an event is the window [ps + ph, pe + ph) of the 8-aligned stretch that
+// starts ph samples earlier: scan_window_ph runs the scan unchanged in those shifted coordinates.
+struct EvRef { int m; long long boff; int ph; };
 
 struct SpineJob {           // speculative spine of one tile: rec(start, end) without left subtrees
     int64_t base;           // offset of the event in the sample array
@@ -129,7 +140,7 @@ struct TreeJob {            // full in-order traversal of rec(start, end), first
     int32_t start, end, j0;
     int32_t out_cap;
     int64_t out_off;        // into the private boundary scratch (int32) and the spill stack (int2)
-    int32_t m, pad_;        // the event's centre (first count) and first block (K0 digest; 0 on the LDS-window path)
+    int32_t m, pad_;        // the event's centre (first count), pad_ = its phase (EvRef::ph), and first block (K0 digest; 0 on the LDS-window path)
     int64_t boff;
 };
 
@@ -1047,7 +1058,7 @@ namespace ps {
 template <int NT, int DT, bool VALIDATE, bool ROWSKIP = true>
 __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int pe, int cand_lo, int cand_hi,
                            double thresh, double *scores, SharedT<NT> &sh, unsigned &bad, Work &wk,
-                           double *best_gain_out = nullptr, int pf_end = 0, const EvRef &er = EvRef{0, 0})
+                           double *best_gain_out = nullptr, int pf_end = 0, const EvRef &er = EvRef{0, 0, 0})
 {
     constexpr int NW = NT / 64;
     const int n = pe - ps;
@@ -1059,7 +1070,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
     }
     if constexpr (NT == 64) {                          // single-wave workgroup: block-sum scan (seg_bs.hpp)
         if (c.bsum != nullptr && scores == nullptr && best_gain_out == nullptr)
-            return scan_window_bs<DT, ROWSKIP>(c, er, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
+            return scan_window_ph<DT, ROWSKIP>(c, er, base, ps, pe, cand_lo, cand_hi, thresh, sh, bad, wk);
     }
     if (c.pre_c != nullptr) {                          // exact route (ps_segment_exact_f64): the reference's own prefix sums, no samples read
         wk.exact += 1;
@@ -1199,7 +1210,7 @@ __device__ int scan_window(const DevCfg &c, int *ys, int64_t base, int ps, int p
 // parent frame, DESIGN.md "memoised left child").
 template <int NT, int DT, bool VALIDATE, bool BSONLY = false, bool ROWSKIP = true>
 __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int end, int j0, int &kind,
-                          SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, const EvRef &er = EvRef{0, 0},
+                          SharedT<NT> &sh, unsigned &bad, Work &wk, long long pf_lim, const EvRef &er = EvRef{0, 0, 0},
                           long long stop_lim = 0x7fffffffffffffffLL, int budget = 0x7fffffff)
 {
     const long long lim = static_cast<long long>(end) - 2LL * c.mw;
@@ -1220,7 +1231,7 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
             if constexpr (BSONLY || NT == 64) {            // (the single-wave kernels exist for the block-sum scan only)
                 static_assert(NT == 64, "block-sum scan: one wave per window");
                 wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1;       // (wave-uniform counters)
-                s = scan_window_bs<DT, ROWSKIP>(c, er, base, static_cast<int>(ps), static_cast<int>(pe),
+                s = scan_window_ph<DT, ROWSKIP>(c, er, base, static_cast<int>(ps), static_cast<int>(pe),
                                                 static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
             } else {
                 s = scan_window<NT, DT, VALIDATE, ROWSKIP>(c, ys, base, static_cast<int>(ps), static_cast<int>(pe),
@@ -1240,10 +1251,11 @@ __device__ int find_split(const DevCfg &c, int *ys, int64_t base, int start, int
 // event constants of a tile job: one load per job (not per window), kept in scalar registers
 __device__ __forceinline__ EvRef ev_ref_of(const DevCfg &c, int ev)
 {
-    EvRef r = {0, 0};
+    EvRef r = {0, 0, 0};
     if (c.bsum != nullptr) {
         const int4 info = c.ev_info[ev];
         r.m = __builtin_amdgcn_readfirstlane(info.x);
+        r.ph = __builtin_amdgcn_readfirstlane(info.y);
         r.boff = (static_cast<long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(info.w))) << 32) |
                  static_cast<unsigned>(__builtin_amdgcn_readfirstlane(info.z));
     }
@@ -1646,7 +1658,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                     if (pe > end) pe = end;
                     if (pe - ps > 2LL * c.mw) {
                         wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1;
-                        val = scan_window_bs<DT>(c, er, job.base, static_cast<int>(ps), static_cast<int>(pe),
+                        val = scan_window_ph<DT>(c, er, job.base, static_cast<int>(ps), static_cast<int>(pe),
                                                  static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
                         if (val >= 0) oc = O_HIT;
                     }
@@ -1742,7 +1754,7 @@ __global__ __launch_bounds__(64 * BR_LA, PS_BRIDGE_MINW) PS_BRIDGE_REGS void bri
                             if (pe > end) pe = end;
                             if (pe - ps > 2LL * c.mw) {
                                 wk.windows += 1; wk.cands += pe - ps - 2LL * c.mw + 1;
-                                val = scan_window_bs<DT>(c, er, job.base, static_cast<int>(ps), static_cast<int>(pe),
+                                val = scan_window_ph<DT>(c, er, job.base, static_cast<int>(ps), static_cast<int>(pe),
                                                          static_cast<int>(ps) + c.mw, static_cast<int>(pe) - c.mw, c.min_gain, sh, bad, wk);
                             }
                         }
@@ -1782,7 +1794,7 @@ __device__ __forceinline__ int tree_job(const DevCfg &c, int *ys, const TreeJob 
     int32_t *out = scratch + job.out_off;
     int2 *sp_glob = spill + job.out_off;
     int start = job.start, end = job.end, j0 = job.j0, sp = 0, cnt = 0, flushed = 0;
-    const EvRef er = {job.m, job.boff};
+    const EvRef er = {job.m, job.boff, job.pad_};       // (pad_: the event's phase, assemble_items_kernel)
     int *obuf = reinterpret_cast<int *>(sh.obuf);
     constexpr int OB = 2 * SharedT<NT>::OB;
     auto emit = [&](int v) {
@@ -1993,7 +2005,7 @@ __global__ __launch_bounds__(64 * PAR_W, 2) void tree_par_kernel(DevCfg c, const
         }
         for (int i = 1 + threadIdx.x; i < PAR_QN; i += 64 * PAR_W) Q.ready[i] = 0;
         __syncthreads();
-        const EvRef er = {job.m, job.boff};
+        const EvRef er = {job.m, job.boff, job.pad_};
         for (;;) {
             // a ticket, then its interval -- or the end of the job
             int t = 0;
@@ -2428,6 +2440,7 @@ __global__ __launch_bounds__(256) void assemble_items_kernel(
     if (ev_info) {
         const int4 info = ev_info[jb2.ev];
         tj.m = info.x;
+        tj.pad_ = info.y;                                    // the event's phase (0 unless the digest is trace-aligned)
         tj.boff = (static_cast<long long>(static_cast<unsigned>(info.w)) << 32) | static_cast<unsigned>(info.z);
     } else { tj.m = 0; tj.boff = 0; }
     tjobs[i] = tj;
@@ -2546,6 +2559,116 @@ __global__ __launch_bounds__(256) void piece_minmax_kernel(DevCfg c, const int2 
         int a = smin[0], b = smax[0];
         for (int w = 1; w < 4; ++w) { a = min(a, smin[w]); b = max(b, smax[w]); }
         mm[blockIdx.x] = make_int2(a, b);
+    }
+}
+
+// The detector of the single-pass file route (round 6): K0 ran over the whole trace as one event and judged every 8-sample block
+// against the threshold (DevCfg::blk_cls: 0 all at or above, 1 all below, 2 mixed -- 2 bits per block, 3 MB per 1e8 samples) and
+// left min / max per 128 blocks (DevCfg::cls_mm).  A thread takes 64 blocks (16 bytes of classes): uniform and equal to the
+// block before them -- nearly always -- there is nothing to do.  Else: a block whose samples lie on one side is judged by its
+// class; a mixed one (the slopes of the events, a handful per 1e8 samples) by its 8 samples, with the detector's own predicate
+// (below_thr).  Position i (an edge sits at i when below(i) != below(i-1), parsers.py:142-147) is judged exactly once: by its own
+// block when that is mixed, by the mixed block before it when its own is not, by the class comparison when neither is.  Output as
+// edge_scan_kernel's: the edge list and min / max (counts) per DET_CHUNK samples.
+constexpr int CLS_NT = 256;
+template <int DT>
+__global__ __launch_bounds__(CLS_NT) void edge_cls_kernel(DevCfg c, int64_t n, double thr, const unsigned char *cls, const int2 *cls_mm,
+                                                          const int4 *ev_info0, int *tics, unsigned *n_tics, unsigned tics_cap,
+                                                          int2 *chunk_mm, unsigned *status)
+{
+    const long long nb = (n + 7) >> 3;
+    const long long tid = static_cast<long long>(blockIdx.x) * CLS_NT + threadIdx.x;
+    const int m = ev_info0[0].x;                        // the trace's centre: K0 wrote it
+    unsigned bad = 0;
+    auto emit = [&](long long i) {
+        const unsigned o = atomicAdd(n_tics, 1u);
+        if (o < tics_cap) tics[o] = static_cast<int>(i);
+    };
+    const long long b0 = 64 * tid;
+    uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+    int prev_cls = -1;
+    bool quiet = true;
+    if (b0 < nb) {
+        w4 = reinterpret_cast<const uint4 *>(cls)[tid];
+        prev_cls = b0 > 0 ? (cls[(b0 >> 2) - 1] >> 6) & 3 : -1;
+        const unsigned pat = prev_cls == 1 ? 0x55555555u : 0u;
+        quiet = prev_cls >= 0 && prev_cls != 2 && b0 + 64 <= nb && w4.x == pat && w4.y == pat && w4.z == pat && w4.w == pat;
+    }
+#ifdef PS_DIAG
+    if (c.rep_stage == 7) quiet = true;                 // (experiments: what the kernel costs without its slow path)
+#endif
+    // The lanes whose 64 blocks hold an edge (a few hundred per 1e8 samples) are served one after the other BY THE WHOLE WAVE, a
+    // block per lane: left to itself such a lane would walk its 64 blocks alone -- ~4 000 instructions of one lane in a wave
+    // that issues one every few cycles, 26 of the kernel's 31 us (measured, docs/ROUND_6.md).
+    const int lane = threadIdx.x & 63;
+    unsigned long long need = __ballot(!quiet);
+    while (need) {
+        const int src = __ffsll(static_cast<long long>(need)) - 1;
+        need &= need - 1;
+        const unsigned x0 = __shfl(w4.x, src), x1 = __shfl(w4.y, src), x2 = __shfl(w4.z, src), x3 = __shfl(w4.w, src);
+        const int sprev = __shfl(prev_cls, src);
+        const long long sb0 = 64 * (tid - lane + src);
+        const long long b = sb0 + lane;
+        if (b < nb) {
+            auto cls_j = [&](int j) -> int {                // class of block sb0 + j, 0 <= j < 64
+                const int q = j >> 4;
+                const unsigned wq = q == 0 ? x0 : q == 1 ? x1 : q == 2 ? x2 : x3;
+                return (wq >> (2 * (j & 15))) & 3;
+            };
+            const int cb = cls_j(lane);
+            const int cp = lane > 0 ? cls_j(lane - 1) : sprev;               // (-1: there is no block before the trace's first)
+            if (cb != 2) {
+                if (cp >= 0 && cp != 2 && cp != cb) emit(8 * b);
+            } else {
+                const long long i0 = 8 * b, i1 = min(i0 + 8, static_cast<long long>(n));
+                int k[9];                                   // the block's samples and the one before them: loaded together, judged afterwards
+    #pragma unroll
+                for (int u = 0; u < 9; ++u) k[u] = (i0 + u - 1 >= 0 && i0 + u - 1 < i1) ? load_count<DT>(c, i0 + u - 1, bad) : 0;
+                bool prev = i0 > 0 ? below_thr<DT>(c, k[0], thr) : false;
+    #pragma unroll
+                for (int u = 1; u < 9; ++u) {
+                    const long long i = i0 + u - 1;
+                    if (i < i1) {
+                        const bool mi = below_thr<DT>(c, k[u], thr);
+                        if (i > 0 && mi != prev) emit(i);
+                        prev = mi;
+                    }
+                }
+                if (b + 1 < nb) {
+                    const int cn = lane < 63 ? cls_j(lane + 1) : (cls[(b + 1) >> 2] >> (2 * ((b + 1) & 3))) & 3;
+                    if (cn != 2 && (cn == 1) != prev) emit(i0 + 8);
+                }
+            }
+        }
+    }
+    // min / max per DET_CHUNK samples from K0's per 128 blocks (blocks beyond the trace were left out there)
+    constexpr int KPC = DET_CHUNK / (8 * BS_CHUNK);     // K0 chunks per detector chunk
+    const long long n_det = (n + DET_CHUNK - 1) / DET_CHUNK;
+    if (tid < n_det) {
+        int a = 0x7fffffff, z = static_cast<int>(0x80000000);
+        for (int k = 0; k < KPC; ++k) {
+            const long long kc = tid * KPC + k;
+            if (kc * BS_CHUNK < nb) { const int2 mm = cls_mm[kc]; a = min(a, mm.x); z = max(z, mm.y); }
+        }
+        chunk_mm[tid] = make_int2(a + m, z + m);
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+// start of the single-pass call: the status block cleared and the one-event table of the whole trace, in one launch
+__global__ __launch_bounds__(256) void trace_setup_kernel(unsigned long long *small, int n_words, long long *ev, long long n, long long nb)
+{
+    for (int i = threadIdx.x; i < n_words; i += 256) small[i] = 0ull;
+    if (threadIdx.x == 0) { ev[0] = 0; ev[1] = n; ev[2] = 0; ev[3] = nb; }    // ev_off[0], ev_len[0], ev_boff[0..1]
+}
+
+// the events cut out of a trace whose digest is trace-aligned: (centre of the trace, phase, first block) per event
+__global__ __launch_bounds__(256) void ev_info_trace_kernel(const int64_t *ev_start, int n_ev, const int4 *ev_info0, int4 *ev_info)
+{
+    const int m = ev_info0[0].x;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n_ev; e += gridDim.x * 256) {
+        const long long s0 = ev_start[e], b = s0 >> 3;
+        ev_info[e] = make_int4(m, static_cast<int>(s0 & 7), static_cast<int>(b & 0xffffffffLL), static_cast<int>(b >> 32));
     }
 }
 

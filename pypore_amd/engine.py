@@ -33,9 +33,9 @@ _ENV_OPTIONS = {
     "PORESEG_UPLOAD": "upload_by_kernel", "PORESEG_TIMING": "timing", "PORESEG_TREE_MW": "tree_mw",
     "PORESEG_TREE_JPW": "tree_jobs_per_wave", "PORESEG_SLOTS_PCT": "slots_pct", "PORESEG_BRIDGE_EXT": "bridge_ext",
     "PORESEG_LAT_HELP": "lat_help", "PORESEG_BRIDGE_BUDGET": "bridge_budget", "PORESEG_DEBUG": "debug",
-    "PORESEG_GATHER_FUSED": "gather_fused", "PORESEG_DOWNLOAD": "download_by_kernel", "PORESEG_K0_UNALIGNED": "k0_unaligned",
+    "PORESEG_GATHER_FUSED": "gather_fused", "PORESEG_SINGLE_PASS": "single_pass", "PORESEG_DOWNLOAD": "download_by_kernel", "PORESEG_K0_UNALIGNED": "k0_unaligned",
     # libporeseg_diag.so only (PORESEG_LIB=.../libporeseg_diag.so): stale or partial results, never the product
-    "PORESEG_DBG_PHASE": "dbg_phase", "PORESEG_DBG_K0_NOGRP": "dbg_k0_nogrp", "PORESEG_SCAN_LDS_PAD": "scan_lds_pad",
+    "PORESEG_DBG_PHASE": "dbg_phase", "PORESEG_DBG_K0_NOGRP": "dbg_k0_nogrp", "PORESEG_SCAN_LDS_PAD": "scan_lds_pad", "PORESEG_REP_STAGE": "rep_stage",
 }
 
 
@@ -141,7 +141,8 @@ class Context(object):
     def near_ties(self):
         """Windows of the most recent segment call that were decided among fp64 contenders with a margin inside the
         noise of the device logarithm against glibc's (1e-9 relative): the reference could have decided
-        them the other way.  0 in every golden vector except the constructed exact tie."""
+        them the other way.  0 in every golden vector except the constructed exact tie.  -1: the call ran on the LDS-window
+        kernels, which do not count them (callers that redo near ties on the exact route treat it as "some")."""
         if not hasattr(self, "_cnt"):
             self._cnt = self.L.ps_counters(self.handle)      # the context's counters in place: no call per look
         return int(self._cnt[11])
@@ -188,7 +189,7 @@ class Context(object):
         _lib.check(rc, self.handle)
         if NEAR_TIE_WARNING:
             nt = self.near_ties()
-            if nt:
+            if nt > 0:
                 import warnings
                 warnings.warn("%d window(s) were decided by a margin inside the reference's own rounding noise (near tie: below 1e-9 "
                               "relative on grid data -- the logarithm's last bit; on re-quantised float64 data, e.g. a filtered event, "
@@ -225,6 +226,34 @@ class Context(object):
                                            st.ctypes.data_as(P64), ln.ctypes.data_as(P64), cap, ctypes.byref(cnt)),
                    self.handle)
         return st[:cnt.value].copy(), ln[:cnt.value].copy()
+
+    @_serialised
+    def detect_segment_trace(self, samples, quantum, params, threshold=90.0, min_duration=100000, min_current=-0.5,
+                             offset_counts=0, want_stats=False):
+        """ps_detect_segment_trace: detect_events + segment_events of a device-resident file trace in one call and one pass
+        over its samples (include/poreseg.h).  Returns (starts, lengths, bounds, bounds_off, stats or None)."""
+        assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
+        fmt = self._fmt(samples, quantum, offset_counts)
+        n = samples.numel()
+        ev_cap = n // max(1, int(min_duration)) + 2
+        cap = n // int(params.min_width) + ev_cap + 1
+        st = np.zeros(ev_cap, dtype=np.int64)
+        ln = np.zeros(ev_cap, dtype=np.int64)
+        boff = np.zeros(ev_cap + 1, dtype=np.int64)
+        cnt = ctypes.c_int64()
+        dev = samples.device
+        bounds = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        stats = torch.empty((max(cap, 1) + ev_cap, 4), dtype=torch.float64, device=dev) if want_stats else None
+        P64 = ctypes.POINTER(ctypes.c_int64)
+        torch.cuda.current_stream(dev).synchronize()
+        _lib.check(self.L.ps_detect_segment_trace(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), n,
+                                                  float(threshold), int(min_duration), float(min_current), ctypes.byref(params),
+                                                  st.ctypes.data_as(P64), ln.ctypes.data_as(P64), ev_cap, ctypes.byref(cnt),
+                                                  ctypes.c_void_p(bounds.data_ptr()), cap, boff.ctypes.data_as(P64),
+                                                  ctypes.c_void_p(stats.data_ptr()) if want_stats else None), self.handle)
+        n_ev = int(cnt.value)
+        total = int(boff[n_ev])
+        return st[:n_ev].copy(), ln[:n_ev].copy(), bounds[:total], boff[:n_ev + 1].copy(), (stats[:total + n_ev] if want_stats else None)
 
     @_serialised
     def segment_events(self, samples, ev_start, ev_len, params, quantum, offset_counts=0, want_stats=False):

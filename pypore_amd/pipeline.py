@@ -8,16 +8,22 @@ from . import _lib, engine
 
 
 def segment_file_trace(samples, quantum, params=None, threshold=90.0, min_duration=100000, min_current=-0.5,
-                       offset_counts=0, device=None, want_stats=False, offset=0.0, ctx=None):
+                       offset_counts=0, device=None, want_stats=False, offset=0.0, ctx=None, single_pass=True):
     """samples: 1-D CUDA tensor (float32 pA on the `quantum` grid, or int16 ADC counts); pA = (count + offset_counts)
     * quantum + offset (`offset`: the part of an .abf offset that is not a whole number of counts; the detector's
     thresholds move by it, the segmenter's gains do not depend on it).
+    single_pass=False: the two calls ps_detect_events + ps_segment_events (two passes over the samples), as until round 5.
     Returns (ev_start, ev_len, bounds int32 CUDA tensor, bounds_off, stats or None)."""
     ctx = ctx or engine.context(device)
     if params is None:
         params = _lib.split_params(prior_segments_per_second=10.)
-    st, ln = ctx.detect_events(samples, quantum, threshold - offset, min_duration, min_current - offset, offset_counts)
-    bounds, boff, stats = ctx.segment_events(samples, st, ln, params, quantum, offset_counts, want_stats)
+    if single_pass:
+        # one library call, one pass over the samples: K0 over the whole trace serves the detector and every event (round 6)
+        st, ln, bounds, boff, stats = ctx.detect_segment_trace(samples, quantum, params, threshold - offset, min_duration,
+                                                               min_current - offset, offset_counts, want_stats)
+    else:
+        st, ln = ctx.detect_events(samples, quantum, threshold - offset, min_duration, min_current - offset, offset_counts)
+        bounds, boff, stats = ctx.segment_events(samples, st, ln, params, quantum, offset_counts, want_stats)
     if stats is not None and offset:
         stats[:, 0] += offset; stats[:, 2] += offset; stats[:, 3] += offset
     return st, ln, bounds, boff, stats

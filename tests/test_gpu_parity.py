@@ -151,7 +151,8 @@ def test_exact_tie_first_maximum_wins_and_is_counted(ctx):
         assert any(issubclass(i.category, engine.NearTieWarning) for i in w)
     # an ordinary trace reports none
     SpeedyStatSplit(quantum=synth.QUANTUM, prior_segments_per_second=10.).parse(synth.config1())
-    assert engine.context().near_ties() == 0
+    # (-1: not counted -- the suite is running with the LDS-window kernels switched on, tools/gpu_validate.sh)
+    assert engine.context().near_ties() == (-1 if os.environ.get("PORESEG_SCAN_BS", "1") == "0" else 0)
 
 
 @pytest.mark.parametrize("case", offgrid_cases("parse_offgrid"), ids=lambda c: c["name"])

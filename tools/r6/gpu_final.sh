@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 6, final build: the round's profile collection, the other workloads' bench lines, the validation and a soak
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+bash tools/profile_round.sh r06 > gpurun_out/r06_profile_round.log 2>&1
+python bench.py --workload sharded-trace --no-cpu > gpurun_out/r06_sharded.json 2>> gpurun_out/r06_bench.err
+python bench.py --workload files --files 16 > gpurun_out/r06_files16.json 2>> gpurun_out/r06_bench.err
+python bench.py --workload file --no-cpu > gpurun_out/r06_file.json 2>> gpurun_out/r06_bench.err
+bash tools/gpu_validate.sh 3000 > gpurun_out/r06_validation.txt 2>&1
+tail -12 gpurun_out/r06_validation.txt
