@@ -85,8 +85,8 @@ def test_single_pass_edge_cases(case, ctx):
         params = _lib.split_params(prior_segments_per_second=10., min_width=2, max_width=100000, window_width=500)
     else:
         c = _trace(43, 700000)
-        oc = 1234                                            # ADC zero offset in counts: samples = (counts - oc) * quantum
-        c = c + oc
+        oc = 1234                                            # ps_sample_format.offset_counts: pA = (raw value + oc) * quantum
+        c = c - oc
     t = torch.from_numpy(c.astype(np.int16)).cuda()
     if case == "empty":
         st, ln, b, off, _ = ctx.detect_segment_trace(t, synth.QUANTUM, params, **kw)
