@@ -1916,7 +1916,7 @@ int events_from_edges(ps_ctx *ctx, const DevCfg &cfg, int64_t n, std::vector<int
 }
 
 // One streaming pass that leaves the edge list in `tics` and min / max per DET_CHUNK samples in det_counts.  by_blocks = false:
-// edge_scan_kernel over the samples; true (ps_detect_segment_trace): edge_blocks_kernel over the per-block extremes K0 left.
+// edge_scan_kernel over the samples; true (ps_detect_segment_trace): edge_cls_kernel over the per-block verdicts K0 left.
 int detect_edges(ps_ctx *ctx, const DevCfg &cfg, int64_t n, double threshold, bool by_blocks, std::vector<int> &tics,
                  unsigned *status_out)
 {
@@ -1992,10 +1992,11 @@ int ps_detect_events(ps_ctx *ctx, const void *d_samples, const ps_sample_format 
 // File.parse + Event.parse for a whole file trace with ONE pass over its samples (round 6).  The two calls
 // ps_detect_events + ps_segment_events stream the samples twice: once for the detector's edges and extremes, once -- the 92 %
 // of them that lie in events -- for K0's block sums.  Here K0 runs over the WHOLE trace as one event (its blocks aligned to the
-// trace, per-block extremes on), the detector reads those 4 bytes per block instead of the samples (edge_blocks_kernel), and the
+// trace) and judges every block against the detector's threshold on its way (DevCfg::blk_cls: 2 bits per block, min / max per 128
+// blocks), the detector reads those bits -- 1/64 of the samples' bytes -- instead of the samples (edge_cls_kernel), and the
 // events it cuts out -- they start at any sample -- are segmented from the same digest: an event that starts ph = start mod 8
 // samples into a block is scanned in coordinates shifted by ph (EvRef::ph, scan_window_ph).  Same events, same boundaries, same
-// statistics as the two calls (tests/test_gpu_parity.py::test_single_pass_file_route...).  Falls back to the two calls by itself
+// statistics (to the last bits of the final fp64 expressions) as the two calls (tests/test_single_pass.py, tools/r6/fuzz_single_pass.py).  Falls back to the two calls by itself
 // when the block-sum scan does not apply (min_width < 8, W > 64 512, options) or the trace's counts leave the 32-bit digest
 // about its first sample (|k - k_0| >= 2^14: the sums are centred on the trace's first sample here, not on each event's).
 int ps_detect_segment_trace(ps_ctx *ctx, const void *d_samples, const ps_sample_format *fmt, int64_t n,

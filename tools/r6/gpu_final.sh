@@ -6,4 +6,7 @@ python bench.py --workload sharded-trace --no-cpu > gpurun_out/r06_sharded.json 
 python bench.py --workload files --files 16 > gpurun_out/r06_files16.json 2>> gpurun_out/r06_bench.err
 python bench.py --workload file --no-cpu > gpurun_out/r06_file.json 2>> gpurun_out/r06_bench.err
 bash tools/gpu_validate.sh 3000 > gpurun_out/r06_validation.txt 2>&1
-tail -12 gpurun_out/r06_validation.txt
+tail -14 gpurun_out/r06_validation.txt | cut -c1-300
+FUZZ_BASE=9600000 bash tools/gpu_soak.sh 6000 4000 > gpurun_out/r06_soak_final.txt 2>&1
+timeout 900 python tools/r6/fuzz_single_pass.py 3000 50000 >> gpurun_out/r06_soak_final.txt 2>&1
+tail -9 gpurun_out/r06_soak_final.txt | cut -c1-300
