@@ -824,31 +824,37 @@ def main():
             def fstep(cx, k, t):
                 return pipeline.segment_file_trace(ftraces[t], synth.QUANTUM, params, threshold=90.0, ctx=cx)[2]
 
+            def timed3(k_, job):
+                """Three repetitions of k_ pool jobs: (median seconds per job, all three in ms, the last results) -- a side
+                measurement of a few milliseconds is at the mercy of one hiccup of the box; the median is not."""
+                ts, res = [], None
+                for _ in range(3):
+                    t1_ = time.perf_counter()
+                    res = pool.run(k_, job)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1_) / k_)
+                return sorted(ts)[1], [round(x * 1e3, 4) for x in ts], res
+
             pool.run(2 * T, fstep)
             torch.cuda.synchronize()
             kf = 40                                      # (its own step count: a side measurement outside the timed region)
-            t1 = time.perf_counter()
-            fres = pool.run(kf, fstep)
-            torch.cuda.synchronize()
-            tf = (time.perf_counter() - t1) / kf
+            tf, tf_runs, fres = timed3(kf, fstep)
 
             def fstep2(cx, k, t):                        # the two calls of rounds 3-5 (two passes over the samples), for comparison
                 return pipeline.segment_file_trace(ftraces[t], synth.QUANTUM, params, threshold=90.0, ctx=cx, single_pass=False)[2]
 
-            fres2 = pool.run(2 * T, fstep2)
+            pool.run(2 * T, fstep2)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            pool.run(kf, fstep2)
-            torch.cuda.synchronize()
-            tf2 = (time.perf_counter() - t1) / kf
-            same_two = bool(torch.equal(fres[-1], fres2[(kf - 1) % T]))     # (job k runs on trace k % T)
+            tf2, tf2_runs, fres2 = timed3(kf, fstep2)
+            same_two = bool(torch.equal(fres[-1], fres2[-1]))
             out["int16_file"] = {
                 "workload": "BASELINE config 3: one %.0e-sample int16 .abf-shaped trace per stream @100 kHz, lambda_event_parser("
                             "threshold=90) -> per-event SpeedyStatSplit, end to end on the GPU, %d batches in flight" % (n, T),
                 "ms_per_step": round(tf * 1e3, 4), "value": round(n / tf / 1e6, 2), "unit": "Msamples/s", "steps": kf,
+                "repetitions_ms": tf_runs, "how": "median of three repetitions of %d steps" % kf,
                 "boundaries": int(fres[-1].numel()),
                 "route": "ps_detect_segment_trace: one pass over the samples (K0 over the whole trace serves the detector and every event)",
-                "two_calls_ms_per_step": round(tf2 * 1e3, 4), "two_calls_same_boundaries": same_two,
+                "two_calls_ms_per_step": round(tf2 * 1e3, 4), "two_calls_repetitions_ms": tf2_runs, "two_calls_same_boundaries": same_two,
                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": 2 * n, "achieved": round(2 * n / tf / 1e9, 2),
                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(2 * n / tf / HBM_PEAK, 5)}}
             del ftraces
@@ -865,13 +871,16 @@ def main():
             for _ in range(3):
                 b2, o2, _ = ctx.segment_batch(t2_, off2, params, synth.QUANTUM, want_stats=False)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            s2 = 0.0
-            for _ in range(20):
-                b2, o2, _ = ctx.segment_batch(t2_, off2, params, synth.QUANTUM, want_stats=False)
-                s2 += ctx.seq_ms()
-            torch.cuda.synchronize()
-            tc2 = (time.perf_counter() - t1) / 20
+            c2_runs = []
+            for _ in range(3):                           # (median of three repetitions of 20 calls, like timed3)
+                t1 = time.perf_counter()
+                s2 = 0.0
+                for _ in range(20):
+                    b2, o2, _ = ctx.segment_batch(t2_, off2, params, synth.QUANTUM, want_stats=False)
+                    s2 += ctx.seq_ms()
+                torch.cuda.synchronize()
+                c2_runs.append(((time.perf_counter() - t1) / 20, s2))
+            tc2, s2 = sorted(c2_runs)[1]
             # the same batch shape with T batches in flight, each on its own events (noise seeds differ), like the headline
             # and `int16_file`: what a caller with more than one batch gets out of the pool
             t2s = [t2_] + [ctx.synth_trace(n_ev2 * ln2, 7 + 13 * t_, np.array(e2), np.array(l2, dtype=np.int32), dtype=torch.float32)
@@ -883,18 +892,23 @@ def main():
             pool.run(2 * T, c2step)
             torch.cuda.synchronize()
             k2 = 48
-            t1 = time.perf_counter()
-            o2s = pool.run(k2, c2step)
-            torch.cuda.synchronize()
-            tp2 = (time.perf_counter() - t1) / k2
+            tp2_runs, o2s = [], None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                o2s = pool.run(k2, c2step)
+                torch.cuda.synchronize()
+                tp2_runs.append((time.perf_counter() - t1) / k2)
+            tp2 = sorted(tp2_runs)[1]
             out["config2"] = {
                 "workload": "BASELINE config 2: %d events x %d samples (5 levels x 10 000 each), one ps_segment_batch, one call at a time" % (n_ev2, ln2),
                 "ms_per_step": round(tc2 * 1e3, 4), "sequence_ms": round(s2 / 20, 4), "value": round(n_ev2 * ln2 / tc2 / 1e6, 2),
-                "unit": "Msamples/s", "steps": 20, "boundaries": int(b2.numel()),
+                "unit": "Msamples/s", "steps": 20, "repetitions_ms": [round(x[0] * 1e3, 4) for x in c2_runs],
+                "how": "median of three repetitions of 20 calls", "boundaries": int(b2.numel()),
                 "events_with_exactly_their_four_steps": int(np.sum(np.diff(o2) == 4)),
                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": 4 * n_ev2 * ln2, "achieved": round(4 * n_ev2 * ln2 / tc2 / 1e9, 2),
                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(4 * n_ev2 * ln2 / tc2 / HBM_PEAK, 5)},
                 "in_flight": {"batches_in_flight": T, "steps": k2, "ms_per_step": round(tp2 * 1e3, 4),
+                              "repetitions_ms": [round(x * 1e3, 4) for x in tp2_runs],
                               "value": round(n_ev2 * ln2 / tp2 / 1e6, 2), "unit": "Msamples/s",
                               "frac": round(4 * n_ev2 * ln2 / tp2 / HBM_PEAK, 5),
                               "events_with_exactly_their_four_steps_min": int(min(np.sum(np.diff(o_) == 4) for o_ in o2s))}}

@@ -20,7 +20,9 @@ echo "GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES" > $ROOT/gpurun_out/${TAG}_profile_en
 cd /tmp
 for s in 16 1; do
   rm -rf /tmp/kstats
-  rocprofv3 --kernel-trace --stats -d /tmp/kstats -o out --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-h2d --streams $s > /tmp/kstats_$s.log 2>&1
+  # (--no-detail since round 6: without it the line's side workloads -- config 2, config 3 -- launch the same kernels on other
+  #  shapes and their durations are averaged into the headline's: K0 of a 5.12e7-sample batch takes half as long)
+  rocprofv3 --kernel-trace --stats -d /tmp/kstats -o out --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-h2d --no-detail --streams $s > /tmp/kstats_$s.log 2>&1
   out=$ROOT/gpurun_out/${TAG}_kernel_stats.csv
   [ $s = 1 ] && out=$ROOT/gpurun_out/${TAG}_s1_kernel_stats.csv
   cp $(find /tmp/kstats -name '*kernel_stats.csv' | head -1) $out
