@@ -25,6 +25,8 @@ DEFAULT_TILING = [0, 0]
 # options a StreamPool applies to its contexts on top of "shared_device" while it runs (experiments: tools/)
 POOL_OVERRIDES = {}
 
+EVENT_CAP = 1 << 16      # events the detector's host arrays hold at first (Context.detect_events / detect_segment_trace grow them when a trace has more)
+
 _ENV_OPTIONS = {
     "PORESEG_MODE": "mode", "PORESEG_SPINE_NT": "spine_nt", "PORESEG_TREE_NT": "tree_nt", "PORESEG_PRUNE": "prune",
     "PORESEG_SCAN_BS": "scan_bs", "PORESEG_GROUPS": "groups", "PORESEG_TREE_PAR": "tree_par", "PORESEG_K0_WAVES": "k0_waves",
@@ -215,17 +217,23 @@ class Context(object):
         assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
         fmt = self._fmt(samples, quantum, offset_counts)
         n = samples.numel()
-        cap = n // max(1, int(min_duration)) + 2
-        st = np.zeros(cap, dtype=np.int64)
-        ln = np.zeros(cap, dtype=np.int64)
+        # (room for every event the rules can keep is n / min_duration + 2 -- gigabytes of host memory for a long trace and a
+        #  small min_duration; a file has a few hundred: start with EVENT_CAP and take the count the library reports if it is more)
+        cap = min(n // max(1, int(min_duration)) + 2, EVENT_CAP)
         cnt = ctypes.c_int64()
         torch.cuda.current_stream(samples.device).synchronize()
         P64 = ctypes.POINTER(ctypes.c_int64)
-        _lib.check(self.L.ps_detect_events(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), n,
-                                           float(threshold), int(min_duration), float(min_current),
-                                           st.ctypes.data_as(P64), ln.ctypes.data_as(P64), cap, ctypes.byref(cnt)),
-                   self.handle)
-        return st[:cnt.value].copy(), ln[:cnt.value].copy()
+        while True:
+            st = np.zeros(cap, dtype=np.int64)
+            ln = np.zeros(cap, dtype=np.int64)
+            rc = self.L.ps_detect_events(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), n,
+                                         float(threshold), int(min_duration), float(min_current),
+                                         st.ctypes.data_as(P64), ln.ctypes.data_as(P64), cap, ctypes.byref(cnt))
+            if rc == _lib.PS_ERR_CAPACITY and cnt.value > cap:
+                cap = int(cnt.value)
+                continue
+            _lib.check(rc, self.handle)
+            return st[:cnt.value].copy(), ln[:cnt.value].copy()
 
     @_serialised
     def detect_segment_trace(self, samples, quantum, params, threshold=90.0, min_duration=100000, min_current=-0.5,
@@ -235,22 +243,29 @@ class Context(object):
         assert samples.is_cuda and samples.is_contiguous() and samples.dim() == 1
         fmt = self._fmt(samples, quantum, offset_counts)
         n = samples.numel()
-        ev_cap = n // max(1, int(min_duration)) + 2
-        cap = n // int(params.min_width) + ev_cap + 1
-        st = np.zeros(ev_cap, dtype=np.int64)
-        ln = np.zeros(ev_cap, dtype=np.int64)
-        boff = np.zeros(ev_cap + 1, dtype=np.int64)
+        ev_cap = min(n // max(1, int(min_duration)) + 2, EVENT_CAP)      # (see detect_events)
         cnt = ctypes.c_int64()
         dev = samples.device
-        bounds = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-        stats = torch.empty((max(cap, 1) + ev_cap, 4), dtype=torch.float64, device=dev) if want_stats else None
         P64 = ctypes.POINTER(ctypes.c_int64)
         torch.cuda.current_stream(dev).synchronize()
-        _lib.check(self.L.ps_detect_segment_trace(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), n,
-                                                  float(threshold), int(min_duration), float(min_current), ctypes.byref(params),
-                                                  st.ctypes.data_as(P64), ln.ctypes.data_as(P64), ev_cap, ctypes.byref(cnt),
-                                                  ctypes.c_void_p(bounds.data_ptr()), cap, boff.ctypes.data_as(P64),
-                                                  ctypes.c_void_p(stats.data_ptr()) if want_stats else None), self.handle)
+        while True:
+            # (every event holds at most length / min_width boundaries, all of them together n / min_width)
+            cap = n // int(params.min_width) + 1
+            st = np.zeros(ev_cap, dtype=np.int64)
+            ln = np.zeros(ev_cap, dtype=np.int64)
+            boff = np.zeros(ev_cap + 1, dtype=np.int64)
+            bounds = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            stats = torch.empty((max(cap, 1) + ev_cap, 4), dtype=torch.float64, device=dev) if want_stats else None
+            rc = self.L.ps_detect_segment_trace(self.handle, ctypes.c_void_p(samples.data_ptr()), ctypes.byref(fmt), n,
+                                                float(threshold), int(min_duration), float(min_current), ctypes.byref(params),
+                                                st.ctypes.data_as(P64), ln.ctypes.data_as(P64), ev_cap, ctypes.byref(cnt),
+                                                ctypes.c_void_p(bounds.data_ptr()), cap, boff.ctypes.data_as(P64),
+                                                ctypes.c_void_p(stats.data_ptr()) if want_stats else None)
+            if rc == _lib.PS_ERR_CAPACITY and cnt.value > ev_cap:        # more events than EVENT_CAP: once more with room for all
+                ev_cap = int(cnt.value)
+                continue
+            _lib.check(rc, self.handle)
+            break
         n_ev = int(cnt.value)
         total = int(boff[n_ev])
         return st[:n_ev].copy(), ln[:n_ev].copy(), bounds[:total], boff[:n_ev + 1].copy(), (stats[:total + n_ev] if want_stats else None)

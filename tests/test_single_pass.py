@@ -146,3 +146,25 @@ def test_single_pass_wide_range_trace_takes_the_two_calls(ctx):
     np.testing.assert_array_equal(st, st2)
     np.testing.assert_array_equal(ln, ln2)
     np.testing.assert_array_equal(b.cpu().numpy(), b2.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_more_events_than_the_first_capacity_grow_the_host_arrays(ctx, monkeypatch):
+    """Context.detect_events / detect_segment_trace start with room for engine.EVENT_CAP events (not n / min_duration: gigabytes
+    for a long trace and a small min_duration) and take the library's count when a trace has more (PS_ERR_CAPACITY)."""
+    import torch
+    from pypore_amd import engine
+    c = _trace(46, 1_500_000)
+    t = torch.from_numpy(c.astype(np.int16)).cuda()
+    params = _lib.split_params(prior_segments_per_second=10.)
+    ref = ctx.detect_segment_trace(t, synth.QUANTUM, params, threshold=90.0, min_duration=1000)
+    ref_ev = ctx.detect_events(t, synth.QUANTUM, threshold=90.0, min_duration=1000)
+    assert len(ref[0]) >= 5
+    monkeypatch.setattr(engine, "EVENT_CAP", 3)
+    got = ctx.detect_segment_trace(t, synth.QUANTUM, params, threshold=90.0, min_duration=1000)
+    got_ev = ctx.detect_events(t, synth.QUANTUM, threshold=90.0, min_duration=1000)
+    np.testing.assert_array_equal(got_ev[0], ref_ev[0])
+    np.testing.assert_array_equal(got_ev[1], ref_ev[1])
+    for a, z in zip(got[:2] + (got[3],), ref[:2] + (ref[3],)):
+        np.testing.assert_array_equal(a, z)
+    np.testing.assert_array_equal(got[2].cpu().numpy(), ref[2].cpu().numpy())
